@@ -1,0 +1,288 @@
+"""ctypes mirror of ``include/hwy_engine.h`` (POD types + constants) and the
+derivation of the flat ``hwy_config`` from a reference-style config dict.
+
+Reference for the dict: ``HighwayEnv.default_config`` (highway_env/envs/highway_env.py:25-53),
+``HighwayEnvFast.default_config`` (:162-175), ``AbstractEnv.default_config``
+(envs/common/abstract.py:101-125), ``KinematicObservation.__init__``
+(envs/common/observation.py:160-197).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import numpy as np
+
+HWY_ABI_VERSION = 1
+HWY_MAX_AGENTS = 16
+HWY_MAX_FEATURES = 16
+HWY_MAX_TARGET_SPEEDS = 8
+HWY_MAX_LANES = 16
+HWY_MAX_VEHICLES = 256
+
+# hwy_status
+HWY_OK, HWY_ERR_INVALID_ARG, HWY_ERR_HIP, HWY_ERR_UNSUPPORTED, HWY_ERR_NO_DEVICE, HWY_ERR_ACTION = 0, -1, -2, -3, -4, -5
+
+# per-vehicle flags
+F_CRASHED, F_HAS_IMPACT, F_CHECK_COLLISIONS, F_CONTROLLED = 1, 2, 4, 8
+# config flags
+C_NORMALIZE_REWARD, C_OFFROAD_TERMINAL, C_OBS_ABSOLUTE, C_OBS_NORMALIZE, C_OBS_CLIP, C_OBS_SEE_BEHIND = 1, 2, 4, 8, 16, 32
+
+FEATURE_IDS = {name: i for i, name in enumerate(
+    ["presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h", "cos_d", "sin_d",
+     "long_off", "lat_off", "ang_off"])}
+
+# DiscreteMetaAction.ACTIONS_ALL (envs/common/action.py:204)
+ACTIONS_ALL = {0: "LANE_LEFT", 1: "IDLE", 2: "LANE_RIGHT", 3: "FASTER", 4: "SLOWER"}
+
+
+class HwyConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("num_envs", C.c_int32),
+        ("num_vehicles", C.c_int32),
+        ("num_agents", C.c_int32),
+        ("agent_index", C.c_int32 * HWY_MAX_AGENTS),
+        ("lanes_count", C.c_int32),
+        ("frames_per_step", C.c_int32),
+        ("flags", C.c_int32),
+        ("obs_vehicles", C.c_int32),
+        ("obs_features", C.c_int32),
+        ("obs_feature_ids", C.c_int32 * HWY_MAX_FEATURES),
+        ("num_target_speeds", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("target_speeds", C.c_double * HWY_MAX_TARGET_SPEEDS),
+        ("dt", C.c_double),
+        ("policy_dt", C.c_double),
+        ("duration", C.c_double),
+        ("lane_width", C.c_double),
+        ("road_length", C.c_double),
+        ("speed_limit", C.c_double),
+        ("collision_reward", C.c_double),
+        ("right_lane_reward", C.c_double),
+        ("high_speed_reward", C.c_double),
+        ("reward_speed_range", C.c_double * 2),
+        ("perception_distance", C.c_double),
+        ("obs_range_x", C.c_double * 2),
+        ("obs_range_y", C.c_double * 2),
+        ("obs_range_vx", C.c_double * 2),
+        ("obs_range_vy", C.c_double * 2),
+    ]
+
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+STATE_F64 = ["x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y"]
+STATE_I32 = ["lane", "target_lane", "speed_index", "flags"]
+
+
+class HwyState(C.Structure):
+    _fields_ = ([(n, _DP) for n in STATE_F64] + [(n, _IP) for n in STATE_I32] + [("time", _DP)])
+
+
+def alloc_state(num_envs: int, num_vehicles: int) -> dict:
+    """Host SoA (numpy) for hwy_set_state / hwy_get_state."""
+    st = {k: np.zeros((num_envs, num_vehicles), np.float64) for k in STATE_F64}
+    st.update({k: np.zeros((num_envs, num_vehicles), np.int32) for k in STATE_I32})
+    st["time"] = np.zeros(num_envs, np.float64)
+    return st
+
+
+def state_struct(st: dict) -> HwyState:
+    """ctypes view of a host SoA dict (arrays must stay alive while the struct is used)."""
+    s = HwyState()
+    for k in STATE_F64 + ["time"]:
+        a = st[k]
+        assert a.dtype == np.float64 and a.flags.c_contiguous, k
+        setattr(s, k, a.ctypes.data_as(_DP))
+    for k in STATE_I32:
+        a = st[k]
+        assert a.dtype == np.int32 and a.flags.c_contiguous, k
+        setattr(s, k, a.ctypes.data_as(_IP))
+    return s
+
+
+def copy_state(st: dict) -> dict:
+    return {k: v.copy() for k, v in st.items()}
+
+
+# --------------------------------------------------------------------------- config dicts
+
+def abstract_default_config() -> dict:
+    """AbstractEnv.default_config (envs/common/abstract.py:101-125), minus rendering keys' effect."""
+    return {
+        "observation": {"type": "Kinematics"},
+        "action": {"type": "DiscreteMetaAction"},
+        "simulation_frequency": 15,
+        "policy_frequency": 1,
+        "other_vehicles_type": "highway_env.vehicle.behavior.IDMVehicle",
+        "screen_width": 600,
+        "screen_height": 150,
+        "centering_position": [0.3, 0.5],
+        "scaling": 5.5,
+        "show_trajectories": False,
+        "render_agent": True,
+        "offscreen_rendering": None,
+        "manual_control": False,
+        "real_time_rendering": False,
+        "neighbour_vehicles_connected_lanes": False,
+    }
+
+
+def highway_default_config() -> dict:
+    """HighwayEnv.default_config (envs/highway_env.py:25-53)."""
+    cfg = abstract_default_config()
+    cfg.update({
+        "observation": {"type": "Kinematics"},
+        "action": {"type": "DiscreteMetaAction"},
+        "lanes_count": 4,
+        "vehicles_count": 50,
+        "controlled_vehicles": 1,
+        "initial_lane_id": None,
+        "duration": 40,
+        "ego_spacing": 2,
+        "vehicles_density": 1,
+        "collision_reward": -1,
+        "right_lane_reward": 0.1,
+        "high_speed_reward": 0.4,
+        "lane_change_reward": 0,
+        "reward_speed_range": [20, 30],
+        "normalize_reward": True,
+        "offroad_terminal": False,
+    })
+    return cfg
+
+
+def highway_fast_default_config() -> dict:
+    """HighwayEnvFast.default_config (envs/highway_env.py:162-175)."""
+    cfg = highway_default_config()
+    cfg.update({"simulation_frequency": 5, "lanes_count": 3, "vehicles_count": 20,
+                "duration": 30, "ego_spacing": 1.5})
+    return cfg
+
+
+def near_split(x: int, num_bins: int) -> list:
+    """utils.near_split (highway_env/utils.py:355-370), num_bins form."""
+    quotient, remainder = divmod(x, num_bins)
+    return [quotient + 1] * remainder + [quotient] * (num_bins - remainder)
+
+
+def agent_indices(vehicles_count: int, controlled: int) -> list:
+    """Positions of the controlled vehicles in Road.vehicles as built by
+    HighwayEnv._create_vehicles (highway_env.py:72-98): ego_k followed by its share of others."""
+    idx, pos = [], 0
+    for others in near_split(vehicles_count, controlled):
+        idx.append(pos)
+        pos += 1 + others
+    return idx
+
+
+def make_config(config: dict, num_envs: int) -> HwyConfig:
+    """Flatten a reference-style config dict into the POD the engine takes.
+
+    Raises the reference's errors for what it rejects (``ValueError("Unknown
+    action type")`` action.py:346, ``ValueError("Unknown observation type")``
+    observation.py:794) and ``NotImplementedError`` for reference features outside
+    the hot-path scope.
+    """
+    cfg = copy.deepcopy(config)
+    act = cfg["action"]
+    if act["type"] == "MultiAgentAction":
+        act = act["action_config"]
+    if act["type"] not in ("DiscreteMetaAction", "ContinuousAction", "DiscreteAction", "MultiAgentAction"):
+        raise ValueError("Unknown action type")
+    if act["type"] != "DiscreteMetaAction":
+        raise NotImplementedError(f"action type {act['type']} is outside the MI355X hot-path scope")
+    if not (act.get("longitudinal", True) and act.get("lateral", True)):
+        raise NotImplementedError("DiscreteMetaAction with longitudinal/lateral disabled is out of scope")
+    obs = cfg["observation"]
+    if obs["type"] == "MultiAgentObservation":
+        obs = obs["observation_config"]
+    known = ("Kinematics", "OccupancyGrid", "GrayscaleObservation", "TimeToCollision", "KinematicsGoal",
+             "AttributesObservation", "MultiAgentObservation", "TupleObservation", "LidarObservation",
+             "ExitObservation")
+    if obs["type"] not in known:
+        raise ValueError("Unknown observation type")
+    if obs["type"] != "Kinematics":
+        raise NotImplementedError(f"observation type {obs['type']} is outside the MI355X hot-path scope")
+    if cfg.get("other_vehicles_type", "highway_env.vehicle.behavior.IDMVehicle") != "highway_env.vehicle.behavior.IDMVehicle":
+        raise NotImplementedError("only IDMVehicle traffic is in the hot-path scope")
+    if cfg.get("neighbour_vehicles_connected_lanes", False):
+        raise NotImplementedError("neighbour_vehicles_connected_lanes is meaningless on a single-segment highway")
+    if obs.get("order", "sorted") != "sorted":
+        raise NotImplementedError("KinematicObservation order='shuffled' is out of scope")
+
+    c = HwyConfig()
+    c.abi_version = HWY_ABI_VERSION
+    c.num_envs = int(num_envs)
+    A = int(cfg["controlled_vehicles"])
+    c.num_agents = A
+    c.num_vehicles = int(cfg["vehicles_count"]) + A
+    if not (1 <= A <= HWY_MAX_AGENTS):
+        raise ValueError(f"controlled_vehicles must be in [1, {HWY_MAX_AGENTS}]")
+    if not (A <= c.num_vehicles <= HWY_MAX_VEHICLES):
+        raise ValueError(f"vehicles_count + controlled_vehicles must be <= {HWY_MAX_VEHICLES}")
+    for k, i in enumerate(agent_indices(int(cfg["vehicles_count"]), A)):
+        c.agent_index[k] = i
+    c.lanes_count = int(cfg["lanes_count"])
+    if not (1 <= c.lanes_count <= HWY_MAX_LANES):
+        raise ValueError(f"lanes_count must be in [1, {HWY_MAX_LANES}]")
+    c.frames_per_step = int(cfg["simulation_frequency"] // cfg["policy_frequency"])
+    c.dt = 1 / cfg["simulation_frequency"]
+    c.policy_dt = 1 / cfg["policy_frequency"]
+    c.duration = float(cfg["duration"])
+    c.lane_width = 4.0        # AbstractLane.DEFAULT_WIDTH (road/lane.py:16)
+    c.road_length = 10000.0   # RoadNetwork.straight_road_network length (road/road.py:296)
+    c.speed_limit = 30.0      # HighwayEnv._create_road (highway_env.py:63)
+    ts = act.get("target_speeds")
+    ts = np.linspace(20, 30, 3) if ts is None else np.asarray(ts, np.float64)  # controller.py:259
+    if not (2 <= ts.size <= HWY_MAX_TARGET_SPEEDS):
+        raise ValueError("target_speeds must hold 2..8 values")
+    c.num_target_speeds = int(ts.size)
+    for k, v in enumerate(ts):
+        c.target_speeds[k] = float(v)
+    c.collision_reward = float(cfg["collision_reward"])
+    c.right_lane_reward = float(cfg["right_lane_reward"])
+    c.high_speed_reward = float(cfg["high_speed_reward"])
+    c.reward_speed_range[0], c.reward_speed_range[1] = map(float, cfg["reward_speed_range"])
+    c.perception_distance = 5.0 * 40.0  # AbstractEnv.PERCEPTION_DISTANCE (abstract.py:58)
+
+    feats = obs.get("features") or ["presence", "x", "y", "vx", "vy"]
+    if len(feats) > HWY_MAX_FEATURES:
+        raise ValueError("too many observation features")
+    c.obs_vehicles = int(obs.get("vehicles_count", 5))
+    c.obs_features = len(feats)
+    for k, name in enumerate(feats):
+        if name not in FEATURE_IDS:
+            raise KeyError(name)  # df[self.features] raises KeyError in the reference
+        c.obs_feature_ids[k] = FEATURE_IDS[name]
+    fr = obs.get("features_range")
+    if not fr:
+        # KinematicObservation.normalize_obs (observation.py:214-226): len(all_side_lanes) == lanes_count
+        fr = {"x": [-200.0, 200.0], "y": [-4.0 * c.lanes_count, 4.0 * c.lanes_count],
+              "vx": [-80.0, 80.0], "vy": [-80.0, 80.0]}
+    inf = float("inf")
+    for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
+        if name in fr:
+            field[0], field[1] = float(fr[name][0]), float(fr[name][1])
+        else:  # feature not normalised: encode as the identity map lmap(v,[-1,1],[-1,1]) is NOT exact; use +-inf sentinel
+            field[0], field[1] = -inf, inf
+    for name in fr:
+        if name not in ("x", "y", "vx", "vy"):
+            raise NotImplementedError(f"features_range for {name!r} is out of scope")
+    flags = 0
+    if cfg["normalize_reward"]:
+        flags |= C_NORMALIZE_REWARD
+    if cfg["offroad_terminal"]:
+        flags |= C_OFFROAD_TERMINAL
+    if obs.get("absolute", False):
+        flags |= C_OBS_ABSOLUTE
+    if obs.get("normalize", True):
+        flags |= C_OBS_NORMALIZE
+    if obs.get("clip", True):
+        flags |= C_OBS_CLIP
+    if obs.get("see_behind", False):
+        flags |= C_OBS_SEE_BEHIND
+    c.flags = flags
+    return c

@@ -1,0 +1,229 @@
+/*
+ * hwy_engine.h -- C-ABI of the MI355X-native batched HighwayEnv step engine.
+ *
+ * The reference (Farama-Foundation/HighwayEnv) has no FFI: its hot path is the
+ * Python method seam
+ *
+ *     AbstractEnv.step      highway_env/envs/common/abstract.py:259-285
+ *       AbstractEnv._simulate                              :287-317
+ *         ActionType.act    envs/common/action.py:259-260  (DiscreteMetaAction)
+ *         Road.act          road/road.py:464-467
+ *         Road.step         road/road.py:469-481
+ *       KinematicObservation.observe   envs/common/observation.py:234-276
+ *       HighwayEnv._reward/_is_terminated/_is_truncated  envs/highway_env.py:100-151
+ *     AbstractEnv.reset     envs/common/abstract.py:219-249  (HighwayEnv._create_vehicles :72-98)
+ *
+ * Each entry point below names the reference interface it replaces.  All
+ * functions are extern "C", take plain pointers and sizes, return 0 on success
+ * or a negative hwy_status; the message of the last failure on an engine is
+ * available through hwy_last_error().  One host thread per engine; calls on one
+ * engine must be serialised; engines on different GPUs are independent.
+ *
+ * Data model.  E environments x N vehicles (vehicle index == position in the
+ * reference's Road.vehicles list; controlled vehicles are where
+ * HighwayEnv._create_vehicles puts them, index 0 for a single agent).  All
+ * floating-point state is f64 like the reference (vehicle/objects.py:43);
+ * observations are f32 (observation.py:276).  Host-side arrays are row-major
+ * [E][N] (state), [E][A][V][F] (obs), [E][A] (actions) unless stated otherwise.
+ */
+#ifndef HWY_ENGINE_H
+#define HWY_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HWY_ABI_VERSION 1
+
+#define HWY_MAX_AGENTS 16
+#define HWY_MAX_FEATURES 16
+#define HWY_MAX_TARGET_SPEEDS 8
+#define HWY_MAX_LANES 16
+#define HWY_MAX_VEHICLES 256
+
+typedef enum hwy_status {
+  HWY_OK = 0,
+  HWY_ERR_INVALID_ARG = -1,
+  HWY_ERR_HIP = -2,
+  HWY_ERR_UNSUPPORTED = -3,
+  HWY_ERR_NO_DEVICE = -4,
+  HWY_ERR_ACTION = -5 /* meta-action outside [0,5): the reference raises KeyError (action.py:260) */
+} hwy_status;
+
+/* per-vehicle flag bits (hwy_state.flags) */
+enum {
+  HWY_F_CRASHED = 1,          /* RoadObject.crashed            vehicle/objects.py:64  */
+  HWY_F_HAS_IMPACT = 2,       /* Vehicle.impact is not None    vehicle/kinematics.py:47,145-148 */
+  HWY_F_CHECK_COLLISIONS = 4, /* RoadObject.check_collisions   vehicle/objects.py:61 (HighwayEnvFast clears it, highway_env.py:177-182) */
+  HWY_F_CONTROLLED = 8        /* MDPVehicle (ego) instead of IDMVehicle */
+};
+
+/* config flag bits (hwy_config.flags) */
+enum {
+  HWY_C_NORMALIZE_REWARD = 1, /* config["normalize_reward"]   highway_env.py:108-116 */
+  HWY_C_OFFROAD_TERMINAL = 2, /* config["offroad_terminal"]   highway_env.py:141-147 */
+  HWY_C_OBS_ABSOLUTE = 4,     /* KinematicObservation.absolute      observation.py:167 */
+  HWY_C_OBS_NORMALIZE = 8,    /* KinematicObservation.normalize     observation.py:169 */
+  HWY_C_OBS_CLIP = 16,        /* KinematicObservation.clip          observation.py:170 */
+  HWY_C_OBS_SEE_BEHIND = 32   /* KinematicObservation.see_behind    observation.py:171 */
+};
+
+/* observation feature ids (Vehicle.to_dict keys, vehicle/kinematics.py:237-261) */
+enum {
+  HWY_FEAT_PRESENCE = 0, HWY_FEAT_X, HWY_FEAT_Y, HWY_FEAT_VX, HWY_FEAT_VY, HWY_FEAT_HEADING,
+  HWY_FEAT_COS_H, HWY_FEAT_SIN_H, HWY_FEAT_COS_D, HWY_FEAT_SIN_D, HWY_FEAT_LONG_OFF,
+  HWY_FEAT_LAT_OFF, HWY_FEAT_ANG_OFF, HWY_FEAT_COUNT
+};
+
+/* meta-actions: DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:204 */
+enum { HWY_LANE_LEFT = 0, HWY_IDLE = 1, HWY_LANE_RIGHT = 2, HWY_FASTER = 3, HWY_SLOWER = 4 };
+
+/*
+ * Flat POD derived from the reference's config dict
+ * (HighwayEnv.default_config, highway_env.py:25-53; AbstractEnv.default_config,
+ * abstract.py:101-125; KinematicObservation.__init__, observation.py:160-197).
+ */
+typedef struct hwy_config {
+  int32_t abi_version;                 /* = HWY_ABI_VERSION */
+  int32_t num_envs;                    /* E */
+  int32_t num_vehicles;                /* N = vehicles_count + controlled_vehicles */
+  int32_t num_agents;                  /* A = controlled_vehicles */
+  int32_t agent_index[HWY_MAX_AGENTS]; /* index of each controlled vehicle in the vehicle list */
+  int32_t lanes_count;                 /* L: lane k is centred on y = k*lane_width (road.py:291-321) */
+  int32_t frames_per_step;             /* T = simulation_frequency // policy_frequency (abstract.py:289-291) */
+  int32_t flags;                       /* HWY_C_* */
+  int32_t obs_vehicles;                /* V = observation.vehicles_count */
+  int32_t obs_features;                /* F */
+  int32_t obs_feature_ids[HWY_MAX_FEATURES];
+  int32_t num_target_speeds;           /* MDPVehicle.target_speeds (controller.py:259,287-291) */
+  int32_t reserved0;
+  double target_speeds[HWY_MAX_TARGET_SPEEDS];
+  double dt;                           /* 1 / simulation_frequency  (abstract.py:307) */
+  double policy_dt;                    /* 1 / policy_frequency      (abstract.py:274) */
+  double duration;                     /* config["duration"] [s]    (highway_env.py:149-151) */
+  double lane_width;                   /* AbstractLane.DEFAULT_WIDTH = 4 (lane.py:16) */
+  double road_length;                  /* 10000 (road.py:296) */
+  double speed_limit;                  /* 30 (highway_env.py:63) */
+  double collision_reward, right_lane_reward, high_speed_reward; /* highway_env.py:38-45 */
+  double reward_speed_range[2];        /* highway_env.py:46 */
+  double perception_distance;          /* AbstractEnv.PERCEPTION_DISTANCE = 5*MAX_SPEED (abstract.py:58) */
+  double obs_range_x[2], obs_range_y[2], obs_range_vx[2], obs_range_vy[2]; /* observation.py:214-226 */
+} hwy_config;
+
+/*
+ * Struct-of-arrays view of the full simulation state in HOST memory, each
+ * vehicle array [E*N] row-major, `time` [E].  Used by hwy_set_state /
+ * hwy_get_state (the reference equivalent is reaching into
+ * env.road.vehicles[i].{position,heading,speed,lane_index,target_lane_index,
+ * crashed,impact,timer,DELTA,target_speed,speed_index}).  Any pointer may be
+ * NULL in hwy_get_state (field skipped); all must be non-NULL in hwy_set_state.
+ */
+typedef struct hwy_state {
+  double *x, *y, *heading, *speed;      /* RoadObject.position/heading/speed     objects.py:42-45 */
+  double *timer;                        /* IDMVehicle.timer                      behavior.py:64   */
+  double *target_speed;                 /* ControlledVehicle.target_speed        controller.py:47 */
+  double *delta;                        /* IDMVehicle.DELTA (randomize_behavior) behavior.py:66-69 */
+  double *impact_x, *impact_y;          /* Vehicle.impact (valid iff HWY_F_HAS_IMPACT) */
+  int32_t *lane;                        /* lane_index[2]                         */
+  int32_t *target_lane;                 /* target_lane_index[2]                  */
+  int32_t *speed_index;                 /* MDPVehicle.speed_index (controlled vehicles) */
+  int32_t *flags;                       /* HWY_F_* */
+  double *time;                         /* AbstractEnv.time [E]                  abstract.py:274 */
+} hwy_state;
+
+typedef struct hwy_engine hwy_engine; /* opaque */
+
+/* Library-level queries (usable without a GPU). */
+int hwy_abi_version(void);
+size_t hwy_config_size(void);            /* sizeof(hwy_config): lets a binding check its struct layout */
+int hwy_device_count(void);              /* number of visible HIP devices, 0 if none / no driver */
+const char *hwy_status_string(int status);
+
+/*
+ * Engine lifetime.  Replaces AbstractEnv.__init__ (abstract.py:60-89) for E
+ * batched environments.  `stream` is an existing hipStream_t (e.g. PyTorch's
+ * current stream) or NULL for an engine-owned stream.  The engine owns all
+ * device memory.  Fails with HWY_ERR_NO_DEVICE when no GPU is present -- there
+ * is no CPU fallback.
+ */
+int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_engine **out);
+int hwy_destroy(hwy_engine *eng);
+const char *hwy_last_error(const hwy_engine *eng); /* eng may be NULL: last hwy_create failure */
+
+/* Parity injection / inspection: H2D and D2H of the whole SoA (synchronous). */
+int hwy_set_state(hwy_engine *eng, const hwy_state *host);
+int hwy_get_state(hwy_engine *eng, hwy_state *host);
+
+/*
+ * Reset.  Replaces AbstractEnv.reset -> HighwayEnv._reset (abstract.py:219-249,
+ * highway_env.py:55-98) for the environments whose mask byte is non-zero (NULL
+ * mask = all), spawning traffic ON THE DEVICE with the reference's spawn rule
+ * (Vehicle.create_random, kinematics.py:50-104) driven by a counter-based RNG
+ * keyed by seeds[e].  The random stream is NOT numpy's PCG64 stream; the
+ * stream-identical reset is host-side (highwayenv_amd/spawn.py) + hwy_set_state.
+ * `ego_spacing`/`vehicles_density`/`initial_lane_id` (-1 = random) are the
+ * config entries of the same names.  Writes the first observation if obs != NULL
+ * (host pointer, [E][A][V][F]; rows of unmasked envs untouched).
+ */
+int hwy_reset(hwy_engine *eng, const uint8_t *mask, const uint64_t *seeds, double ego_spacing,
+              double vehicles_density, int32_t initial_lane_id, float *obs);
+
+/*
+ * One batched policy step == AbstractEnv.step for every environment:
+ * T x { action_type.act (first frame); road.act(); road.step(dt) } + observe +
+ * reward + terminated + truncated + info{speed,crashed}.
+ *   actions    int32 [E][A]   in   DiscreteMetaAction ids
+ *   obs        f32   [E][A][V][F]
+ *   reward     f64   [E][A]   (single-agent envs: the reference's scalar reward)
+ *   terminated u8    [E]
+ *   truncated  u8    [E]
+ *   info_speed f64   [E][A], info_crashed u8 [E][A]    (may be NULL)
+ * hwy_step takes HOST pointers (H2D actions, kernels, D2H results, synchronises).
+ * hwy_step_device takes DEVICE pointers, only enqueues on the engine's stream
+ * and does not synchronise -- the path for on-GPU policies, RCCL gathers and
+ * the benchmark's HBM-resident timing.
+ */
+int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward,
+             uint8_t *terminated, uint8_t *truncated, double *info_speed, uint8_t *info_crashed);
+int hwy_step_device(hwy_engine *eng, const int32_t *d_actions, float *d_obs, double *d_reward,
+                    uint8_t *d_terminated, uint8_t *d_truncated, double *d_info_speed,
+                    uint8_t *d_info_crashed);
+
+/*
+ * Debug / parity: advance `n_frames` simulation frames (Road.act + Road.step)
+ * without observing.  If actions != NULL (host, [E][A]) the meta-action is
+ * applied on the first of those frames (abstract.py:294-304).  `time` is not
+ * advanced.
+ */
+int hwy_step_frames(hwy_engine *eng, const int32_t *actions, int32_t n_frames);
+
+/* KinematicObservation.observe for the current state (host pointer out). */
+int hwy_observe(hwy_engine *eng, float *obs);
+
+/*
+ * Auto-reset (gymnasium vector "next-step" mode): when enabled, an environment
+ * that returned terminated|truncated is re-spawned on the device at the start
+ * of the following hwy_step* call (its action for that step is ignored and the
+ * returned obs is the reset obs, reward 0).  seeds advance per episode.
+ */
+int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base_seed, double ego_spacing,
+                      double vehicles_density, int32_t initial_lane_id);
+
+int hwy_sync(hwy_engine *eng); /* hipStreamSynchronize on the engine stream */
+
+/*
+ * Kernel timing with HIP events recorded on the engine's stream around the
+ * step kernel of every hwy_step / hwy_step_device / hwy_step_frames call while enabled.
+ * hwy_profile_read synchronises and returns the accumulated kernel time and
+ * launch count since the last hwy_profile_enable(eng, 1).
+ */
+int hwy_profile_enable(hwy_engine *eng, int32_t enabled);
+int hwy_profile_read(hwy_engine *eng, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HWY_ENGINE_H */

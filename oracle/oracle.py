@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE: ctypes wrapper around oracle/_build/libhwy_oracle.so.
+
+The oracle is the checker for the HIP engine (and bench.py's timed CPU baseline);
+it is never imported by the product package ``highwayenv_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from highwayenv_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libhwy_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (no GPU needed)."""
+    src = os.path.join(_HERE, "hwy_oracle.c")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "hwy_engine.h")
+    stale = (not os.path.exists(_LIB_PATH)
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_config_size.restype = C.c_size_t
+        assert _lib.orc_config_size() == C.sizeof(_abi.HwyConfig), "hwy_config layout mismatch"
+        for fn in (_lib.orc_frames, _lib.orc_observe, _lib.orc_step):
+            fn.restype = C.c_int
+    return _lib
+
+
+def _p(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def frames(cfg: _abi.HwyConfig, st: dict, actions, n_frames: int) -> None:
+    """n_frames x {[meta-action]; Road.act(); Road.step(dt)} in place on the SoA dict."""
+    acts = None if actions is None else np.ascontiguousarray(actions, np.int32)
+    s = _abi.state_struct(st)
+    rc = lib().orc_frames(C.byref(cfg), C.byref(s), _p(acts, C.c_int32), C.c_int32(n_frames))
+    assert rc == 0, rc
+
+
+def observe(cfg: _abi.HwyConfig, st: dict) -> np.ndarray:
+    obs = np.zeros((cfg.num_envs, cfg.num_agents, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    s = _abi.state_struct(st)
+    rc = lib().orc_observe(C.byref(cfg), C.byref(s), _p(obs, C.c_float))
+    assert rc == 0, rc
+    return obs
+
+
+def step(cfg: _abi.HwyConfig, st: dict, actions) -> tuple:
+    """AbstractEnv.step for every env; returns (obs, reward, terminated, truncated, info)."""
+    E, A = cfg.num_envs, cfg.num_agents
+    acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
+    obs = np.zeros((E, A, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    reward = np.zeros((E, A), np.float64)
+    term = np.zeros(E, np.uint8)
+    trunc = np.zeros(E, np.uint8)
+    speed = np.zeros((E, A), np.float64)
+    crashed = np.zeros((E, A), np.uint8)
+    s = _abi.state_struct(st)
+    rc = lib().orc_step(C.byref(cfg), C.byref(s), _p(acts, C.c_int32), _p(obs, C.c_float),
+                        _p(reward, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8),
+                        _p(speed, C.c_double), _p(crashed, C.c_uint8))
+    if rc == _abi.HWY_ERR_ACTION:
+        raise KeyError("invalid meta-action")
+    assert rc == 0, rc
+    return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}

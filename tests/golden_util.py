@@ -1,0 +1,82 @@
+"""Helpers to load the golden fixtures recorded from the unmodified reference
+(tests/golden/make_golden.py) into the engine's SoA layout."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from highwayenv_amd import _abi
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+ALL = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
+       "fast_idle_long", "fast_offroad_terminal"]
+WITH_FRAMES = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash"]
+
+
+class Golden:
+    def __init__(self, name: str):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        z = self.z
+        self.E, self.N, self.T, self.steps, self.frames_for = (int(v) for v in z["meta"])
+        self.fast = bool(z["cfg_fast"])
+        self.config = (_abi.highway_fast_default_config() if self.fast else _abi.highway_default_config())
+        self.config.update({
+            "lanes_count": int(z["cfg_lanes_count"]),
+            "vehicles_count": int(z["cfg_vehicles_count"]),
+            "simulation_frequency": int(z["cfg_simulation_frequency"]),
+            "policy_frequency": int(z["cfg_policy_frequency"]),
+            "duration": float(z["cfg_duration"]),
+            "ego_spacing": float(z["cfg_ego_spacing"]),
+            "vehicles_density": float(z["cfg_vehicles_density"]),
+            "normalize_reward": bool(z["cfg_normalize_reward"]),
+            "offroad_terminal": bool(z["cfg_offroad_terminal"]),
+            "collision_reward": float(z["cfg_collision_reward"]),
+            "right_lane_reward": float(z["cfg_right_lane_reward"]),
+            "high_speed_reward": float(z["cfg_high_speed_reward"]),
+            "reward_speed_range": [float(v) for v in z["cfg_reward_speed_range"]],
+        })
+        self.seeds = z["seeds"]
+        self.actions = z["actions"]  # [steps, E]
+
+    def hwy_config(self, num_envs=None) -> _abi.HwyConfig:
+        return _abi.make_config(self.config, self.E if num_envs is None else num_envs)
+
+    def state(self, prefix: str, index=None, envs=None, time=0.0) -> dict:
+        """SoA dict from `init_*` (index None), `step_*[index]` or `frame_*[index]`."""
+        z = self.z
+
+        def get(k):
+            a = z[f"{prefix}_{k}"]
+            if index is not None:
+                a = a[index]
+            if envs is not None:
+                a = a[envs]
+            return a
+
+        E = get("x").shape[0]
+        st = _abi.alloc_state(E, self.N)
+        for k in ["x", "y", "heading", "speed", "target_speed", "impact_x", "impact_y"]:
+            st[k][...] = get(k)
+        st["timer"][...] = np.nan_to_num(get("timer"), nan=0.0)
+        st["delta"][...] = np.nan_to_num(get("delta"), nan=0.0)
+        st["lane"][...] = get("lane")
+        st["target_lane"][...] = get("target_lane")
+        st["speed_index"][...] = np.maximum(get("speed_index"), 0)
+        st["flags"][...] = (get("crashed") * _abi.F_CRASHED + get("has_impact") * _abi.F_HAS_IMPACT
+                            + get("check_collisions") * _abi.F_CHECK_COLLISIONS
+                            + get("controlled") * _abi.F_CONTROLLED)
+        st["time"][...] = time
+        return st
+
+
+def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
+    for k in ["lane", "target_lane", "flags"]:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=f"{what}: {k}")
+    ctrl = (want["flags"] & _abi.F_CONTROLLED) != 0
+    np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
+    for k in ["x", "y", "heading", "speed", "target_speed", "impact_x", "impact_y"]:
+        np.testing.assert_allclose(got[k], want[k], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+    np.testing.assert_allclose(got["timer"][~ctrl], want["timer"][~ctrl], rtol=0, atol=atol, err_msg=f"{what}: timer")

@@ -1,0 +1,76 @@
+"""Pin the C oracle (oracle/hwy_oracle.c) against traces of the unmodified reference.
+
+CPU only.  Golden fixtures: tests/golden/*.npz (tests/golden/make_golden.py).
+Tolerance: the oracle computes in f64 with glibc libm, the reference with numpy's
+SIMD libm -- values differ by a few ulp per operation; flags / lane indices must
+be exact.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi
+from oracle import oracle
+from tests.golden_util import ALL, WITH_FRAMES, Golden, assert_state_close
+
+
+@pytest.mark.parametrize("name", WITH_FRAMES)
+def test_oracle_teacher_forced_frames(name):
+    """Every single frame, started from the reference's own state: Road.act + Road.step."""
+    g = Golden(name)
+    Ef = g.frames_for
+    cfg = g.hwy_config(Ef)
+    envs = slice(0, Ef)
+    for step in range(g.steps):
+        for fr in range(g.T):
+            k = step * g.T + fr
+            if k == 0:
+                st = g.state("init", envs=envs)
+            else:
+                st = g.state("frame", k - 1)
+            acts = g.actions[step, :Ef].reshape(Ef, 1) if fr == 0 else None
+            oracle.frames(cfg, st, acts, 1)
+            assert_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}")
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_oracle_free_running_steps(name):
+    """Whole episodes from reset state: obs / reward / terminated / truncated / info / state per step."""
+    g = Golden(name)
+    cfg = g.hwy_config()
+    st = g.state("init")
+    np.testing.assert_allclose(oracle.observe(cfg, st)[:, 0], g.z["obs0"], rtol=0, atol=1e-6)
+    for t in range(g.steps):
+        obs, reward, term, trunc, info = oracle.step(cfg, st, g.actions[t])
+        what = f"{name} step {t}"
+        np.testing.assert_allclose(obs[:, 0], g.z["obs"][t], rtol=0, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(reward[:, 0], g.z["reward"][t], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_array_equal(term, g.z["terminated"][t].astype(bool), err_msg=what)
+        np.testing.assert_array_equal(trunc, g.z["truncated"][t].astype(bool), err_msg=what)
+        np.testing.assert_allclose(info["speed"][:, 0], g.z["info_speed"][t], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_array_equal(info["crashed"][:, 0], g.z["info_crashed"][t].astype(bool), err_msg=what)
+        assert_state_close(st, g.state("step", t), atol=1e-8, what=what)
+
+
+def test_oracle_known_answer_vector():
+    """HighwayEnvFast(), reset(seed=0), actions [1,3,0]."""
+    g = Golden("cfg1_fast_default")
+    assert g.seeds[0] == 0
+    np.testing.assert_allclose(g.z["obs0"][0, 0], [1, 0.75410974, 0.6666667, 0.3125, 0], atol=1e-7)
+    np.testing.assert_allclose(g.z["obs0"][0, 1], [1, 0.10281888, -0.33333334, -0.04846349, 0], atol=1e-7)
+    cfg = g.hwy_config(1)
+    st = g.state("init", envs=slice(0, 1))
+    rewards, terms = [], []
+    for a in [1, 3, 0]:
+        _, r, te, _, _ = oracle.step(cfg, st, [[a]])
+        rewards.append(r[0, 0])
+        terms.append(bool(te[0]))
+    np.testing.assert_allclose(rewards, [0.8666666667, 0.9824417010, 0.0333333333], atol=1e-9)
+    assert terms == [False, False, True]
+
+
+def test_invalid_action_is_keyerror():
+    g = Golden("cfg1_fast_default")
+    cfg = g.hwy_config(1)
+    st = g.state("init", envs=slice(0, 1))
+    with pytest.raises(KeyError):
+        oracle.step(cfg, st, [[7]])
