@@ -27,6 +27,7 @@ HWY_OK, HWY_ERR_INVALID_ARG, HWY_ERR_HIP, HWY_ERR_UNSUPPORTED, HWY_ERR_NO_DEVICE
 F_CRASHED, F_HAS_IMPACT, F_CHECK_COLLISIONS, F_CONTROLLED = 1, 2, 4, 8
 # config flags
 C_NORMALIZE_REWARD, C_OFFROAD_TERMINAL, C_OBS_ABSOLUTE, C_OBS_NORMALIZE, C_OBS_CLIP, C_OBS_SEE_BEHIND = 1, 2, 4, 8, 16, 32
+C_EGO_ONLY_COLLISIONS = 64
 
 FEATURE_IDS = {name: i for i, name in enumerate(
     ["presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h", "cos_d", "sin_d",
@@ -178,7 +179,7 @@ def agent_indices(vehicles_count: int, controlled: int) -> list:
     return idx
 
 
-def make_config(config: dict, num_envs: int) -> HwyConfig:
+def make_config(config: dict, num_envs: int, fast: bool = False) -> HwyConfig:
     """Flatten a reference-style config dict into the POD the engine takes.
 
     Raises the reference's errors for what it rejects (``ValueError("Unknown
@@ -284,5 +285,7 @@ def make_config(config: dict, num_envs: int) -> HwyConfig:
         flags |= C_OBS_CLIP
     if obs.get("see_behind", False):
         flags |= C_OBS_SEE_BEHIND
+    if fast:  # HighwayEnvFast._create_vehicles (highway_env.py:177-182)
+        flags |= C_EGO_ONLY_COLLISIONS
     c.flags = flags
     return c

@@ -1,0 +1,70 @@
+"""ctypes binding of libhwy_engine.so (the C-ABI of include/hwy_engine.h).
+
+The library is the product: if it is missing this module raises -- there is no
+Python/CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi
+from .build import LIB_PATH
+
+_lib = None
+
+# every symbol include/hwy_engine.h declares
+EXPORTS = [
+    "hwy_abi_version", "hwy_config_size", "hwy_device_count", "hwy_status_string", "hwy_create",
+    "hwy_destroy", "hwy_last_error", "hwy_set_state", "hwy_get_state", "hwy_reset", "hwy_step",
+    "hwy_step_device", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
+    "hwy_profile_enable", "hwy_profile_read",
+]
+
+
+class EngineLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineLibraryMissing(
+            f"{LIB_PATH} not found. Build it with `python -m highwayenv_amd.build` (needs hipcc, "
+            "cross-compiles for gfx950). The MI355X engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u8p, f64 = C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), C.c_double
+    lib.hwy_abi_version.restype = C.c_int
+    lib.hwy_config_size.restype = C.c_size_t
+    lib.hwy_device_count.restype = C.c_int
+    lib.hwy_status_string.restype = C.c_char_p
+    lib.hwy_status_string.argtypes = [C.c_int]
+    lib.hwy_last_error.restype = C.c_char_p
+    lib.hwy_last_error.argtypes = [vp]
+    lib.hwy_create.argtypes = [C.POINTER(_abi.HwyConfig), C.c_int, vp, C.POINTER(vp)]
+    lib.hwy_destroy.argtypes = [vp]
+    lib.hwy_set_state.argtypes = [vp, C.POINTER(_abi.HwyState)]
+    lib.hwy_get_state.argtypes = [vp, C.POINTER(_abi.HwyState)]
+    lib.hwy_reset.argtypes = [vp, vp, vp, f64, f64, i32, vp]
+    lib.hwy_step.argtypes = [vp] + [vp] * 7
+    lib.hwy_step_device.argtypes = [vp] + [vp] * 7
+    lib.hwy_step_frames.argtypes = [vp, vp, i32]
+    lib.hwy_observe.argtypes = [vp, vp]
+    lib.hwy_set_autoreset.argtypes = [vp, i32, C.c_uint64, f64, f64, i32]
+    lib.hwy_sync.argtypes = [vp]
+    lib.hwy_profile_enable.argtypes = [vp, i32]
+    lib.hwy_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int or name.startswith(("hwy_create", "hwy_destroy", "hwy_set", "hwy_get", "hwy_reset",
+                                                      "hwy_step", "hwy_observe", "hwy_sync", "hwy_profile")):
+            if name not in ("hwy_status_string", "hwy_last_error", "hwy_config_size"):
+                fn.restype = C.c_int
+    if lib.hwy_abi_version() != _abi.HWY_ABI_VERSION:
+        raise RuntimeError("libhwy_engine.so ABI version mismatch; rebuild with python -m highwayenv_amd.build")
+    if lib.hwy_config_size() != C.sizeof(_abi.HwyConfig):
+        raise RuntimeError("hwy_config layout mismatch between include/hwy_engine.h and highwayenv_amd/_abi.py")
+    _lib = lib
+    return lib

@@ -1,0 +1,54 @@
+"""Build the gfx950 HIP engine in-tree: highwayenv_amd/csrc/libhwy_engine.so.
+
+``hipcc --offload-arch=gfx950`` cross-compiles without a GPU.  ``-ffp-contract=off`` keeps every
+``a*b+c`` double-rounded like the reference's numpy scalar arithmetic (see hwy_device.h).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libhwy_engine.so")
+SOURCES = ["hwy_kernels.hip", "hwy_engine.hip"]
+HEADERS = ["hwy_device.h", "hwy_launch.h", "hwy_params.h", os.path.join("..", "..", "include", "hwy_engine.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X engine cannot be built (there is no CPU fallback)")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_engine(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_engine(force=True, verbose=True))

@@ -1,0 +1,913 @@
+// hwy_device.h -- device code of the MI355X (gfx950) batched HighwayEnv step engine.
+//
+// One workgroup == one environment, thread i == vehicle i (index in the
+// reference's Road.vehicles list), NW = ceil(N/64) wavefronts per workgroup
+// (one 64-wide wavefront for the headline 51-vehicle case).  The whole policy
+// step -- T simulation frames of {meta-action, Road.act, Road.step}, then
+// KinematicObservation + reward + termination -- is ONE launch: the
+// environment's struct-of-arrays is read from HBM once, lives in registers
+// and LDS for all frames, and is written back once.
+//
+// What replaces the reference's O(N) Python scans (road/road.py:483-547,
+// 56% of its run time):
+//   * each frame every thread computes its RANK by longitudinal coordinate
+//     (one LDS-broadcast pass, 3 VALU ops per candidate);
+//   * one wave ballot per lane builds a 64-bit membership mask in rank space
+//     (bit r == "the r-th vehicle along the road is geometrically on lane L",
+//     AbstractLane.on_lane with margin 1, road/lane.py:80-102);
+//   * a front/rear neighbour query is then two bit-scans on that mask
+//     (s_ff1 / s_flbit) + one LDS gather instead of a scan over N vehicles.
+//   Exact-tie semantics of the reference loop (front: last wins, rear: first
+//   wins) are preserved by a workgroup-uniform fallback to the literal scan
+//   whenever two vehicles share the same x.
+// Sequential semantics hidden in the reference's Python loops (SURVEY.md 7,
+// "hard parts") are honoured explicitly: the Gauss-Seidel read of neighbours'
+// target lanes in the lane-change abort rule (behavior.py:229-244) is an
+// ordered chain over the (rare) lane-changing vehicles; "last pair in loop
+// order wins" for collision impacts (road.py:477-481, objects.py:103-113) is
+// "partner with the highest index wins".
+//
+// All arithmetic is IEEE f64 like the reference (objects.py:43), compiled
+// with -ffp-contract=off so that every a*b+c rounds twice exactly like
+// numpy's scalar ops; only libm (ocml vs numpy) differs, by ulps.
+//
+// This header has no #include of the HIP runtime on purpose: the product
+// translation unit (hwy_kernels.hip) includes <hip/hip_runtime.h> first; the
+// CPU emulation harness under tests/emu (test infrastructure, never shipped)
+// includes its own shim first.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/hwy_engine.h"
+
+namespace hwy {
+
+typedef unsigned long long u64;
+
+// ---- class constants of the reference ------------------------------------------------
+// vehicle/kinematics.py:21-30
+#define HWY_VEH_LENGTH 5.0
+#define HWY_VEH_WIDTH 2.0
+#define HWY_MAX_SPEED 40.0
+#define HWY_MIN_SPEED (-40.0)
+// vehicle/controller.py:24-33
+#define HWY_KP_A (1.0 / 0.6)
+#define HWY_KP_HEADING (1.0 / 0.2)
+#define HWY_KP_LATERAL (1.0 / 0.6)
+#define HWY_PI 3.141592653589793
+#define HWY_MAX_STEER (HWY_PI / 3.0)
+// vehicle/behavior.py:21-46
+#define HWY_ACC_MAX 6.0
+#define HWY_COMFORT_ACC_MAX 3.0
+#define HWY_COMFORT_ACC_MIN (-5.0)
+#define HWY_DISTANCE_WANTED (5.0 + HWY_VEH_LENGTH)
+#define HWY_TIME_WANTED 1.5
+#define HWY_LC_MIN_ACC_GAIN 0.2
+#define HWY_LC_MAX_BRAKING 2.0
+#define HWY_LC_DELAY 1.0
+
+// packed per-vehicle word: lane | target_lane<<8 | speed_index<<16 | flags<<24
+__host__ __device__ inline int32_t pack_word(int lane, int tgt, int sidx, int flags) {
+  return (lane & 0xff) | ((tgt & 0xff) << 8) | ((sidx & 0xff) << 16) | ((flags & 0xff) << 24);
+}
+
+struct DevState {
+  double *x, *y, *heading, *speed, *timer, *target_speed, *delta, *impact_x, *impact_y;  // [E][pitch]
+  int32_t *packed;                                                                       // [E][pitch]
+  double *time;       // [E]
+  uint8_t *done;      // [E] terminated|truncated of the previous step (auto-reset)
+  uint32_t *episode;  // [E] episode counter (RNG stream selector)
+};
+
+struct ResetParams {
+  double ego_spacing;     // config["ego_spacing"]
+  double other_spacing;   // 1 / config["vehicles_density"]
+  double lane_factor;     // exp(-5/40 * lanes_count), kinematics.py:92-96 (host libm)
+  int32_t initial_lane_id;  // -1: random
+  int32_t fast;             // HighwayEnvFast: only controlled vehicles check collisions
+  uint64_t base_seed;
+};
+
+struct StepParams {
+  // compact config (hwy_config subset)
+  int32_t N, A, L, T, flags, V, F, n_ts, pitch;
+  int32_t agent_index[HWY_MAX_AGENTS];
+  int32_t feat[HWY_MAX_FEATURES];
+  double target_speeds[HWY_MAX_TARGET_SPEEDS];
+  double dt, policy_dt, duration, lane_width, road_length, speed_limit;
+  double collision_reward, right_lane_reward, high_speed_reward, rs0, rs1, perception;
+  double rx0, rx1, ry0, ry1, rvx0, rvx1, rvy0, rvy1;
+  DevState st;
+  // per-call
+  int32_t n_frames;       // frames to simulate (T for a policy step)
+  int32_t full_step;      // 1: advance time, observe, reward, done flags; 0: frames only
+  int32_t autoreset;      // 1: envs with done[e] are re-spawned instead of stepped
+  const int32_t *actions;  // [E][A] or nullptr
+  float *obs;              // [E][A][V][F] or nullptr
+  double *reward;          // [E][A]
+  uint8_t *terminated, *truncated;  // [E]
+  double *info_speed;      // [E][A] or nullptr
+  uint8_t *info_crashed;   // [E][A] or nullptr
+  const uint8_t *reset_mask;  // reset kernel only: [E] or nullptr (= all)
+  const uint64_t *reset_seeds;  // reset kernel only: [E] or nullptr (= base_seed + e)
+  ResetParams rp;
+};
+
+// ---- utils.py ---------------------------------------------------------------------------
+// utils.py:50-56
+__device__ inline double not_zero(double x) {
+  const double eps = 1e-2;
+  if (fabs(x) > eps) return x;
+  return x >= 0 ? eps : -eps;
+}
+// Python/numpy float % (floor-mod)
+__device__ inline double py_mod(double a, double b) {
+  double m = (a >= 0 && a < b) ? a : fmod(a, b);  // fmod is exact; the guard only skips the call
+  if (m != 0.0) {
+    if ((b < 0) != (m < 0)) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m;
+}
+// utils.py:59-60
+__device__ inline double wrap_to_pi(double x) { return py_mod(x + HWY_PI, 2 * HWY_PI) - HWY_PI; }
+__device__ inline double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
+// utils.py:31-33
+__device__ inline double lmap(double v, double x0, double x1, double y0, double y1) {
+  return y0 + (v - x0) * (y1 - y0) / (x1 - x0);
+}
+
+// ---- counter-based RNG for the device-side reset: Philox-4x32-10 --------------------------
+// (Salmon et al., SC'11.)  NOT numpy's PCG64 stream: see hwy_reset in hwy_engine.h.
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// two uniforms in [0,1) with 53 random bits each from one Philox block
+__host__ __device__ inline void philox_uniform2(uint64_t seed, uint32_t vehicle, uint32_t episode,
+                                                uint32_t draw, double *u0, double *u1) {
+  uint32_t c[4] = {vehicle, episode, draw, 0x48575931u /* "HWY1" */};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t a = ((uint64_t)c[0] << 32) | c[1], b = ((uint64_t)c[2] << 32) | c[3];
+  *u0 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+  *u1 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---- small bit helpers ----------------------------------------------------------------------
+__device__ inline int ctz64(u64 m) { return __ffsll((long long)m) - 1; }       // m != 0
+__device__ inline int msb64(u64 m) { return 63 - __clzll((long long)m); }      // m != 0
+
+// =============================================================================================
+template <int NW>
+struct EnvBlock {
+  static constexpr int NV = NW * 64;
+
+  // LDS image of one environment (frame-start / post-integration snapshots)
+  struct Shared {
+    double x[NV], y[NV], v[NV], c[NV], s[NV], ts[NV];
+    double aux0[NV], aux1[NV];   // collision translation exchange / observation keys
+    int lane[NV], tgt[NV], perm[NV];
+    u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
+    u64 bal0[NW], bal1[NW], bal2[NW];
+    u64 chk[NW];                  // vehicles with check_collisions (index space)
+  };
+
+  // ---- workgroup-wide ballot: out[w] = ballot of wave w.  Must be called by ALL threads.
+  __device__ static inline void block_ballot(Shared &sh, bool pred, u64 *slot, u64 out[NW]) {
+    const u64 b = __ballot(pred);
+    if (NW == 1) {
+      out[0] = b;
+    } else {
+      const int i = threadIdx.x;
+      if ((i & 63) == 0) slot[i >> 6] = b;
+      __syncthreads();
+      for (int w = 0; w < NW; ++w) out[w] = slot[w];
+      __syncthreads();
+    }
+  }
+  __device__ static inline bool any_of(const u64 m[NW]) {
+    u64 a = 0;
+    for (int w = 0; w < NW; ++w) a |= m[w];
+    return a != 0;
+  }
+
+  // ---- Road.neighbour_vehicles (road/road.py:483-547) ----------------------------------------
+  // Fast path: all x distinct.  rank r of the querying vehicle; returns vehicle indices or -1.
+  __device__ static inline void neighbours_ranked(const Shared &sh, int Lq, int r, int *front, int *rear) {
+    int fr = -1, rr = -1;
+    const int rw = r >> 6, rb = r & 63;
+    // front: lowest member rank above r
+    for (int w = rw; w < NW; ++w) {
+      u64 m = sh.mask[Lq][w];
+      if (w == rw) m &= ~(((u64)2 << rb) - 1);  // ranks > r  (2<<63 wraps to 0 => all cleared)
+      if (m) { fr = w * 64 + ctz64(m); break; }
+    }
+    // rear: highest member rank below r
+    for (int w = rw; w >= 0; --w) {
+      u64 m = sh.mask[Lq][w];
+      if (w == rw) m &= (((u64)1 << rb) - 1);   // ranks < r
+      if (m) { rr = w * 64 + msb64(m); break; }
+    }
+    *front = fr < 0 ? -1 : sh.perm[fr];
+    *rear = rr < 0 ? -1 : sh.perm[rr];
+  }
+  // Literal restatement of the reference loop (taken only when two vehicles share the same x).
+  __device__ static inline void neighbours_scan(const StepParams &p, const Shared &sh, int Lq, int self,
+                                                double s, int *front, int *rear) {
+    int f = -1, b = -1;
+    double s_front = 0, s_rear = 0;
+    for (int j = 0; j < p.N; ++j) {
+      if (j == self) continue;
+      const double s_v = sh.x[j], lat_v = sh.y[j] - Lq * p.lane_width;
+      if (!(fabs(lat_v) <= p.lane_width / 2 + 1.0 && -5.0 <= s_v && s_v < p.road_length + 5.0)) continue;
+      if (s <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
+      if (s_v < s && (b < 0 || s_v > s_rear)) { s_rear = s_v; b = j; }
+    }
+    *front = f;
+    *rear = b;
+  }
+
+  // ---- IDM (vehicle/behavior.py:150-217) -------------------------------------------------------
+  // free-road term COMFORT_ACC_MAX*(1-(v/v0)^delta), with the CALLER's delta (behavior.py:177-183)
+  __device__ static inline double idm_free(const StepParams &p, double v, double ts, double delta) {
+    const double v0 = clipd(ts, 0.0, p.speed_limit);
+    return HWY_COMFORT_ACC_MAX * (1 - pow(fmax(v, 0.0) / fabs(not_zero(v0)), delta));
+  }
+  // interaction term COMFORT_ACC_MAX*(d*/d)^2 of `ego` behind `front`
+  __device__ static inline double idm_gap(double xe, double ve, double ce, double se, double xf, double vf,
+                                          double cf, double sf) {
+    const double d = xf - xe;  // lane_distance_to (objects.py:183-198): longitudinal == x
+    const double dv = (ve * ce - vf * cf) * ce + (ve * se - vf * sf) * se;
+    const double ab = -HWY_COMFORT_ACC_MAX * HWY_COMFORT_ACC_MIN;
+    const double d_star = HWY_DISTANCE_WANTED + ve * HWY_TIME_WANTED + ve * dv / (2 * sqrt(ab));
+    const double q = d_star / not_zero(d);
+    return HWY_COMFORT_ACC_MAX * (q * q);
+  }
+  __device__ static inline double desired_gap(double ve, double ce, double se, double vf, double cf, double sf) {
+    const double dv = (ve * ce - vf * cf) * ce + (ve * se - vf * sf) * se;
+    const double ab = -HWY_COMFORT_ACC_MAX * HWY_COMFORT_ACC_MIN;
+    return HWY_DISTANCE_WANTED + ve * HWY_TIME_WANTED + ve * dv / (2 * sqrt(ab));
+  }
+
+  // ---- ControlledVehicle.steering_control (vehicle/controller.py:145-187), StraightLane heading 0
+  __device__ static inline double steering_control(const StepParams &p, double y, double h, double v, int tgt) {
+    const double lat = y - tgt * p.lane_width;
+    const double lateral_speed_command = -HWY_KP_LATERAL * lat;
+    const double heading_command = asin(clipd(lateral_speed_command / not_zero(v), -1.0, 1.0));
+    const double heading_ref = 0.0 + clipd(heading_command, -HWY_PI / 4, HWY_PI / 4);
+    const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
+    const double slip_angle = asin(clipd(HWY_VEH_LENGTH / 2 / not_zero(v) * heading_rate_command, -1.0, 1.0));
+    const double steering_angle = atan(2 * tan(slip_angle));
+    return clipd(steering_angle, -HWY_MAX_STEER, HWY_MAX_STEER);
+  }
+
+  // ---- AbstractLane.is_reachable_from (road/lane.py:104-118) -------------------------------------
+  __device__ static inline bool reachable(const StepParams &p, int lane, double x, double y) {
+    return fabs(y - lane * p.lane_width) <= 2 * p.lane_width && 0 <= x && x < p.road_length + 5.0;
+  }
+  // ---- RoadNetwork.get_closest_lane_index (road/road.py:55-71, lane.py:132-143) --------------------
+  __device__ static inline int closest_lane(const StepParams &p, double x, double y, double h) {
+    const double angle = fabs(wrap_to_pi(h - 0.0));
+    int best = 0;
+    double bd = 0;
+    for (int k = 0; k < p.L; ++k) {
+      // abs(r) + max(s - length, 0) + max(0 - s, 0) + 1.0*angle, summed left to right
+      const double d = fabs(y - k * p.lane_width) + fmax(x - p.road_length, 0.0) + fmax(0 - x, 0.0) + 1.0 * angle;
+      if (k == 0 || d < bd) { bd = d; best = k; }
+    }
+    return best;
+  }
+
+  // ---- rectangle SAT with swept extension (utils.py:196-241, objects.py:122-138,169-181) -----------
+  // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
+  // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
+  __device__ static int pair_collide(const Shared &sh, int a, int b, double dt, double *tx, double *ty) {
+    const double ax = sh.x[a], ay = sh.y[a], bx = sh.x[b], by = sh.y[b];
+    const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
+    const double dx = bx - ax, dy = by - ay;
+    *tx = 0;
+    *ty = 0;
+    if (sqrt(dx * dx + dy * dy) > (diagonal + diagonal) / 2 + sh.v[a] * dt) return 0;
+    const double ca = sh.c[a], sa = sh.s[a], cb = sh.c[b], sb = sh.s[b];
+    const double lx[4] = {-HWY_VEH_LENGTH / 2, -HWY_VEH_LENGTH / 2, +HWY_VEH_LENGTH / 2, +HWY_VEH_LENGTH / 2};
+    const double ly[4] = {-HWY_VEH_WIDTH / 2, +HWY_VEH_WIDTH / 2, +HWY_VEH_WIDTH / 2, -HWY_VEH_WIDTH / 2};
+    double pa[4][2], pb[4][2];
+    for (int k = 0; k < 4; ++k) {
+      pa[k][0] = (ca * lx[k] + -sa * ly[k]) + ax;
+      pa[k][1] = (sa * lx[k] + ca * ly[k]) + ay;
+      pb[k][0] = (cb * lx[k] + -sb * ly[k]) + bx;
+      pb[k][1] = (sb * lx[k] + cb * ly[k]) + by;
+    }
+    // displacement_a - displacement_b, velocity = speed*(cos h, sin h)  (objects.py:165-167)
+    const double ddx = sh.v[a] * ca * dt - sh.v[b] * cb * dt;
+    const double ddy = sh.v[a] * sa * dt - sh.v[b] * sb * dt;
+    // centre difference d = mean(a) - mean(b) (row-order sum / 4)
+    const double cdx = (((pa[0][0] + pa[1][0]) + pa[2][0]) + pa[3][0]) / 4 - (((pb[0][0] + pb[1][0]) + pb[2][0]) + pb[3][0]) / 4;
+    const double cdy = (((pa[0][1] + pa[1][1]) + pa[2][1]) + pa[3][1]) / 4 - (((pb[0][1] + pb[1][1]) + pb[2][1]) + pb[3][1]) / 4;
+    bool intersecting = true, will = true;
+    double min_distance = __builtin_inf(), axx = 0, axy = 0;
+    for (int pi = 0; pi < 2; ++pi) {
+      for (int k = 0; k < 4; ++k) {
+        const int k2 = (k + 1) & 3;
+        const double p1x = pi ? pb[k][0] : pa[k][0], p1y = pi ? pb[k][1] : pa[k][1];
+        const double p2x = pi ? pb[k2][0] : pa[k2][0], p2y = pi ? pb[k2][1] : pa[k2][1];
+        double nx = -p2y + p1y, ny = p2x - p1x;
+        const double nn = sqrt(nx * nx + ny * ny);
+        nx /= nn;
+        ny /= nn;
+        // project_polygon over the closed 5-point polygons == over the 4 corners
+        double min_a = pa[0][0] * nx + pa[0][1] * ny, max_a = min_a;
+        double min_b = pb[0][0] * nx + pb[0][1] * ny, max_b = min_b;
+        for (int q = 1; q < 4; ++q) {
+          const double qa = pa[q][0] * nx + pa[q][1] * ny, qb = pb[q][0] * nx + pb[q][1] * ny;
+          min_a = qa < min_a ? qa : min_a;
+          max_a = qa > max_a ? qa : max_a;
+          min_b = qb < min_b ? qb : min_b;
+          max_b = qb > max_b ? qb : max_b;
+        }
+        if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) intersecting = false;
+        const double vp = nx * ddx + ny * ddy;
+        if (vp < 0) min_a += vp; else max_a += vp;
+        const double distance = min_a < min_b ? min_b - max_a : min_a - max_b;
+        if (distance > 0) will = false;
+        if (!intersecting && !will) break;  // leaves the edge loop of this polygon only
+        if (fabs(distance) < min_distance) {
+          min_distance = fabs(distance);
+          const bool pos = cdx * nx + cdy * ny > 0;
+          axx = pos ? nx : -nx;
+          axy = pos ? ny : -ny;
+        }
+      }
+    }
+    if (will) {
+      *tx = min_distance * axx;
+      *ty = min_distance * axy;
+    }
+    return (intersecting ? 1 : 0) | (will ? 2 : 0);
+  }
+
+  // ---- Vehicle.to_dict feature (vehicle/kinematics.py:237-261) ---------------------------------------
+  __device__ static inline double feature(const StepParams &p, int fid, double x, double y, double h, double v,
+                                          double c, double s, int lane) {
+    switch (fid) {
+      case HWY_FEAT_PRESENCE: return 1.0;
+      case HWY_FEAT_X: return x;
+      case HWY_FEAT_Y: return y;
+      case HWY_FEAT_VX: return v * c;
+      case HWY_FEAT_VY: return v * s;
+      case HWY_FEAT_HEADING: return h;
+      case HWY_FEAT_COS_H: return c;
+      case HWY_FEAT_SIN_H: return s;
+      case HWY_FEAT_LONG_OFF: return x;
+      case HWY_FEAT_LAT_OFF: return y - lane * p.lane_width;
+      case HWY_FEAT_ANG_OFF: return wrap_to_pi(h - 0.0);
+      default: return 0.0;  // cos_d / sin_d: no route => destination == position => zeros
+    }
+  }
+};
+
+// =============================================================================================
+// Per-thread vehicle registers
+struct Veh {
+  double x, y, h, v, timer, ts, delta, impx, impy, ch, sh;
+  int lane, tgt, sidx, flags;
+};
+
+// ---- device-side spawn: HighwayEnv._create_vehicles (envs/highway_env.py:72-98) with
+//      Vehicle.create_random's rule (vehicle/kinematics.py:50-104), IDMVehicle ctor timer
+//      (behavior.py:64), randomize_behavior (behavior.py:66-69), MDPVehicle ladder snap
+//      (controller.py:287-293).  Thread i == vehicle i.  Needs sh.aux0 as scratch.
+template <int NW>
+__device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Shared &sh, int e, uint64_t seed,
+                                 uint32_t episode, Veh &o) {
+  const int i = threadIdx.x;
+  const bool active = i < p.N;
+  bool controlled = false;
+  for (int a = 0; a < p.A; ++a) controlled |= (p.agent_index[a] == i);
+  double u_lane, u_speed, u_pos, u_delta;
+  philox_uniform2(seed, (uint32_t)i, episode, 0u, &u_lane, &u_speed);
+  philox_uniform2(seed, (uint32_t)i, episode, 1u, &u_pos, &u_delta);
+  int lane = (int)(u_lane * p.L);
+  if (lane > p.L - 1) lane = p.L - 1;
+  if (controlled && p.rp.initial_lane_id >= 0) lane = p.rp.initial_lane_id;
+  // speed: ego 25.0; others uniform(0.7*limit, 0.8*limit) == low + (high-low)*u  (numpy's formula)
+  const double lo = 0.7 * p.speed_limit, hi = 0.8 * p.speed_limit;
+  const double speed = controlled ? 25.0 : lo + (hi - lo) * u_speed;
+  const double spacing = controlled ? p.rp.ego_spacing : p.rp.other_spacing;
+  const double default_spacing = 12 + 1.0 * speed;
+  const double offset = spacing * default_spacing * p.rp.lane_factor;
+  const double step = offset * (0.9 + (1.1 - 0.9) * u_pos);  // offset * uniform(0.9, 1.1)
+  if (active) sh.aux0[i] = step;
+  if (active && i == 0) sh.aux1[0] = 3 * offset;  // first vehicle starts from 3*offset
+  __syncthreads();
+  // x_k = max_x(existing) + step_k == running sum in creation order (steps are positive)
+  double x = sh.aux1[0];
+  for (int k = 0; k <= i && k < p.N; ++k) x += sh.aux0[k];
+  __syncthreads();
+  o.x = x;
+  o.y = lane * p.lane_width;
+  o.h = 0.0;
+  o.v = speed;
+  o.lane = lane;
+  o.tgt = lane;
+  o.impx = o.impy = 0.0;
+  o.ch = 1.0;
+  o.sh = 0.0;
+  if (controlled) {
+    // MDPVehicle: speed_index = speed_to_index(target_speed=speed); target_speed = ladder[idx]
+    const double xs = (speed - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+    o.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
+    o.ts = p.target_speeds[o.sidx];
+    o.timer = 0.0;
+    o.delta = 0.0;
+    o.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
+  } else {
+    o.sidx = 0;
+    o.ts = speed;
+    o.timer = fmod((o.x + o.y) * HWY_PI, HWY_LC_DELAY);  // operands positive: % == fmod
+    o.delta = 3.5 + (4.5 - 3.5) * u_delta;
+    o.flags = p.rp.fast ? 0 : HWY_F_CHECK_COLLISIONS;
+  }
+  (void)e;
+}
+
+// ---- KinematicObservation.observe (envs/common/observation.py:234-276) + Road.close_objects_to
+//      (road/road.py:421-450) + reward/termination (envs/highway_env.py:100-151) for every agent.
+//      Expects sh.x/y/v/c/s to hold the CURRENT state of all vehicles.  Block-uniform control flow.
+template <int NW>
+__device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::Shared &sh, int e, const Veh &me,
+                                   bool write_reward) {
+  typedef EnvBlock<NW> B;
+  const int i = threadIdx.x;
+  const bool active = i < p.N;
+  const int V = p.V, F = p.F;
+  for (int a = 0; a < p.A; ++a) {
+    const int ia = p.agent_index[a];
+    const double ex = sh.x[ia], ey = sh.y[ia], ev = sh.v[ia], ec = sh.c[ia], es = sh.s[ia];
+    // eligibility (road.py:430-436): within perception distance, not self, not more than 2*LENGTH behind
+    const double dxe = me.x - ex, dye = me.y - ey;
+    const double d_lane = me.x - ex;  // lane_distance_to on the ego's (straight) lane
+    const bool elig = active && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
+                      ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
+    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    __syncthreads();  // previous users of aux0 are done
+    sh.aux0[i] = key;
+    __syncthreads();
+    u64 em[NW];
+    B::block_ballot(sh, elig, sh.bal0, em);
+    int n_elig = 0;
+    for (int w = 0; w < NW; ++w) n_elig += __popcll(em[w]);
+    const int m = n_elig < V - 1 ? n_elig : V - 1;  // rows 1..m are filled
+    // stable sort position (sorted() keeps list order among equal keys)
+    int pos = 0;
+    if (elig) {
+      for (int k = 0; k < p.N; ++k) {
+        const double kk = sh.aux0[k];
+        pos += (kk < key) || (kk == key && k < i);
+      }
+    }
+    if (p.obs) {
+      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
+      if (active && row >= 0) {
+        for (int f = 0; f < F; ++f) {
+          const int fid = p.feat[f];
+          double val = B::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
+          const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+          if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
+            const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+            val -= origin;
+          }
+          if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
+            const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+            const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+            if (r0 > -__builtin_inf()) {  // -inf/+inf == feature absent from features_range
+              val = lmap(val, r0, r1, -1.0, 1.0);
+              if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
+            }
+          }
+          out[row * F + f] = (float)val;
+        }
+      }
+      // zero-fill the missing rows (observation.py:262-267)
+      for (int t = i; t < V * F; t += B::NV)
+        if (t / F > m) out[t] = 0.0f;
+    }
+    if (write_reward && i == ia) {
+      // HighwayEnv._rewards / _reward (highway_env.py:100-139)
+      const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
+      const bool on_road = fabs(me.y - me.lane * p.lane_width) <= p.lane_width / 2 + 0.0 && -5.0 <= me.x &&
+                           me.x < p.road_length + 5.0;
+      const double forward_speed = me.v * me.ch;
+      const double scaled_speed = lmap(forward_speed, p.rs0, p.rs1, 0.0, 1.0);
+      const int nl = p.L - 1 > 1 ? p.L - 1 : 1;
+      double reward = 0.0;
+      reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
+      reward = reward + p.right_lane_reward * ((double)me.tgt / (double)nl);
+      reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
+      reward = reward + 0.0 * (on_road ? 1.0 : 0.0);
+      if (p.flags & HWY_C_NORMALIZE_REWARD)
+        reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
+      reward *= (on_road ? 1.0 : 0.0);
+      p.reward[(size_t)e * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      if (a == 0) {
+        // _is_terminated looks at controlled_vehicles[0] (highway_env.py:141-147); time += 1/policy_frequency
+        // (abstract.py:274); _is_truncated: time >= duration (highway_env.py:149-151)
+        const bool term = crashed || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
+        const double t = p.st.time[e] + p.policy_dt;
+        const bool trunc = t >= p.duration;
+        p.st.time[e] = t;
+        p.terminated[e] = term ? 1 : 0;
+        p.truncated[e] = trunc ? 1 : 0;
+        if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+      }
+    }
+  }
+}
+
+template <int NW>
+__device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
+  const int i = threadIdx.x;
+  o = Veh{};
+  if (i < p.N) {
+    const size_t k = (size_t)e * p.pitch + i;
+    o.x = p.st.x[k]; o.y = p.st.y[k]; o.h = p.st.heading[k]; o.v = p.st.speed[k];
+    o.timer = p.st.timer[k]; o.ts = p.st.target_speed[k]; o.delta = p.st.delta[k];
+    o.impx = p.st.impact_x[k]; o.impy = p.st.impact_y[k];
+    const int w = p.st.packed[k];
+    o.lane = w & 0xff; o.tgt = (w >> 8) & 0xff; o.sidx = (w >> 16) & 0xff; o.flags = (w >> 24) & 0xff;
+    o.ch = cos(o.h);
+    o.sh = sin(o.h);
+  }
+}
+template <int NW>
+__device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o) {
+  const int i = threadIdx.x;
+  if (i < p.N) {
+    const size_t k = (size_t)e * p.pitch + i;
+    p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
+    p.st.timer[k] = o.timer; p.st.target_speed[k] = o.ts; p.st.delta[k] = o.delta;
+    p.st.impact_x[k] = o.impx; p.st.impact_y[k] = o.impy;
+    p.st.packed[k] = pack_word(o.lane, o.tgt, o.sidx, o.flags);
+  }
+}
+template <int NW>
+__device__ inline void publish(typename EnvBlock<NW>::Shared &sh, const Veh &me, bool active) {
+  const int i = threadIdx.x;
+  if (active) {
+    sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = me.ch; sh.s[i] = me.sh; sh.ts[i] = me.ts;
+    sh.lane[i] = me.lane; sh.tgt[i] = me.tgt;
+  }
+}
+
+// =============================================================================================
+// Reset kernel: AbstractEnv.reset for the masked environments + first observation.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) hwy_reset_kernel(const StepParams p) {
+  typedef EnvBlock<NW> B;
+  __shared__ typename B::Shared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
+  const bool active = i < p.N;
+  Veh me = Veh{};
+  const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
+  spawn_env<NW>(p, sh, e, seed, 0u, me);
+  publish<NW>(sh, me, active);
+  __syncthreads();
+  observe_env<NW>(p, sh, e, me, false);
+  store_vehicle<NW>(p, e, me);
+  if (i == 0) {
+    p.st.time[e] = 0.0;
+    p.st.done[e] = 0;
+    p.st.episode[e] = 0;
+  }
+}
+
+// Observation-only kernel (hwy_observe).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) hwy_observe_kernel(const StepParams p) {
+  typedef EnvBlock<NW> B;
+  __shared__ typename B::Shared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  Veh me;
+  load_vehicle<NW>(p, e, me);
+  publish<NW>(sh, me, i < p.N);
+  __syncthreads();
+  observe_env<NW>(p, sh, e, me, false);
+}
+
+// =============================================================================================
+// The fused policy-step kernel.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
+  typedef EnvBlock<NW> B;
+  __shared__ typename B::Shared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  const int N = p.N;
+  const bool active = i < N;
+  const int lane_id = i & 63, wave = i >> 6;
+
+  // ---- auto-reset (gymnasium vector "next-step" mode): re-spawn instead of stepping ------------
+  if (p.autoreset && p.st.done[e]) {  // block-uniform
+    Veh me = Veh{};
+    const uint32_t episode = p.st.episode[e] + 1u;
+    spawn_env<NW>(p, sh, e, p.rp.base_seed + (uint64_t)e, episode, me);
+    publish<NW>(sh, me, active);
+    __syncthreads();
+    observe_env<NW>(p, sh, e, me, false);
+    store_vehicle<NW>(p, e, me);
+    if (active && (me.flags & HWY_F_CONTROLLED)) {
+      for (int a = 0; a < p.A; ++a)
+        if (p.agent_index[a] == i) {
+          p.reward[(size_t)e * p.A + a] = 0.0;
+          if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
+          if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = 0;
+        }
+    }
+    if (i == 0) {
+      p.st.time[e] = 0.0;
+      p.st.done[e] = 0;
+      p.st.episode[e] = episode;
+      p.terminated[e] = 0;
+      p.truncated[e] = 0;
+    }
+    return;
+  }
+
+  Veh me;
+  load_vehicle<NW>(p, e, me);
+  const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
+  const bool idm = active && !controlled;
+  int agent = 0;
+  if (controlled)
+    for (int a = 0; a < p.A; ++a)
+      if (p.agent_index[a] == i) agent = a;
+
+  // static collision-check membership (index space)
+  u64 chk[NW];
+  B::block_ballot(sh, active && (me.flags & HWY_F_CHECK_COLLISIONS), sh.bal0, chk);
+  int n_chk = 0;
+  for (int w = 0; w < NW; ++w) n_chk += __popcll(chk[w]);
+  const bool all_check = n_chk == N;  // highway-v0: full pairwise; highway-fast-v0: ego only
+
+  for (int fr = 0; fr < p.n_frames; ++fr) {
+    // ---- A. action_type.act (abstract.py:294-304) -> MDPVehicle.act(label) (controller.py:295-315):
+    //         target updates only; the controllers run below with Road.act (same state => same command)
+    if (fr == 0 && p.actions && controlled) {
+      const int act = p.actions[(size_t)e * p.A + agent];
+      if (act == HWY_FASTER || act == HWY_SLOWER) {
+        const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+        int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
+        idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
+        me.sidx = idx;
+        me.ts = p.target_speeds[idx];
+      } else if (act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) {
+        int id = me.tgt + (act == HWY_LANE_RIGHT ? 1 : -1);
+        id = id < 0 ? 0 : (id > p.L - 1 ? p.L - 1 : id);
+        if (B::reachable(p, id, me.x, me.y)) me.tgt = id;
+      }
+    }
+
+    // ---- B. frame-start snapshot -> LDS -----------------------------------------------------------
+    __syncthreads();  // everyone is done reading the previous snapshot
+    publish<NW>(sh, me, active);
+    __syncthreads();
+
+    // ---- C. rank along the road + lane membership masks ---------------------------------------------
+    int rank = 0;
+    bool tie = false;
+    for (int j = 0; j < N; ++j) {
+      const double xj = sh.x[j];
+      rank += (xj < me.x) || (xj == me.x && j < i);
+      tie |= (xj == me.x && j != i);
+    }
+    if (active) sh.perm[rank] = i;
+    u64 tm[NW];
+    B::block_ballot(sh, active && tie, sh.bal1, tm);
+    const bool has_tie = B::any_of(tm);
+    __syncthreads();
+    {
+      const int j = active ? sh.perm[i] : 0;
+      const double xj = sh.x[j], yj = sh.y[j];
+      const bool inr = active && (-5.0 <= xj) && (xj < p.road_length + 5.0);
+      for (int L = 0; L < p.L; ++L) {
+        const bool m = inr && (fabs(yj - L * p.lane_width) <= p.lane_width / 2 + 1.0);
+        const u64 b = __ballot(m);
+        if (lane_id == 0) sh.mask[L][wave] = b;
+      }
+    }
+    __syncthreads();
+
+    // ---- D. Road.act: lane-change policy (behavior.py:219-263) ----------------------------------------
+    const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
+    const bool drives = idm && !crashed0;  // IDMVehicle.act returns early when crashed (behavior.py:102-103)
+    const int tgt_old = me.tgt;
+    const bool changer = drives && me.lane != me.tgt;
+    const bool decide = drives && me.lane == me.tgt && (HWY_LC_DELAY < me.timer);  // utils.do_every
+    int f_own = -1, r_own = -1;
+    double free_self = 0.0;
+    if (drives) {
+      if (!has_tie) B::neighbours_ranked(sh, me.lane, rank, &f_own, &r_own);
+      else B::neighbours_scan(p, sh, me.lane, i, me.x, &f_own, &r_own);
+      free_self = B::idm_free(p, me.v, me.ts, me.delta);
+    }
+    if (decide) {
+      me.timer = 0.0;
+      // self_a: my IDM acceleration behind my current leader (old_preceding)
+      const double self_a = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own],
+                                                                sh.c[f_own], sh.s[f_own]) : 0.0);
+      for (int side = 0; side < 2; ++side) {  // side_lanes: [id-1], [id+1]  (road.py:200-211)
+        const int cand = me.lane + (side == 0 ? -1 : 1);
+        if (cand < 0 || cand >= p.L) continue;
+        if (!B::reachable(p, cand, me.x, me.y)) continue;
+        if (fabs(me.v) < 1) continue;
+        // mobil(cand)  (behavior.py:265-324; route is None; POLITENESS == 0 so the followers' terms are
+        // multiplied by 0.0 -- finite by construction -- and only the safety criterion needs new_following)
+        int nprec, nfoll;
+        if (!has_tie) B::neighbours_ranked(sh, cand, rank, &nprec, &nfoll);
+        else B::neighbours_scan(p, sh, cand, i, me.x, &nprec, &nfoll);
+        if (nfoll >= 0) {
+          const double nf_pred_a = B::idm_free(p, sh.v[nfoll], sh.ts[nfoll], me.delta) -
+                                   B::idm_gap(sh.x[nfoll], sh.v[nfoll], sh.c[nfoll], sh.s[nfoll], me.x, me.v, me.ch, me.sh);
+          if (nf_pred_a < -HWY_LC_MAX_BRAKING) continue;
+        }
+        const double self_pred_a = free_self - (nprec >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[nprec], sh.v[nprec],
+                                                                        sh.c[nprec], sh.s[nprec]) : 0.0);
+        const double jerk = self_pred_a - self_a;
+        if (jerk < HWY_LC_MIN_ACC_GAIN) continue;
+        me.tgt = cand;
+      }
+    }
+    // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
+    {
+      u64 cm[NW];
+      B::block_ballot(sh, changer, sh.bal2, cm);
+      for (int w = 0; w < NW; ++w) {
+        u64 m = cm[w];
+        while (m) {  // block-uniform loop
+          const int ci = w * 64 + ctz64(m);
+          m &= m - 1;
+          const int Tc = sh.tgt[ci];  // the changer's target lane (unchanged so far this frame)
+          const double xc = sh.x[ci], vc = sh.v[ci], cc = sh.c[ci], sc = sh.s[ci];
+          // what vehicle ci reads from me: my target AFTER my act if I come before it in the list
+          const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+          bool blk = false;
+          if (active && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+            const double d = me.x - xc;
+            const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
+            blk = (0 < d) && (d < d_star);
+          }
+          u64 bm[NW];
+          B::block_ballot(sh, blk, sh.bal1, bm);
+          if (i == ci && B::any_of(bm)) me.tgt = me.lane;  // abort
+        }
+      }
+    }
+
+    // ---- E. Road.act: low-level control (controller.py:89-133, behavior.py:104-137) ---------------------
+    double steering = 0.0, accel = 0.0;
+    if (controlled) {
+      steering = clipd(B::steering_control(p, me.y, me.h, me.v, me.tgt), -HWY_MAX_STEER, HWY_MAX_STEER);
+      accel = HWY_KP_A * (me.ts - me.v);
+    } else if (drives) {
+      steering = clipd(B::steering_control(p, me.y, me.h, me.v, me.tgt), -HWY_MAX_STEER, HWY_MAX_STEER);
+      accel = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own], sh.c[f_own],
+                                                   sh.s[f_own]) : 0.0);
+      if (me.lane != me.tgt) {
+        int f2, r2;
+        if (!has_tie) B::neighbours_ranked(sh, me.tgt, rank, &f2, &r2);
+        else B::neighbours_scan(p, sh, me.tgt, i, me.x, &f2, &r2);
+        const double a2 = free_self - (f2 >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f2], sh.v[f2], sh.c[f2],
+                                                            sh.s[f2]) : 0.0);
+        accel = (a2 < accel) ? a2 : accel;  // Python min(a, b)
+      }
+      accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
+    }
+
+    // ---- F. Road.step: integrate (behavior.py:139-148, kinematics.py:130-177) --------------------------
+    if (active) {
+      if (idm) me.timer += p.dt;
+      if (crashed0) {  // clip_actions
+        steering = 0.0;
+        accel = -1.0 * me.v;
+      }
+      if (me.v > HWY_MAX_SPEED) accel = fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v));
+      else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
+      const double beta = atan(1.0 / 2 * tan(steering));
+      const double vx = me.v * cos(me.h + beta), vy = me.v * sin(me.h + beta);
+      me.x += vx * p.dt;
+      me.y += vy * p.dt;
+      if (me.flags & HWY_F_HAS_IMPACT) {
+        me.x += me.impx;
+        me.y += me.impy;
+        me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
+        me.impx = me.impy = 0.0;
+      }
+      me.h += me.v * sin(beta) / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.v += accel * p.dt;
+      me.lane = B::closest_lane(p, me.x, me.y, me.h);  // on_state_update
+      me.ch = cos(me.h);
+      me.sh = sin(me.h);
+    }
+
+    // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
+    __syncthreads();  // all reads of the frame-start snapshot are done
+    publish<NW>(sh, me, active);
+    __syncthreads();
+    if (all_check) {
+      // full pairwise: every thread walks its partners in index order; the partner with the highest
+      // index is the last writer of `impact` in the reference's (i, j>i) loop order.
+      if (active) {
+        for (int q = 0; q < N; ++q) {
+          if (q == i) continue;
+          // conservative reject (never skips a pair the exact pre-check of objects.py:124-127 would keep):
+          // exact radius is sqrt(29) + speed_a*dt <= 5.5 + max|speed|*dt
+          const double dx = sh.x[q] - me.x, dy = sh.y[q] - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[q])) * p.dt;
+          if (dx * dx + dy * dy > lim * lim) continue;
+          const int a = i < q ? i : q, b = i < q ? q : i;
+          double tx, ty;
+          const int r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
+          if (r & 2) {
+            me.impx = (i == a) ? tx / 2 : -tx / 2;
+            me.impy = (i == a) ? ty / 2 : -ty / 2;
+            me.flags |= HWY_F_HAS_IMPACT;
+          }
+          if (r & 1) me.flags |= HWY_F_CRASHED;
+        }
+      }
+    } else {
+      // sparse checkers (highway-fast-v0: the ego only): for each checker c, thread q evaluates the pair
+      // {c, q}; q applies it to itself (ascending c == loop order), c gathers from all q.
+      for (int w = 0; w < NW; ++w) {
+        u64 m = chk[w];
+        while (m) {  // block-uniform
+          const int c = w * 64 + ctz64(m);
+          m &= m - 1;
+          int r = 0;
+          double tx = 0, ty = 0;
+          if (active && i != c) {
+            const int a = i < c ? i : c, b = i < c ? c : i;
+            r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
+            const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;
+            if (!i_check) {  // my only partners are the checkers
+              if (r & 2) {
+                me.impx = (i == a) ? tx / 2 : -tx / 2;
+                me.impy = (i == a) ? ty / 2 : -ty / 2;
+                me.flags |= HWY_F_HAS_IMPACT;
+              }
+              if (r & 1) me.flags |= HWY_F_CRASHED;
+            }
+            sh.aux0[i] = tx;
+            sh.aux1[i] = ty;
+          }
+          u64 wm[NW], im[NW];
+          const u64 bw = __ballot((r & 2) != 0), bi = __ballot((r & 1) != 0);
+          if (lane_id == 0) { sh.bal0[wave] = bw; sh.bal1[wave] = bi; }
+          __syncthreads();
+          for (int ww = 0; ww < NW; ++ww) { wm[ww] = sh.bal0[ww]; im[ww] = sh.bal1[ww]; }
+          if (i == c) {
+            if (B::any_of(im)) me.flags |= HWY_F_CRASHED;
+            for (int ww = NW - 1; ww >= 0; --ww)
+              if (wm[ww]) {
+                const int q = ww * 64 + msb64(wm[ww]);  // last partner in loop order
+                const double qx = sh.aux0[q], qy = sh.aux1[q];
+                me.impx = (c < q) ? qx / 2 : -qx / 2;
+                me.impy = (c < q) ? qy / 2 : -qy / 2;
+                me.flags |= HWY_F_HAS_IMPACT;
+                break;
+              }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }  // frames
+
+  // ---- H. observe / reward / done (abstract.py:277-281) ---------------------------------------------------
+  if (p.full_step) {
+    // sh.x/y/v/c/s already hold the post-integration state of the last frame (collisions do not move anyone)
+    if (p.n_frames == 0) {
+      __syncthreads();
+      publish<NW>(sh, me, active);
+      __syncthreads();
+    }
+    observe_env<NW>(p, sh, e, me, true);
+  }
+  store_vehicle<NW>(p, e, me);
+}
+
+}  // namespace hwy

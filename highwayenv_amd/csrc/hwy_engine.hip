@@ -1,0 +1,495 @@
+// hwy_engine.hip -- C-ABI host side of the MI355X HighwayEnv step engine (include/hwy_engine.h).
+//
+// Owns the device-resident struct-of-arrays of E environments x N vehicles, one HIP stream,
+// pinned staging buffers for the host-pointer entry points, and HIP-event kernel timing.
+// There is deliberately NO CPU implementation behind these entry points: without a GPU
+// hwy_create fails with HWY_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hwy_engine.h"
+#include "hwy_launch.h"
+#include "hwy_params.h"
+
+using hwy::StepParams;
+
+struct hwy_engine {
+  hwy_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int pitch = 0;
+  // device state
+  double *d_f64 = nullptr;   // 9 fields x E x pitch
+  int32_t *d_packed = nullptr;
+  double *d_time = nullptr;
+  uint8_t *d_done = nullptr;
+  uint32_t *d_episode = nullptr;
+  // device I/O buffers for the host-pointer entry points
+  int32_t *d_actions = nullptr;
+  float *d_obs = nullptr;
+  double *d_reward = nullptr, *d_info_speed = nullptr;
+  uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_info_crashed = nullptr;
+  uint8_t *d_mask = nullptr;
+  uint64_t *d_seeds = nullptr;
+  // pinned host staging
+  void *h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+  // auto-reset
+  int autoreset = 0;
+  hwy::ResetParams rp{};
+  // profiling
+  int profiling = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+#define HWY_HIP(eng, call)                                                                        \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      (eng)->err = std::string(#call) + ": " + hipGetErrorString(_e);                             \
+      return HWY_ERR_HIP;                                                                         \
+    }                                                                                             \
+  } while (0)
+
+static int fail(hwy_engine *eng, int code, const std::string &msg) {
+  if (eng) eng->err = msg; else g_create_error = msg;
+  return code;
+}
+
+extern "C" int hwy_abi_version(void) { return HWY_ABI_VERSION; }
+extern "C" size_t hwy_config_size(void) { return sizeof(hwy_config); }
+extern "C" int hwy_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" const char *hwy_status_string(int status) {
+  switch (status) {
+    case HWY_OK: return "ok";
+    case HWY_ERR_INVALID_ARG: return "invalid argument";
+    case HWY_ERR_HIP: return "HIP runtime error";
+    case HWY_ERR_UNSUPPORTED: return "unsupported configuration";
+    case HWY_ERR_NO_DEVICE: return "no MI355X / HIP device available (there is no CPU fallback)";
+    case HWY_ERR_ACTION: return "meta-action outside [0,5)";
+    default: return "unknown status";
+  }
+}
+extern "C" const char *hwy_last_error(const hwy_engine *eng) {
+  return eng ? eng->err.c_str() : g_create_error.c_str();
+}
+
+static int validate(const hwy_config *c, std::string &why) {
+  char buf[256];
+#define BAD(...) do { snprintf(buf, sizeof buf, __VA_ARGS__); why = buf; return HWY_ERR_INVALID_ARG; } while (0)
+  if (!c) BAD("config is NULL");
+  if (c->abi_version != HWY_ABI_VERSION) BAD("abi_version %d != %d", c->abi_version, HWY_ABI_VERSION);
+  if (c->num_envs < 1) BAD("num_envs must be >= 1");
+  if (c->num_vehicles < 1 || c->num_vehicles > HWY_MAX_VEHICLES) BAD("num_vehicles must be in [1,%d]", HWY_MAX_VEHICLES);
+  if (c->num_agents < 1 || c->num_agents > HWY_MAX_AGENTS || c->num_agents > c->num_vehicles) BAD("num_agents out of range");
+  for (int a = 0; a < c->num_agents; ++a)
+    if (c->agent_index[a] < 0 || c->agent_index[a] >= c->num_vehicles) BAD("agent_index[%d] out of range", a);
+  if (c->lanes_count < 1 || c->lanes_count > HWY_MAX_LANES) BAD("lanes_count must be in [1,%d]", HWY_MAX_LANES);
+  if (c->frames_per_step < 0) BAD("frames_per_step must be >= 0");
+  if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
+  if (c->obs_features < 1 || c->obs_features > HWY_MAX_FEATURES) BAD("obs_features out of range");
+  for (int f = 0; f < c->obs_features; ++f)
+    if (c->obs_feature_ids[f] < 0 || c->obs_feature_ids[f] >= HWY_FEAT_COUNT) BAD("unknown feature id");
+  if (c->num_target_speeds < 2 || c->num_target_speeds > HWY_MAX_TARGET_SPEEDS) BAD("num_target_speeds must be in [2,%d]", HWY_MAX_TARGET_SPEEDS);
+  if (!(c->dt > 0) || !(c->policy_dt > 0)) BAD("dt and policy_dt must be positive");
+  if (!(c->lane_width > 0) || !(c->road_length > 0)) BAD("lane_width and road_length must be positive");
+#undef BAD
+  return HWY_OK;
+}
+
+static void fill_params(const hwy_engine *eng, StepParams &p) {
+  hwy::params_from_config(eng->cfg, eng->pitch, p);
+  hwy::bind_planes(eng->d_f64, (size_t)eng->cfg.num_envs * eng->pitch, p.st);
+  p.st.packed = eng->d_packed; p.st.time = eng->d_time; p.st.done = eng->d_done; p.st.episode = eng->d_episode;
+  p.autoreset = eng->autoreset;
+  p.rp = eng->rp;
+}
+
+static size_t io_counts(const hwy_config &c, size_t *n_act, size_t *n_obs, size_t *n_ea) {
+  *n_act = (size_t)c.num_envs * c.num_agents;
+  *n_obs = *n_act * (size_t)c.obs_vehicles * c.obs_features;
+  *n_ea = *n_act;
+  return 0;
+}
+
+extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_engine **out) {
+  if (!out) return fail(nullptr, HWY_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  std::string why;
+  if (int rc = validate(cfg, why)) return fail(nullptr, rc, why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, HWY_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, HWY_ERR_INVALID_ARG, "device index out of range");
+  hwy_engine *eng = new (std::nothrow) hwy_engine();
+  if (!eng) return fail(nullptr, HWY_ERR_HIP, "out of host memory");
+  eng->cfg = *cfg;
+  eng->device = device;
+  eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
+  auto bail = [&](hipError_t e, const char *what) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+    hwy_destroy(eng);
+    return HWY_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if (stream) {
+    eng->stream = (hipStream_t)stream;
+  } else {
+    if ((e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    eng->own_stream = true;
+  }
+  const size_t E = cfg->num_envs, plane = E * eng->pitch;
+  size_t n_act, n_obs, n_ea;
+  io_counts(*cfg, &n_act, &n_obs, &n_ea);
+#define ALLOC(ptr, bytes) if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) return bail(e, "hipMalloc " #ptr)
+  ALLOC(eng->d_f64, plane * 9 * sizeof(double));
+  ALLOC(eng->d_packed, plane * sizeof(int32_t));
+  ALLOC(eng->d_time, E * sizeof(double));
+  ALLOC(eng->d_done, E);
+  ALLOC(eng->d_episode, E * sizeof(uint32_t));
+  ALLOC(eng->d_actions, n_act * sizeof(int32_t));
+  ALLOC(eng->d_obs, n_obs * sizeof(float));
+  ALLOC(eng->d_reward, n_ea * sizeof(double));
+  ALLOC(eng->d_info_speed, n_ea * sizeof(double));
+  ALLOC(eng->d_term, E);
+  ALLOC(eng->d_trunc, E);
+  ALLOC(eng->d_info_crashed, n_ea);
+  ALLOC(eng->d_mask, E);
+  ALLOC(eng->d_seeds, E * sizeof(uint64_t));
+#undef ALLOC
+  if ((e = hipMemsetAsync(eng->d_f64, 0, plane * 9 * sizeof(double), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemsetAsync(eng->d_packed, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemsetAsync(eng->d_time, 0, E * sizeof(double), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemsetAsync(eng->d_done, 0, E, eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+  if ((e = hipMemsetAsync(eng->d_episode, 0, E * sizeof(uint32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+  // pinned staging: the largest of {state SoA, step I/O}
+  const size_t state_bytes = plane * (9 * sizeof(double) + sizeof(int32_t)) + E * sizeof(double);
+  const size_t io_bytes = n_act * 4 + n_obs * 4 + n_ea * (8 + 8 + 1) + E * 2 + E * 9 + 64;
+  eng->h_pinned_bytes = state_bytes > io_bytes ? state_bytes : io_bytes;
+  if ((e = hipHostMalloc(&eng->h_pinned, eng->h_pinned_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  if ((e = hipStreamSynchronize(eng->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+  // default reset parameters: highway-v0 semantics (every vehicle checks collisions)
+  eng->rp.ego_spacing = 2.0;
+  eng->rp.other_spacing = 1.0;
+  eng->rp.lane_factor = std::exp(-5.0 / 40.0 * cfg->lanes_count);
+  eng->rp.initial_lane_id = -1;
+  eng->rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;  // HighwayEnvFast (highway_env.py:177-182)
+  eng->rp.base_seed = 0;
+  *out = eng;
+  return HWY_OK;
+}
+
+extern "C" int hwy_destroy(hwy_engine *eng) {
+  if (!eng) return HWY_OK;
+  (void)hipSetDevice(eng->device);
+  if (eng->stream) (void)hipStreamSynchronize(eng->stream);
+  for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_obs,
+                  eng->d_reward, eng->d_info_speed, eng->d_term, eng->d_trunc, eng->d_info_crashed, eng->d_mask,
+                  eng->d_seeds};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
+  if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
+  if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
+  delete eng;
+  return HWY_OK;
+}
+
+// ---- state injection / inspection -----------------------------------------------------------------
+static void pack_rows(const hwy_engine *eng, const double *src, double *dst) {  // [E][N] -> [E][pitch]
+  const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
+  for (int e = 0; e < E; ++e) {
+    std::memcpy(dst + (size_t)e * P, src + (size_t)e * N, sizeof(double) * N);
+    for (int i = N; i < P; ++i) dst[(size_t)e * P + i] = 0.0;
+  }
+}
+static void unpack_rows(const hwy_engine *eng, const double *src, double *dst) {  // [E][pitch] -> [E][N]
+  const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
+  for (int e = 0; e < E; ++e) std::memcpy(dst + (size_t)e * N, src + (size_t)e * P, sizeof(double) * N);
+}
+
+extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
+  if (!eng || !h) return HWY_ERR_INVALID_ARG;
+  const double *fields[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};
+  for (auto f : fields) if (!f) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: NULL field");
+  if (!h->lane || !h->target_lane || !h->speed_index || !h->flags || !h->time)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: NULL field");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
+  const size_t plane = (size_t)E * P;
+  for (size_t k = 0; k < (size_t)E * N; ++k) {
+    if (h->lane[k] < 0 || h->lane[k] >= eng->cfg.lanes_count || h->target_lane[k] < 0 ||
+        h->target_lane[k] >= eng->cfg.lanes_count)
+      return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: lane index out of range");
+    if (h->speed_index[k] < 0 || h->speed_index[k] >= eng->cfg.num_target_speeds)
+      return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: speed_index out of range");
+  }
+  double *stage = (double *)eng->h_pinned;
+  for (int f = 0; f < 9; ++f) pack_rows(eng, fields[f], stage + f * plane);
+  int32_t *pk = (int32_t *)(stage + 9 * plane);
+  for (int e = 0; e < E; ++e)
+    for (int i = 0; i < P; ++i) {
+      const size_t k = (size_t)e * N + i;
+      pk[(size_t)e * P + i] = i < N ? hwy::pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k]) : 0;
+    }
+  double *tm = (double *)(pk + plane);
+  std::memcpy(tm, h->time, sizeof(double) * E);
+  HWY_HIP(eng, hipMemcpyAsync(eng->d_f64, stage, plane * 9 * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(eng->d_packed, pk, plane * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(eng->d_time, tm, E * sizeof(double), hipMemcpyHostToDevice, eng->stream));
+  HWY_HIP(eng, hipMemsetAsync(eng->d_done, 0, E, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  return HWY_OK;
+}
+
+extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
+  if (!eng || !h) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
+  const size_t plane = (size_t)E * P;
+  double *stage = (double *)eng->h_pinned;
+  int32_t *pk = (int32_t *)(stage + 9 * plane);
+  double *tm = (double *)(pk + plane);
+  HWY_HIP(eng, hipMemcpyAsync(stage, eng->d_f64, plane * 9 * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(pk, eng->d_packed, plane * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(tm, eng->d_time, E * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  double *fields[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};
+  for (int f = 0; f < 9; ++f) if (fields[f]) unpack_rows(eng, stage + f * plane, fields[f]);
+  for (int e = 0; e < E; ++e)
+    for (int i = 0; i < N; ++i) {
+      const int32_t w = pk[(size_t)e * P + i];
+      const size_t k = (size_t)e * N + i;
+      if (h->lane) h->lane[k] = w & 0xff;
+      if (h->target_lane) h->target_lane[k] = (w >> 8) & 0xff;
+      if (h->speed_index) h->speed_index[k] = (w >> 16) & 0xff;
+      if (h->flags) h->flags[k] = (w >> 24) & 0xff;
+    }
+  if (h->time) std::memcpy(h->time, tm, sizeof(double) * E);
+  return HWY_OK;
+}
+
+// ---- kernel timing ----------------------------------------------------------------------------------
+static int timed_launch(hwy_engine *eng, const StepParams &p) {
+  if (!eng->profiling) {
+    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream));
+    return HWY_OK;
+  }
+  if (eng->events_used == eng->events.size()) {
+    hipEvent_t a, b;
+    HWY_HIP(eng, hipEventCreate(&a));
+    HWY_HIP(eng, hipEventCreate(&b));
+    eng->events.emplace_back(a, b);
+  }
+  auto &pr = eng->events[eng->events_used++];
+  HWY_HIP(eng, hipEventRecord(pr.first, eng->stream));
+  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, hipEventRecord(pr.second, eng->stream));
+  return HWY_OK;
+}
+static int drain_events(hwy_engine *eng) {
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  for (size_t k = 0; k < eng->events_used; ++k) {
+    float ms = 0;
+    HWY_HIP(eng, hipEventElapsedTime(&ms, eng->events[k].first, eng->events[k].second));
+    eng->prof_ms += ms;
+    eng->prof_launches++;
+  }
+  eng->events_used = 0;
+  return HWY_OK;
+}
+extern "C" int hwy_profile_enable(hwy_engine *eng, int32_t enabled) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  if (int rc = drain_events(eng)) return rc;
+  eng->profiling = enabled ? 1 : 0;
+  if (enabled) { eng->prof_ms = 0.0; eng->prof_launches = 0; }
+  return HWY_OK;
+}
+extern "C" int hwy_profile_read(hwy_engine *eng, double *total_ms, int64_t *launches) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  if (int rc = drain_events(eng)) return rc;
+  if (total_ms) *total_ms = eng->prof_ms;
+  if (launches) *launches = eng->prof_launches;
+  return HWY_OK;
+}
+
+// ---- stepping ------------------------------------------------------------------------------------------
+extern "C" int hwy_step_device(hwy_engine *eng, const int32_t *d_actions, float *d_obs, double *d_reward,
+                               uint8_t *d_terminated, uint8_t *d_truncated, double *d_info_speed,
+                               uint8_t *d_info_crashed) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_step_device: actions/obs/reward/terminated/truncated must be non-NULL");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  StepParams p;
+  fill_params(eng, p);
+  p.n_frames = eng->cfg.frames_per_step;
+  p.full_step = 1;
+  p.actions = d_actions; p.obs = d_obs; p.reward = d_reward; p.terminated = d_terminated; p.truncated = d_truncated;
+  p.info_speed = d_info_speed; p.info_crashed = d_info_crashed;
+  if (eng->profiling && eng->events_used >= 65536)
+    if (int rc = drain_events(eng)) return rc;
+  return timed_launch(eng, p);
+}
+
+extern "C" int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward, uint8_t *terminated,
+                        uint8_t *truncated, double *info_speed, uint8_t *info_crashed) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (!actions || !obs || !reward || !terminated || !truncated)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_step: actions/obs/reward/terminated/truncated must be non-NULL");
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  const size_t E = eng->cfg.num_envs;
+  // the reference raises KeyError for an unknown meta-action before touching the simulation (action.py:260)
+  for (size_t k = 0; k < n_act; ++k)
+    if (actions[k] < 0 || actions[k] > 4) return fail(eng, HWY_ERR_ACTION, "meta-action outside [0,5)");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  // pinned layout: obs | reward | speed | actions | term | trunc | crashed
+  char *base = (char *)eng->h_pinned;
+  float *h_obs = (float *)base;                       base += ((n_obs * 4 + 7) & ~(size_t)7);
+  double *h_reward = (double *)base;                  base += n_ea * 8;
+  double *h_speed = (double *)base;                   base += n_ea * 8;
+  int32_t *h_act = (int32_t *)base;                   base += ((n_act * 4 + 7) & ~(size_t)7);
+  uint8_t *h_term = (uint8_t *)base;                  base += E;
+  uint8_t *h_trunc = (uint8_t *)base;                 base += E;
+  uint8_t *h_crashed = (uint8_t *)base;
+  std::memcpy(h_act, actions, n_act * 4);
+  HWY_HIP(eng, hipMemcpyAsync(eng->d_actions, h_act, n_act * 4, hipMemcpyHostToDevice, eng->stream));
+  if (int rc = hwy_step_device(eng, eng->d_actions, eng->d_obs, eng->d_reward, eng->d_term, eng->d_trunc,
+                               eng->d_info_speed, eng->d_info_crashed))
+    return rc;
+  HWY_HIP(eng, hipMemcpyAsync(h_obs, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_reward, eng->d_reward, n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_speed, eng->d_info_speed, n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_term, eng->d_term, E, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_trunc, eng->d_trunc, E, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_crashed, eng->d_info_crashed, n_ea, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  std::memcpy(obs, h_obs, n_obs * 4);
+  std::memcpy(reward, h_reward, n_ea * 8);
+  std::memcpy(terminated, h_term, E);
+  std::memcpy(truncated, h_trunc, E);
+  if (info_speed) std::memcpy(info_speed, h_speed, n_ea * 8);
+  if (info_crashed) std::memcpy(info_crashed, h_crashed, n_ea);
+  return HWY_OK;
+}
+
+extern "C" int hwy_step_frames(hwy_engine *eng, const int32_t *actions, int32_t n_frames) {
+  if (!eng || n_frames < 0) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  StepParams p;
+  fill_params(eng, p);
+  p.n_frames = n_frames;
+  p.full_step = 0;
+  p.autoreset = 0;
+  if (actions) {
+    for (size_t k = 0; k < n_act; ++k)
+      if (actions[k] < 0 || actions[k] > 4) return fail(eng, HWY_ERR_ACTION, "meta-action outside [0,5)");
+    std::memcpy(eng->h_pinned, actions, n_act * 4);
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_actions, eng->h_pinned, n_act * 4, hipMemcpyHostToDevice, eng->stream));
+    p.actions = eng->d_actions;
+  }
+  p.reward = eng->d_reward; p.terminated = eng->d_term; p.truncated = eng->d_trunc;
+  if (int rc = timed_launch(eng, p)) return rc;
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  return HWY_OK;
+}
+
+extern "C" int hwy_observe(hwy_engine *eng, float *obs) {
+  if (!eng || !obs) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  StepParams p;
+  fill_params(eng, p);
+  p.obs = eng->d_obs;
+  p.reward = eng->d_reward; p.terminated = eng->d_term; p.truncated = eng->d_trunc;
+  HWY_HIP(eng, hwy::launch_observe(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(eng->h_pinned, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  std::memcpy(obs, eng->h_pinned, n_obs * 4);
+  return HWY_OK;
+}
+
+// ---- reset --------------------------------------------------------------------------------------------------
+static int set_reset_params(hwy_engine *eng, double ego_spacing, double vehicles_density, int32_t initial_lane_id) {
+  if (!(ego_spacing > 0) || !(vehicles_density > 0)) return fail(eng, HWY_ERR_INVALID_ARG, "spacing/density must be positive");
+  if (initial_lane_id >= eng->cfg.lanes_count) return fail(eng, HWY_ERR_INVALID_ARG, "initial_lane_id out of range");
+  eng->rp.ego_spacing = ego_spacing;
+  eng->rp.other_spacing = 1 / vehicles_density;  // highway_env.py:94
+  eng->rp.initial_lane_id = initial_lane_id < 0 ? -1 : initial_lane_id;
+  return HWY_OK;
+}
+
+extern "C" int hwy_reset(hwy_engine *eng, const uint8_t *mask, const uint64_t *seeds, double ego_spacing,
+                         double vehicles_density, int32_t initial_lane_id, float *obs) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (int rc = set_reset_params(eng, ego_spacing, vehicles_density, initial_lane_id)) return rc;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  const size_t E = eng->cfg.num_envs;
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  StepParams p;
+  fill_params(eng, p);
+  char *base = (char *)eng->h_pinned;
+  if (seeds) {
+    std::memcpy(base, seeds, E * 8);
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_seeds, base, E * 8, hipMemcpyHostToDevice, eng->stream));
+    p.reset_seeds = eng->d_seeds;
+  }
+  if (mask) {
+    std::memcpy(base + E * 8, mask, E);
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_mask, base + E * 8, E, hipMemcpyHostToDevice, eng->stream));
+    p.reset_mask = eng->d_mask;
+  }
+  p.obs = eng->d_obs;
+  p.reward = eng->d_reward; p.terminated = eng->d_term; p.truncated = eng->d_trunc;
+  HWY_HIP(eng, hwy::launch_reset(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  if (obs) {
+    HWY_HIP(eng, hipMemcpyAsync(eng->h_pinned, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
+    HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+    const size_t per_env = n_obs / E;
+    const float *src = (const float *)eng->h_pinned;
+    for (size_t e = 0; e < E; ++e)
+      if (!mask || mask[e]) std::memcpy(obs + e * per_env, src + e * per_env, per_env * 4);
+  }
+  return HWY_OK;
+}
+
+extern "C" int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base_seed, double ego_spacing,
+                                 double vehicles_density, int32_t initial_lane_id) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (int rc = set_reset_params(eng, ego_spacing, vehicles_density, initial_lane_id)) return rc;
+  eng->autoreset = enabled ? 1 : 0;
+  eng->rp.base_seed = base_seed;
+  return HWY_OK;
+}
+
+extern "C" int hwy_sync(hwy_engine *eng) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  return HWY_OK;
+}

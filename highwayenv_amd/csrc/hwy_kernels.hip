@@ -1,0 +1,27 @@
+// hwy_kernels.hip -- gfx950 translation unit: instantiates the fused step / reset /
+// observe kernels of hwy_device.h and exposes plain launch functions to the C-ABI host
+// (hwy_engine.cpp).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "hwy_device.h"
+#include "hwy_launch.h"
+
+namespace hwy {
+
+static inline int waves_for(int n_vehicles) { return (n_vehicles + 63) / 64; }
+
+#define HWY_DISPATCH(KERNEL)                                                                  \
+  switch (waves_for(p.N)) {                                                                   \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(num_envs), dim3(64), 0, stream, p); break;     \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(num_envs), dim3(128), 0, stream, p); break;    \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(num_envs), dim3(192), 0, stream, p); break;    \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(num_envs), dim3(256), 0, stream, p); break;    \
+    default: return hipErrorInvalidValue;                                                     \
+  }                                                                                           \
+  return hipGetLastError();
+
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_step_kernel) }
+hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_reset_kernel) }
+hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_observe_kernel) }
+
+}  // namespace hwy

@@ -1,0 +1,33 @@
+// hwy_params.h -- host helper: flatten hwy_config into the kernel-argument block.
+#pragma once
+#include <cstring>
+
+#include "hwy_device.h"
+
+namespace hwy {
+
+inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
+  std::memset(&p, 0, sizeof p);
+  p.N = c.num_vehicles; p.A = c.num_agents; p.L = c.lanes_count; p.T = c.frames_per_step;
+  p.flags = c.flags; p.V = c.obs_vehicles; p.F = c.obs_features; p.n_ts = c.num_target_speeds;
+  p.pitch = pitch;
+  for (int a = 0; a < HWY_MAX_AGENTS; ++a) p.agent_index[a] = a < c.num_agents ? c.agent_index[a] : -1;
+  for (int f = 0; f < HWY_MAX_FEATURES; ++f) p.feat[f] = c.obs_feature_ids[f];
+  for (int k = 0; k < HWY_MAX_TARGET_SPEEDS; ++k) p.target_speeds[k] = c.target_speeds[k];
+  p.dt = c.dt; p.policy_dt = c.policy_dt; p.duration = c.duration; p.lane_width = c.lane_width;
+  p.road_length = c.road_length; p.speed_limit = c.speed_limit;
+  p.collision_reward = c.collision_reward; p.right_lane_reward = c.right_lane_reward;
+  p.high_speed_reward = c.high_speed_reward; p.rs0 = c.reward_speed_range[0]; p.rs1 = c.reward_speed_range[1];
+  p.perception = c.perception_distance;
+  p.rx0 = c.obs_range_x[0]; p.rx1 = c.obs_range_x[1]; p.ry0 = c.obs_range_y[0]; p.ry1 = c.obs_range_y[1];
+  p.rvx0 = c.obs_range_vx[0]; p.rvx1 = c.obs_range_vx[1]; p.rvy0 = c.obs_range_vy[0]; p.rvy1 = c.obs_range_vy[1];
+}
+
+// the 9 f64 planes of the device SoA live in one allocation, [field][E][pitch]
+inline void bind_planes(double *f64, size_t plane, DevState &st) {
+  st.x = f64 + 0 * plane; st.y = f64 + 1 * plane; st.heading = f64 + 2 * plane; st.speed = f64 + 3 * plane;
+  st.timer = f64 + 4 * plane; st.target_speed = f64 + 5 * plane; st.delta = f64 + 6 * plane;
+  st.impact_x = f64 + 7 * plane; st.impact_y = f64 + 8 * plane;
+}
+
+}  // namespace hwy

@@ -1,0 +1,128 @@
+"""Thin object wrapper over the C-ABI (include/hwy_engine.h): one ``Engine`` == one GPU's
+batch of E environments.  Host numpy in / numpy out for the gymnasium-style API, raw device
+pointers for on-GPU policies, RCCL gathers and the benchmark.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    def __init__(self, cfg: _abi.HwyConfig, device: int = 0, stream: int | None = None):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self.E, self.N, self.A = cfg.num_envs, cfg.num_vehicles, cfg.num_agents
+        self.V, self.F = cfg.obs_vehicles, cfg.obs_features
+        h = C.c_void_p()
+        rc = self._lib.hwy_create(C.byref(cfg), int(device), C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            msg = self._lib.hwy_last_error(None).decode()
+            raise EngineError(f"hwy_create failed ({self._lib.hwy_status_string(rc).decode()}): {msg}")
+        self._h = h
+        self.device = device
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hwy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == _abi.HWY_ERR_ACTION:
+            # the reference raises KeyError from self.actions[int(action)] (envs/common/action.py:260)
+            raise KeyError(self._lib.hwy_last_error(self._h).decode())
+        if rc != 0:
+            raise EngineError(f"{self._lib.hwy_status_string(rc).decode()}: {self._lib.hwy_last_error(self._h).decode()}")
+
+    # -- state --------------------------------------------------------------------------------
+    def set_state(self, st: dict):
+        st = {k: np.ascontiguousarray(v) for k, v in st.items()}
+        s = _abi.state_struct(st)
+        self._check(self._lib.hwy_set_state(self._h, C.byref(s)))
+
+    def get_state(self) -> dict:
+        st = _abi.alloc_state(self.E, self.N)
+        s = _abi.state_struct(st)
+        self._check(self._lib.hwy_get_state(self._h, C.byref(s)))
+        return st
+
+    # -- stepping -----------------------------------------------------------------------------
+    def step(self, actions):
+        E, A = self.E, self.A
+        acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
+        obs = np.empty((E, A, self.V, self.F), np.float32)
+        reward = np.empty((E, A), np.float64)
+        term = np.empty(E, np.uint8)
+        trunc = np.empty(E, np.uint8)
+        speed = np.empty((E, A), np.float64)
+        crashed = np.empty((E, A), np.uint8)
+        self._check(self._lib.hwy_step(self._h, _ptr(acts), _ptr(obs), _ptr(reward), _ptr(term), _ptr(trunc),
+                                       _ptr(speed), _ptr(crashed)))
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+
+    def step_device(self, d_actions: int, d_obs: int, d_reward: int, d_terminated: int, d_truncated: int,
+                    d_info_speed: int = 0, d_info_crashed: int = 0):
+        """Enqueue one batched policy step on raw device pointers; does not synchronise."""
+        vp = C.c_void_p
+        self._check(self._lib.hwy_step_device(self._h, vp(d_actions), vp(d_obs), vp(d_reward), vp(d_terminated),
+                                              vp(d_truncated), vp(d_info_speed or None), vp(d_info_crashed or None)))
+
+    def step_frames(self, actions, n_frames: int):
+        acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(self.E, self.A))
+        self._check(self._lib.hwy_step_frames(self._h, _ptr(acts), int(n_frames)))
+
+    def observe(self) -> np.ndarray:
+        obs = np.empty((self.E, self.A, self.V, self.F), np.float32)
+        self._check(self._lib.hwy_observe(self._h, _ptr(obs)))
+        return obs
+
+    # -- reset --------------------------------------------------------------------------------
+    def reset(self, seeds=None, mask=None, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1, base_seed=0):
+        """Device-side spawn (counter-based RNG; NOT numpy's stream -- see spawn.py for that)."""
+        if seeds is None:
+            seeds = np.uint64(base_seed) + np.arange(self.E, dtype=np.uint64)
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        obs = np.zeros((self.E, self.A, self.V, self.F), np.float32)
+        self._check(self._lib.hwy_reset(self._h, _ptr(mk), _ptr(sd), float(ego_spacing), float(vehicles_density),
+                                        int(initial_lane_id), _ptr(obs)))
+        return obs
+
+    def set_autoreset(self, enabled: bool, base_seed: int = 0, ego_spacing=2.0, vehicles_density=1.0,
+                      initial_lane_id=-1):
+        self._check(self._lib.hwy_set_autoreset(self._h, int(bool(enabled)), C.c_uint64(base_seed), float(ego_spacing),
+                                                float(vehicles_density), int(initial_lane_id)))
+
+    # -- misc ---------------------------------------------------------------------------------
+    def sync(self):
+        self._check(self._lib.hwy_sync(self._h))
+
+    def profile_enable(self, enabled: bool = True):
+        self._check(self._lib.hwy_profile_enable(self._h, int(bool(enabled))))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.hwy_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def device_count() -> int:
+    return _lib.load().hwy_device_count()

@@ -68,7 +68,8 @@ enum {
   HWY_C_OBS_ABSOLUTE = 4,     /* KinematicObservation.absolute      observation.py:167 */
   HWY_C_OBS_NORMALIZE = 8,    /* KinematicObservation.normalize     observation.py:169 */
   HWY_C_OBS_CLIP = 16,        /* KinematicObservation.clip          observation.py:170 */
-  HWY_C_OBS_SEE_BEHIND = 32   /* KinematicObservation.see_behind    observation.py:171 */
+  HWY_C_OBS_SEE_BEHIND = 32,  /* KinematicObservation.see_behind    observation.py:171 */
+  HWY_C_EGO_ONLY_COLLISIONS = 64 /* HighwayEnvFast: spawned traffic has check_collisions=False (highway_env.py:177-182) */
 };
 
 /* observation feature ids (Vehicle.to_dict keys, vehicle/kinematics.py:237-261) */

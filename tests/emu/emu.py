@@ -1,0 +1,120 @@
+"""TEST INFRASTRUCTURE ONLY: run the product's kernel source on the CPU (tests/emu/hip_emu.h).
+
+``EmuEngine`` has the same Python surface as ``highwayenv_amd.engine.Engine`` so that the
+parity tests can be written once and run against the CPU emulation here (no GPU in the build
+container) and against the real HIP engine on the MI355X (``-m gpu``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from highwayenv_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = os.path.join(_HERE, "_build", "libhwy_emu.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, "emu_engine.cpp"), os.path.join(_HERE, "hip_emu.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_params.h"),
+            os.path.join(_ROOT, "include", "hwy_engine.h")]
+    stale = not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
+                        "-o", _LIB, srcs[0]], check=True, capture_output=True)
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.emu_config_size.restype = C.c_size_t
+        assert _lib.emu_config_size() == C.sizeof(_abi.HwyConfig)
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class EmuEngine:
+    def __init__(self, cfg: _abi.HwyConfig):
+        self.cfg = cfg
+        self.E, self.N, self.A = cfg.num_envs, cfg.num_vehicles, cfg.num_agents
+        self.st = _abi.alloc_state(self.E, self.N)
+        self.done = np.zeros(self.E, np.uint8)
+        self.episode = np.zeros(self.E, np.uint32)
+        self.autoreset = (0, 0, 2.0, 1.0, -1)
+
+    def close(self):
+        pass
+
+    def set_state(self, st):
+        self.st = _abi.copy_state(st)
+        self.done[:] = 0
+
+    def get_state(self):
+        return _abi.copy_state(self.st)
+
+    def set_autoreset(self, enabled, base_seed=0, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1):
+        self.autoreset = (int(enabled), int(base_seed), float(ego_spacing), float(vehicles_density), int(initial_lane_id))
+
+    def _run(self, mode, n_frames, actions):
+        E, A = self.E, self.A
+        acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
+        obs = np.zeros((E, A, self.cfg.obs_vehicles, self.cfg.obs_features), np.float32)
+        reward = np.zeros((E, A))
+        term = np.zeros(E, np.uint8)
+        trunc = np.zeros(E, np.uint8)
+        speed = np.zeros((E, A))
+        crashed = np.zeros((E, A), np.uint8)
+        s = _abi.state_struct(self.st)
+        ar = self.autoreset
+        rc = lib().emu_run(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
+                           C.c_int(mode), C.c_int(n_frames), _p(acts, C.c_int32), _p(obs, C.c_float),
+                           _p(reward, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(speed, C.c_double),
+                           _p(crashed, C.c_uint8), C.c_int(ar[0]), C.c_uint64(ar[1]), C.c_double(ar[2]),
+                           C.c_double(ar[3]), C.c_int(ar[4]))
+        assert rc == 0
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+
+    def step_frames(self, actions, n_frames):
+        self._run(0, n_frames, actions)
+
+    def step(self, actions):
+        a = np.asarray(actions)
+        if ((a < 0) | (a > 4)).any():
+            raise KeyError("invalid meta-action")
+        return self._run(1, self.cfg.frames_per_step, actions)
+
+    def observe(self):
+        return self._run(2, 0, None)[0]
+
+    def reset(self, seeds=None, mask=None, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1, base_seed=0):
+        E, A = self.E, self.A
+        obs = np.zeros((E, A, self.cfg.obs_vehicles, self.cfg.obs_features), np.float32)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        s = _abi.state_struct(self.st)
+        rc = lib().emu_reset(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
+                             _p(mk, C.c_uint8), _p(sd, C.c_uint64), C.c_uint64(base_seed), C.c_double(ego_spacing),
+                             C.c_double(vehicles_density), C.c_int(initial_lane_id), _p(obs, C.c_float))
+        assert rc == 0
+        return obs
+
+
+def philox_uniform2(seed, vehicle, episode, draw):
+    u0, u1 = C.c_double(), C.c_double()
+    lib().emu_philox_uniform2(C.c_uint64(seed), C.c_uint32(vehicle), C.c_uint32(episode), C.c_uint32(draw),
+                              C.byref(u0), C.byref(u1))
+    return u0.value, u1.value

@@ -1,0 +1,124 @@
+// emu_engine.cpp -- TEST INFRASTRUCTURE ONLY.  Runs the product's kernel source
+// (highwayenv_amd/csrc/hwy_device.h) on the CPU through hip_emu.h, on host SoA arrays.
+#include "hip_emu.h"
+
+#include <cstring>
+#include <vector>
+
+#include "../../highwayenv_amd/csrc/hwy_device.h"
+#include "../../highwayenv_amd/csrc/hwy_params.h"
+
+using hwy::StepParams;
+
+namespace {
+struct HostImage {
+  int E, N;
+  std::vector<double> f64;
+  std::vector<int32_t> packed;
+  HostImage(const hwy_config &c, const hwy_state &h) : E(c.num_envs), N(c.num_vehicles) {
+    const size_t plane = (size_t)E * N;
+    f64.resize(plane * 9);
+    packed.resize(plane);
+    const double *fields[9] = {h.x, h.y, h.heading, h.speed, h.timer, h.target_speed, h.delta, h.impact_x, h.impact_y};
+    for (int f = 0; f < 9; ++f) std::memcpy(&f64[f * plane], fields[f], plane * sizeof(double));
+    for (size_t k = 0; k < plane; ++k) packed[k] = hwy::pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k]);
+  }
+  void store(hwy_state &h) const {
+    const size_t plane = (size_t)E * N;
+    double *fields[9] = {h.x, h.y, h.heading, h.speed, h.timer, h.target_speed, h.delta, h.impact_x, h.impact_y};
+    for (int f = 0; f < 9; ++f) std::memcpy(fields[f], &f64[f * plane], plane * sizeof(double));
+    for (size_t k = 0; k < plane; ++k) {
+      const int32_t w = packed[k];
+      h.lane[k] = w & 0xff; h.target_lane[k] = (w >> 8) & 0xff; h.speed_index[k] = (w >> 16) & 0xff; h.flags[k] = (w >> 24) & 0xff;
+    }
+  }
+};
+
+
+enum Which { STEP, RESET, OBSERVE };
+void dispatch(Which which, const StepParams &p, int E) {
+  const int nw = (p.N + 63) / 64;
+#define RUN(NW)                                                                                         \
+  switch (which) {                                                                                      \
+    case STEP: emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW>(q); }, E, NW * 64, p); break;     \
+    case RESET: emu::launch([](const StepParams &q) { hwy::hwy_reset_kernel<NW>(q); }, E, NW * 64, p); break;   \
+    case OBSERVE: emu::launch([](const StepParams &q) { hwy::hwy_observe_kernel<NW>(q); }, E, NW * 64, p); break; \
+  }
+  switch (nw) {
+    case 1: RUN(1) break;
+    case 2: RUN(2) break;
+    case 3: RUN(3) break;
+    default: RUN(4) break;
+  }
+#undef RUN
+}
+}  // namespace
+
+extern "C" {
+
+size_t emu_config_size(void) { return sizeof(hwy_config); }
+
+// mode: 0 = frames only (hwy_step_frames), 1 = full policy step (hwy_step), 2 = observe only
+int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episode, int mode, int n_frames,
+            const int32_t *actions, float *obs, double *reward, uint8_t *term, uint8_t *trunc, double *speed,
+            uint8_t *crashed, int autoreset, uint64_t base_seed, double ego_spacing, double vehicles_density,
+            int initial_lane_id) {
+  HostImage img(*cfg, *st);
+  StepParams p;
+  hwy::params_from_config(*cfg, cfg->num_vehicles, p);
+  hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);
+  p.st.packed = img.packed.data();
+  p.st.time = st->time;
+  p.st.done = done;
+  p.st.episode = episode;
+  p.autoreset = autoreset;
+  p.rp.ego_spacing = ego_spacing;
+  p.rp.other_spacing = 1 / vehicles_density;
+  p.rp.lane_factor = exp(-5.0 / 40.0 * cfg->lanes_count);
+  p.rp.initial_lane_id = initial_lane_id;
+  p.rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;
+  p.rp.base_seed = base_seed;
+  p.actions = actions; p.obs = obs; p.reward = reward; p.terminated = term; p.truncated = trunc;
+  p.info_speed = speed; p.info_crashed = crashed;
+  if (mode == 2) {
+    dispatch(OBSERVE, p, cfg->num_envs);
+  } else {
+    p.n_frames = n_frames;
+    p.full_step = mode == 1;
+    if (mode == 0) p.autoreset = 0;
+    dispatch(STEP, p, cfg->num_envs);
+  }
+  img.store(*st);
+  return 0;
+}
+
+int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episode, const uint8_t *mask,
+              const uint64_t *seeds, uint64_t base_seed, double ego_spacing, double vehicles_density,
+              int initial_lane_id, float *obs) {
+  HostImage img(*cfg, *st);
+  StepParams p;
+  hwy::params_from_config(*cfg, cfg->num_vehicles, p);
+  hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);
+  p.st.packed = img.packed.data();
+  p.st.time = st->time;
+  p.st.done = done;
+  p.st.episode = episode;
+  p.rp.ego_spacing = ego_spacing;
+  p.rp.other_spacing = 1 / vehicles_density;
+  p.rp.lane_factor = exp(-5.0 / 40.0 * cfg->lanes_count);
+  p.rp.initial_lane_id = initial_lane_id;
+  p.rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;
+  p.rp.base_seed = base_seed;
+  p.reset_mask = mask;
+  p.reset_seeds = seeds;
+  p.obs = obs;
+  dispatch(RESET, p, cfg->num_envs);
+  img.store(*st);
+  return 0;
+}
+
+// host-side Philox, for tests of the device spawn rule
+void emu_philox_uniform2(uint64_t seed, uint32_t vehicle, uint32_t episode, uint32_t draw, double *u0, double *u1) {
+  hwy::philox_uniform2(seed, vehicle, episode, draw, u0, u1);
+}
+}
