@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched AbstractEnv.step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): highway-fast-v0 semantics, 4096 batched envs x 50 IDM
+vehicles (+1 ego = 51) per GPU, 4 lanes, DiscreteMetaAction (uniform random actions, pre-generated
+and resident in HBM), Kinematics 5x5 observation, device-side spawn + auto-reset on
+terminated/truncated.  One "step" == one batched policy step of every env == ONE launch of
+hwy_step_kernel (5 simulation frames + observe + reward + done).  Weak scaling: every rank owns
+4096 envs; with N>1 ranks the (obs, reward, terminated, truncated) block of every rank is gathered
+to rank 0 over RCCL each step.
+
+Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs, inputs resident in HBM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+VEHICLES_COUNT = 50
+LANES = 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int) -> int:
+    """B_env = 72*N + 110*A bytes per env-step."""
+    return 72 * n_vehicles + 110 * agents
+
+
+def cpu_baseline(cfg_dict, budget_s: float = 12.0):
+    """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
+    same workload: same config, same spawn rule, random actions."""
+    from highwayenv_amd import _abi, spawn
+    from oracle import oracle
+    E = 64
+    cfg = _abi.make_config(cfg_dict, E, fast=True)
+    st0 = spawn.spawn_reference_stream(cfg, np.arange(E) + 7, cfg_dict["ego_spacing"], cfg_dict["vehicles_density"])
+    rng = np.random.default_rng(3)
+    steps_done, t_used = 0, 0.0
+    st = _abi.copy_state(st0)
+    episode_len = int(cfg_dict["duration"])
+    while t_used < budget_s:
+        if steps_done % episode_len == 0:
+            st = _abi.copy_state(st0)  # bounded stand-in for per-env resets: restart the batch
+        acts = rng.integers(0, 5, size=(E, 1)).astype(np.int32)
+        t0 = time.perf_counter()
+        oracle.step(cfg, st, acts)
+        t_used += time.perf_counter() - t0
+        steps_done += 1
+    rate = steps_done * E / t_used
+    return {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{E} envs x {steps_done} policy steps of the same workload on 1 host core "
+                      f"(oracle/hwy_oracle.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
+            "vehicle_steps_per_s": rate * cfg.num_vehicles}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from highwayenv_amd import _abi
+    from highwayenv_amd.engine import Engine
+    from highwayenv_amd.dist import PackedStepOutputs
+
+    cfg_dict = _abi.highway_fast_default_config()
+    cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
+    E = args.envs_per_gpu
+    cfg = _abi.make_config(cfg_dict, E, fast=True)
+    N, A = cfg.num_vehicles, cfg.num_agents
+
+    stream = torch.cuda.current_stream(dev)
+    eng = Engine(cfg, device=local_rank, stream=stream.cuda_stream)
+    eng.reset(base_seed=1_000_003 * (rank + 1), ego_spacing=cfg_dict["ego_spacing"],
+              vehicles_density=cfg_dict["vehicles_density"])
+    eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), ego_spacing=cfg_dict["ego_spacing"],
+                      vehicles_density=cfg_dict["vehicles_density"])
+
+    total = args.warmup + args.steps
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    actions = torch.randint(0, 5, (total, E, A), generator=g, device=dev, dtype=torch.int32)
+    out = PackedStepOutputs(cfg, dev, world, rank)
+
+    def one_step(t: int) -> None:
+        eng.step_device(actions[t].data_ptr(), *out.pointers())
+        if world > 1:
+            out.gather_to_rank0()
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for t in range(args.warmup):
+        one_step(t)
+    fence()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        one_step(t)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+
+    # statistics of the run (sanity: the workload really stepped and reset)
+    term = out.terminated().sum().item()
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+
+    if rank == 0:
+        env_steps = args.steps * E * world
+        value = env_steps / elapsed
+        b_env = algorithmic_bytes_per_env_step(N, A)
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = b_env * E / avg_kernel_s / 1e9
+        line = {
+            "metric": "env-steps/s",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
+                                   f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
+                                   "device spawn + auto-reset",
+                       "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}"},
+            "vehicle_steps_per_s": value * N,
+            "vehicle_steps_per_s_excl_ego": value * VEHICLES_COUNT,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hwy_step_kernel<1>", "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
+                         "algorithmic_bytes_per_launch": b_env * E},
+            "terminated_in_last_step": int(term),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg_dict)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,8 +28,15 @@
 // "partner with the highest index wins".
 //
 // All arithmetic is IEEE f64 like the reference (objects.py:43), compiled
-// with -ffp-contract=off so that every a*b+c rounds twice exactly like
-// numpy's scalar ops; only libm (ocml vs numpy) differs, by ulps.
+// with -ffp-contract=off (no silent FMA contraction).  The reference pays
+// 12 libm calls per vehicle-frame (asin x2, tan x2, atan x2, cos x2, sin x3,
+// pow); here the steering -> slip -> bicycle chain is folded with exact
+// trigonometric identities (tan(asin w) = w/sqrt(1-w^2), tan(atan u) = u,
+// cos/sin(atan t) = (1,t)/sqrt(1+t^2), angle addition against the cached
+// cos/sin of the heading) so that only asin, sincos and pow remain -- each
+// folded expression agrees with the literal one to a few ulp, the same
+// order as ocml-vs-numpy libm differences, and is checked against the
+// literal C oracle at 1e-9 per frame.
 //
 // This header has no #include of the HIP runtime on purpose: the product
 // translation unit (hwy_kernels.hip) includes <hip/hip_runtime.h> first; the
@@ -244,32 +251,39 @@ struct EnvBlock {
     const double v0 = clipd(ts, 0.0, p.speed_limit);
     return HWY_COMFORT_ACC_MAX * (1 - pow(fmax(v, 0.0) / fabs(not_zero(v0)), delta));
   }
-  // interaction term COMFORT_ACC_MAX*(d*/d)^2 of `ego` behind `front`
-  __device__ static inline double idm_gap(double xe, double ve, double ce, double se, double xf, double vf,
-                                          double cf, double sf) {
-    const double d = xf - xe;  // lane_distance_to (objects.py:183-198): longitudinal == x
-    const double dv = (ve * ce - vf * cf) * ce + (ve * se - vf * sf) * se;
-    const double ab = -HWY_COMFORT_ACC_MAX * HWY_COMFORT_ACC_MIN;
-    const double d_star = HWY_DISTANCE_WANTED + ve * HWY_TIME_WANTED + ve * dv / (2 * sqrt(ab));
-    const double q = d_star / not_zero(d);
-    return HWY_COMFORT_ACC_MAX * (q * q);
-  }
+  // desired gap d* (behavior.py:192-217): projected speed difference, velocity = speed*(cos h, sin h)
   __device__ static inline double desired_gap(double ve, double ce, double se, double vf, double cf, double sf) {
     const double dv = (ve * ce - vf * cf) * ce + (ve * se - vf * sf) * se;
-    const double ab = -HWY_COMFORT_ACC_MAX * HWY_COMFORT_ACC_MIN;
-    return HWY_DISTANCE_WANTED + ve * HWY_TIME_WANTED + ve * dv / (2 * sqrt(ab));
+    const double inv_2sqrt_ab = 0.12909944487358055;  // 1 / (2*sqrt(-COMFORT_ACC_MAX*COMFORT_ACC_MIN)) = 1/(2 sqrt 15)
+    return HWY_DISTANCE_WANTED + ve * HWY_TIME_WANTED + (ve * dv) * inv_2sqrt_ab;
+  }
+  // interaction term COMFORT_ACC_MAX*(d*/d)^2 of `ego` behind `front`; d = lane_distance_to
+  // (objects.py:183-198): on the straight lane the longitudinal coordinate is x
+  __device__ static inline double idm_gap(double xe, double ve, double ce, double se, double xf, double vf,
+                                          double cf, double sf) {
+    const double q = desired_gap(ve, ce, se, vf, cf, sf) / not_zero(xf - xe);
+    return HWY_COMFORT_ACC_MAX * (q * q);
   }
 
-  // ---- ControlledVehicle.steering_control (vehicle/controller.py:145-187), StraightLane heading 0
-  __device__ static inline double steering_control(const StepParams &p, double y, double h, double v, int tgt) {
+  // ---- ControlledVehicle.steering_control (vehicle/controller.py:145-187) folded with the first line
+  //      of Vehicle.step (kinematics.py:141-142), StraightLane heading 0.
+  // Reference chain:  a = -KP_LAT*lat / nz(v);  heading_ref = clip(asin(clip(a)), +-pi/4)
+  //                   w = clip(L/2 / nz(v) * KP_H*wrap(heading_ref - h));  slip = asin(w)
+  //                   steering = clip(atan(2 tan slip), +-pi/3);  beta = atan(1/2 tan steering)
+  // Since tan(asin w) = w/sqrt(1-w^2), tan(atan u) = u and tan is increasing on (-pi/2, pi/2):
+  //                   tan(steering) = clip(2w/sqrt(1-w^2), +-tan(pi/3))
+  // so this returns  t = tan(beta) = 1/2 tan(steering)  without evaluating slip/steering/beta.
+  __device__ static inline double steer_tan_beta(const StepParams &p, double y, double h, double inv_v, int tgt) {
     const double lat = y - tgt * p.lane_width;
-    const double lateral_speed_command = -HWY_KP_LATERAL * lat;
-    const double heading_command = asin(clipd(lateral_speed_command / not_zero(v), -1.0, 1.0));
-    const double heading_ref = 0.0 + clipd(heading_command, -HWY_PI / 4, HWY_PI / 4);
+    const double a = clipd((-HWY_KP_LATERAL * lat) * inv_v, -1.0, 1.0);
+    // clip(asin(a), +-pi/4): asin is only evaluated when it is not going to be clipped
+    const double s45 = 0.7071067811865476;  // sin(pi/4) rounded up: |a| >= s45 => |asin a| >= pi/4 (clipped)
+    const double heading_ref = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin(a), -HWY_PI / 4, HWY_PI / 4));
     const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
-    const double slip_angle = asin(clipd(HWY_VEH_LENGTH / 2 / not_zero(v) * heading_rate_command, -1.0, 1.0));
-    const double steering_angle = atan(2 * tan(slip_angle));
-    return clipd(steering_angle, -HWY_MAX_STEER, HWY_MAX_STEER);
+    const double w = clipd((HWY_VEH_LENGTH / 2 * inv_v) * heading_rate_command, -1.0, 1.0);
+    const double tan_max = 1.7320508075688767;  // tan(MAX_STEERING_ANGLE = fl(pi/3)) in f64
+    const double tan_steer = clipd(2 * w / sqrt(1 - w * w), -tan_max, tan_max);  // w = +-1 -> +-inf -> clipped
+    return 0.5 * tan_steer;
   }
 
   // ---- AbstractLane.is_reachable_from (road/lane.py:104-118) -------------------------------------
@@ -292,7 +306,7 @@ struct EnvBlock {
   // ---- rectangle SAT with swept extension (utils.py:196-241, objects.py:122-138,169-181) -----------
   // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
   // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
-  __device__ static int pair_collide(const Shared &sh, int a, int b, double dt, double *tx, double *ty) {
+  __device__ static __attribute__((noinline)) int pair_collide(const Shared &sh, int a, int b, double dt, double *tx, double *ty) {
     const double ax = sh.x[a], ay = sh.y[a], bx = sh.x[b], by = sh.y[b];
     const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
     const double dx = bx - ax, dy = by - ay;
@@ -549,8 +563,7 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
     o.impx = p.st.impact_x[k]; o.impy = p.st.impact_y[k];
     const int w = p.st.packed[k];
     o.lane = w & 0xff; o.tgt = (w >> 8) & 0xff; o.sidx = (w >> 16) & 0xff; o.flags = (w >> 24) & 0xff;
-    o.ch = cos(o.h);
-    o.sh = sin(o.h);
+    sincos(o.h, &o.sh, &o.ch);
   }
 }
 template <int NW>
@@ -611,8 +624,9 @@ __global__ void __launch_bounds__(NW * 64) hwy_observe_kernel(const StepParams p
 
 // =============================================================================================
 // The fused policy-step kernel.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
+// WPE = minimum waves per SIMD the register allocator must leave room for (occupancy knob).
+template <int NW, int WPE>
+__global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams p) {
   typedef EnvBlock<NW> B;
   __shared__ typename B::Shared sh;
   const int e = blockIdx.x, i = threadIdx.x;
@@ -687,13 +701,19 @@ __global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
     __syncthreads();
 
     // ---- C. rank along the road + lane membership masks ---------------------------------------------
-    int rank = 0;
-    bool tie = false;
+    // rank = #{j : x_j < x_i} when all x are distinct; a tie (count_le - count_lt > 1, self included)
+    // is resolved by list order, exactly like a stable sort (rare: workgroup-uniform slow path)
+    int cnt_lt = 0, cnt_le = 0;
+#pragma unroll 4
     for (int j = 0; j < N; ++j) {
       const double xj = sh.x[j];
-      rank += (xj < me.x) || (xj == me.x && j < i);
-      tie |= (xj == me.x && j != i);
+      cnt_lt += (xj < me.x) ? 1 : 0;
+      cnt_le += (xj <= me.x) ? 1 : 0;
     }
+    const bool tie = (cnt_le - cnt_lt) > 1;
+    int rank = cnt_lt;
+    if (tie)
+      for (int j = 0; j < i; ++j) rank += (sh.x[j] == me.x) ? 1 : 0;
     if (active) sh.perm[rank] = i;
     u64 tm[NW];
     B::block_ballot(sh, active && tie, sh.bal1, tm);
@@ -739,15 +759,17 @@ __global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
         int nprec, nfoll;
         if (!has_tie) B::neighbours_ranked(sh, cand, rank, &nprec, &nfoll);
         else B::neighbours_scan(p, sh, cand, i, me.x, &nprec, &nfoll);
+        // mobil() is a pure predicate: safety (new follower's braking) AND incentive (my gain) -- evaluated
+        // incentive first because it needs no pow() and rejects ~98% of the candidates
+        const double self_pred_a = free_self - (nprec >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[nprec], sh.v[nprec],
+                                                                        sh.c[nprec], sh.s[nprec]) : 0.0);
+        const double jerk = self_pred_a - self_a;
+        if (jerk < HWY_LC_MIN_ACC_GAIN) continue;
         if (nfoll >= 0) {
           const double nf_pred_a = B::idm_free(p, sh.v[nfoll], sh.ts[nfoll], me.delta) -
                                    B::idm_gap(sh.x[nfoll], sh.v[nfoll], sh.c[nfoll], sh.s[nfoll], me.x, me.v, me.ch, me.sh);
           if (nf_pred_a < -HWY_LC_MAX_BRAKING) continue;
         }
-        const double self_pred_a = free_self - (nprec >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[nprec], sh.v[nprec],
-                                                                        sh.c[nprec], sh.s[nprec]) : 0.0);
-        const double jerk = self_pred_a - self_a;
-        if (jerk < HWY_LC_MIN_ACC_GAIN) continue;
         me.tgt = cand;
       }
     }
@@ -778,12 +800,15 @@ __global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
     }
 
     // ---- E. Road.act: low-level control (controller.py:89-133, behavior.py:104-137) ---------------------
-    double steering = 0.0, accel = 0.0;
+    // tb = tan(beta) = 1/2 tan(steering) (see steer_tan_beta); acceleration command
+    double tb = 0.0, accel = 0.0;
+    if (controlled || drives) {
+      const double inv_v = 1.0 / not_zero(me.v);
+      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
+    }
     if (controlled) {
-      steering = clipd(B::steering_control(p, me.y, me.h, me.v, me.tgt), -HWY_MAX_STEER, HWY_MAX_STEER);
-      accel = HWY_KP_A * (me.ts - me.v);
+      accel = HWY_KP_A * (me.ts - me.v);  // speed_control (controller.py:189-198), not clipped
     } else if (drives) {
-      steering = clipd(B::steering_control(p, me.y, me.h, me.v, me.tgt), -HWY_MAX_STEER, HWY_MAX_STEER);
       accel = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own], sh.c[f_own],
                                                    sh.s[f_own]) : 0.0);
       if (me.lane != me.tgt) {
@@ -800,14 +825,16 @@ __global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
     // ---- F. Road.step: integrate (behavior.py:139-148, kinematics.py:130-177) --------------------------
     if (active) {
       if (idm) me.timer += p.dt;
-      if (crashed0) {  // clip_actions
-        steering = 0.0;
+      if (crashed0) {  // clip_actions: steering = 0 => tan(beta) = 0
+        tb = 0.0;
         accel = -1.0 * me.v;
       }
       if (me.v > HWY_MAX_SPEED) accel = fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v));
       else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
-      const double beta = atan(1.0 / 2 * tan(steering));
-      const double vx = me.v * cos(me.h + beta), vy = me.v * sin(me.h + beta);
+      // beta = atan(tb):  cos(beta) = 1/sqrt(1+tb^2), sin(beta) = tb*cos(beta);
+      // cos(h+beta), sin(h+beta) by angle addition against the cached cos(h), sin(h)
+      const double cb = 1.0 / sqrt(1.0 + tb * tb), sb = tb * cb;
+      const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
       me.x += vx * p.dt;
       me.y += vy * p.dt;
       if (me.flags & HWY_F_HAS_IMPACT) {
@@ -816,11 +843,10 @@ __global__ void __launch_bounds__(NW * 64) hwy_step_kernel(const StepParams p) {
         me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
         me.impx = me.impy = 0.0;
       }
-      me.h += me.v * sin(beta) / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.h += me.v * sb / (HWY_VEH_LENGTH / 2) * p.dt;
       me.v += accel * p.dt;
       me.lane = B::closest_lane(p, me.x, me.y, me.h);  // on_state_update
-      me.ch = cos(me.h);
-      me.sh = sin(me.h);
+      sincos(me.h, &me.sh, &me.ch);
     }
 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -25,6 +26,7 @@ struct hwy_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int pitch = 0;
+  int waves_per_eu = 4;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -143,6 +145,10 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->cfg = *cfg;
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
+  if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
+    const int v = std::atoi(w);
+    if (v >= 1 && v <= 4) eng->waves_per_eu = v;
+  }
   auto bail = [&](hipError_t e, const char *what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
     hwy_destroy(eng);
@@ -289,7 +295,7 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
 // ---- kernel timing ----------------------------------------------------------------------------------
 static int timed_launch(hwy_engine *eng, const StepParams &p) {
   if (!eng->profiling) {
-    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream));
+    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
     return HWY_OK;
   }
   if (eng->events_used == eng->events.size()) {
@@ -300,7 +306,7 @@ static int timed_launch(hwy_engine *eng, const StepParams &p) {
   }
   auto &pr = eng->events[eng->events_used++];
   HWY_HIP(eng, hipEventRecord(pr.first, eng->stream));
-  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
   HWY_HIP(eng, hipEventRecord(pr.second, eng->stream));
   return HWY_OK;
 }

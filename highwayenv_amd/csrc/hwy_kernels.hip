@@ -20,7 +20,25 @@ static inline int waves_for(int n_vehicles) { return (n_vehicles + 63) / 64; }
   }                                                                                           \
   return hipGetLastError();
 
-hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_step_kernel) }
+template <int WPE>
+static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
+  switch (waves_for(p.N)) {
+    case 1: hipLaunchKernelGGL((hwy_step_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((hwy_step_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((hwy_step_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((hwy_step_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
+  switch (waves_per_eu) {
+    case 1: return launch_step_wpe<1>(p, num_envs, stream);
+    case 2: return launch_step_wpe<2>(p, num_envs, stream);
+    case 3: return launch_step_wpe<3>(p, num_envs, stream);
+    default: return launch_step_wpe<4>(p, num_envs, stream);
+  }
+}
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_reset_kernel) }
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_observe_kernel) }
 

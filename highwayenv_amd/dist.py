@@ -1,0 +1,97 @@
+"""Multi-GPU: environments are independent, so they shard across ranks with NO data-path
+collective while stepping.  The only exchange is one gather per batched
+step of each rank's packed (reward | info_speed | obs | terminated | truncated | info_crashed)
+block to rank 0 -- ``torch.distributed.gather`` on the ``nccl`` backend == RCCL over xGMI; every
+peer -> rank-0 transfer rides its own direct xGMI link, so the step is latency-bound, which is
+why everything is packed into ONE buffer (one collective launch per step, not six).
+
+One process per GPU (torch.distributed.run).  The same code runs on ``gloo``/CPU tensors for
+the world_size-2 tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _abi
+
+
+def shard_range(total_envs: int, world: int, rank: int) -> range:
+    """Contiguous block partition of env ids; remainders go to the lowest ranks."""
+    q, r = divmod(total_envs, world)
+    start = rank * q + min(rank, r)
+    return range(start, start + q + (1 if rank < r else 0))
+
+
+class PackedStepOutputs:
+    """Per-rank output block of ``hwy_step_device`` laid out in one contiguous byte buffer.
+
+    Layout (8-byte aligned f64 first): reward f64[E,A] | info_speed f64[E,A] | obs f32[E,A,V,F]
+    | terminated u8[E] | truncated u8[E] | info_crashed u8[E,A].
+    """
+
+    def __init__(self, cfg: _abi.HwyConfig, device, world: int = 1, rank: int = 0):
+        E, A, V, F = cfg.num_envs, cfg.num_agents, cfg.obs_vehicles, cfg.obs_features
+        self.E, self.A, self.V, self.F = E, A, V, F
+        self.world, self.rank = world, rank
+        sizes = [("reward", E * A * 8), ("info_speed", E * A * 8), ("obs", E * A * V * F * 4),
+                 ("terminated", E), ("truncated", E), ("info_crashed", E * A)]
+        self.offsets, off = {}, 0
+        for name, nbytes in sizes:
+            self.offsets[name] = (off, nbytes)
+            off += (nbytes + 7) & ~7
+        self.nbytes = off
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.gathered = ([torch.zeros(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world)]
+                         if (world > 1 and rank == 0) else None)
+
+    def _view(self, buf, name, dtype, shape):
+        off, nbytes = self.offsets[name]
+        return buf[off:off + nbytes].view(dtype).view(*shape)
+
+    def views(self, buf=None) -> dict:
+        b = self.buf if buf is None else buf
+        E, A, V, F = self.E, self.A, self.V, self.F
+        return {
+            "reward": self._view(b, "reward", torch.float64, (E, A)),
+            "info_speed": self._view(b, "info_speed", torch.float64, (E, A)),
+            "obs": self._view(b, "obs", torch.float32, (E, A, V, F)),
+            "terminated": self._view(b, "terminated", torch.uint8, (E,)),
+            "truncated": self._view(b, "truncated", torch.uint8, (E,)),
+            "info_crashed": self._view(b, "info_crashed", torch.uint8, (E, A)),
+        }
+
+    def pointers(self):
+        """(d_obs, d_reward, d_terminated, d_truncated, d_info_speed, d_info_crashed) for Engine.step_device."""
+        base = self.buf.data_ptr()
+        o = self.offsets
+        return (base + o["obs"][0], base + o["reward"][0], base + o["terminated"][0], base + o["truncated"][0],
+                base + o["info_speed"][0], base + o["info_crashed"][0])
+
+    def terminated(self):
+        return self.views()["terminated"]
+
+    def gather_to_rank0(self):
+        """One collective per batched step.  Returns, on rank 0, the dict of global arrays
+        (env-major concatenation over ranks); None elsewhere."""
+        if self.world == 1:
+            return self.views()
+        dist.gather(self.buf, self.gathered if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        per_rank = [self.views(b) for b in self.gathered]
+        return {k: torch.cat([v[k] for v in per_rank], dim=0) for k in per_rank[0]}
+
+
+def scatter_actions(actions_global, world: int, rank: int, envs_per_rank: int, device):
+    """Rank 0 holds int32 [world*E, A] actions; every rank receives its [E, A] block."""
+    if world == 1:
+        return actions_global
+    A = actions_global.shape[-1] if rank == 0 else None
+    shape = torch.tensor([A or 0], device=device)
+    dist.broadcast(shape, src=0)
+    out = torch.empty((envs_per_rank, int(shape.item())), dtype=torch.int32, device=device)
+    chunks = list(actions_global.contiguous().chunk(world, dim=0)) if rank == 0 else None
+    dist.scatter(out, chunks, src=0)
+    return out

@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's environment API for the accelerated path.
+
+``BatchedHighwayEnv`` keeps the shape of ``AbstractEnv`` (highway_env/envs/common/abstract.py):
+``default_config()`` / ``configure()`` / ``reset(seed=, options=)`` / ``step(action)`` / ``close()``,
+same config dict keys as ``HighwayEnv.default_config`` (envs/highway_env.py:25-53) and the same
+exceptions for what the reference rejects -- but steps E environments per call, and the body of
+``_simulate`` + ``observe`` + ``_reward`` + ``_is_terminated`` + ``_is_truncated``
+(abstract.py:259-317) is ONE C-ABI call into the HIP engine.
+
+``HighwayEnv`` / ``HighwayEnvFast`` are the E == 1 drop-ins with the reference's unbatched return
+types (obs ``(5,5) float32``, ``float`` reward, ``bool`` flags, ``info`` dict with
+``speed/crashed/action/rewards``).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from . import _abi, spawn
+from .engine import Engine
+
+try:  # optional: only to expose real spaces when gymnasium is installed
+    import gymnasium as _gym
+except Exception:  # pragma: no cover - gymnasium is absent in the build image
+    _gym = None
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n, self.shape, self.dtype = n, (), np.int64
+
+    def contains(self, x):
+        return 0 <= int(x) < self.n
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+
+class _Box:
+    def __init__(self, shape, dtype=np.float32):
+        self.shape, self.dtype, self.low, self.high = tuple(shape), np.dtype(dtype), -np.inf, np.inf
+
+    def contains(self, x):
+        return tuple(np.shape(x)) == self.shape
+
+
+class VehicleView:
+    """Read-only view of one vehicle of one env (reference: Vehicle / ControlledVehicle attributes)."""
+
+    def __init__(self, st, e, i):
+        self.position = np.array([st["x"][e, i], st["y"][e, i]])
+        self.heading = float(st["heading"][e, i])
+        self.speed = float(st["speed"][e, i])
+        self.lane_index = ("0", "1", int(st["lane"][e, i]))
+        self.target_lane_index = ("0", "1", int(st["target_lane"][e, i]))
+        self.target_speed = float(st["target_speed"][e, i])
+        f = int(st["flags"][e, i])
+        self.crashed = bool(f & _abi.F_CRASHED)
+        self.check_collisions = bool(f & _abi.F_CHECK_COLLISIONS)
+        self.controlled = bool(f & _abi.F_CONTROLLED)
+        self.speed_index = int(st["speed_index"][e, i]) if self.controlled else None
+        self.timer = None if self.controlled else float(st["timer"][e, i])
+        self.DELTA = None if self.controlled else float(st["delta"][e, i])
+
+    @property
+    def velocity(self):
+        return self.speed * np.array([np.cos(self.heading), np.sin(self.heading)])
+
+
+class RoadView:
+    def __init__(self, st, e):
+        self.vehicles = [VehicleView(st, e, i) for i in range(st["x"].shape[1])]
+        self.objects = []
+
+
+class BatchedHighwayEnv:
+    """E parallel ``highway-v0``-family environments on one MI355X."""
+
+    #: ``HighwayEnvFast`` semantics (ego-only collision checks, highway_env.py:177-182)
+    FAST = False
+    PERCEPTION_DISTANCE = 5.0 * 40.0
+    #: the HIP engine; tests substitute the CPU emulation of the same kernel source
+    _engine_factory = staticmethod(lambda cfg, device, stream: Engine(cfg, device=device, stream=stream))
+
+    def __init__(self, config: dict | None = None, num_envs: int = 1, device: int = 0, render_mode=None,
+                 spawn_mode: str = "reference", autoreset: bool = False, stream: int | None = None):
+        if render_mode is not None:
+            raise NotImplementedError("rendering is outside the MI355X hot-path scope")
+        if spawn_mode not in ("reference", "device"):
+            raise ValueError("spawn_mode must be 'reference' (numpy PCG64 stream) or 'device' (Philox)")
+        self.num_envs = int(num_envs)
+        self.device = device
+        self.spawn_mode = spawn_mode
+        self.autoreset = bool(autoreset)
+        self._stream = stream
+        self.config = self.default_config()
+        self.configure(config)
+        self._engine = None
+        self._engine_key = None
+        self.np_random = [None] * self.num_envs  # per-env Generator == reference env.np_random
+        self.time = np.zeros(self.num_envs)
+        self.steps = 0
+        self._define_spaces()
+
+    # ---- config (abstract.py:101-144) ------------------------------------------------------
+    @classmethod
+    def default_config(cls) -> dict:
+        return _abi.highway_fast_default_config() if cls.FAST else _abi.highway_default_config()
+
+    def configure(self, config: dict | None) -> None:
+        if config:
+            self.config.update(config)
+
+    def _define_spaces(self):
+        hc = _abi.make_config(self.config, self.num_envs, fast=self.FAST)
+        self._hcfg = hc
+        A, V, F = hc.num_agents, hc.obs_vehicles, hc.obs_features
+        self.single_observation_shape = (V, F) if A == 1 else (A, V, F)
+        if _gym is not None:
+            self.single_action_space = _gym.spaces.Discrete(5)
+            self.single_observation_space = _gym.spaces.Box(-np.inf, np.inf, self.single_observation_shape, np.float32)
+        else:
+            self.single_action_space = _Discrete(5)
+            self.single_observation_space = _Box(self.single_observation_shape)
+        self.action_space, self.observation_space = self.single_action_space, self.single_observation_space
+
+    def _ensure_engine(self):
+        key = bytes(self._hcfg)
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._engine_factory(self._hcfg, self.device, self._stream)  # raises without a GPU
+            self._engine_key = key
+        return self._engine
+
+    # ---- reset (abstract.py:219-249) -----------------------------------------------------------
+    def reset(self, *, seed=None, options: dict | None = None):
+        if options and "config" in options:
+            self.configure(options["config"])
+        self._define_spaces()
+        eng = self._ensure_engine()
+        E = self.num_envs
+        if seed is None:
+            seeds = [None] * E
+        elif np.ndim(seed) == 0:
+            seeds = [int(seed) + e for e in range(E)]  # gymnasium vector-env convention
+        else:
+            seeds = list(seed)
+            if len(seeds) != E:
+                raise ValueError("one seed per env expected")
+        cfg = self.config
+        lane_id = cfg["initial_lane_id"]
+        if self.spawn_mode == "reference":
+            for e, s in enumerate(seeds):
+                if s is not None or self.np_random[e] is None:
+                    # gymnasium.utils.seeding.np_random(seed): Generator(PCG64(SeedSequence(seed)))
+                    self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+            st = spawn.spawn_reference_stream(self._hcfg, self.np_random, cfg["ego_spacing"], cfg["vehicles_density"],
+                                              lane_id)
+            eng.set_state(st)
+            obs = eng.observe()
+        else:
+            sd = np.array([np.random.SeedSequence(s).generate_state(1, np.uint64)[0] if s is None else s
+                           for s in seeds], np.uint64)
+            obs = eng.reset(seeds=sd, ego_spacing=cfg["ego_spacing"], vehicles_density=cfg["vehicles_density"],
+                            initial_lane_id=-1 if lane_id is None else lane_id)
+        eng.set_autoreset(self.autoreset, base_seed=int(seeds[0] or 0) + 0x9E3779B9, ego_spacing=cfg["ego_spacing"],
+                          vehicles_density=cfg["vehicles_density"], initial_lane_id=-1 if lane_id is None else lane_id)
+        self.time[:] = 0
+        self.steps = 0
+        st = eng.get_state()
+        ego = self._hcfg.agent_index[0]
+        info = {"speed": st["speed"][:, ego].copy(), "crashed": (st["flags"][:, ego] & _abi.F_CRASHED) != 0,
+                "action": None}
+        return self._shape_obs(obs), info
+
+    # ---- step (abstract.py:259-285) ---------------------------------------------------------------
+    def step(self, action):
+        if self._engine is None:
+            # the reference raises NotImplementedError when road/vehicle are unset (abstract.py:269-272)
+            raise NotImplementedError("The road and vehicle must be initialized in the environment implementation")
+        E, A = self.num_envs, self._hcfg.num_agents
+        acts = np.asarray(action)
+        acts = acts.reshape(E, A) if acts.size == E * A else np.broadcast_to(acts, (E, A))
+        obs, reward, term, trunc, info = self._engine.step(acts.astype(np.int32))  # KeyError on bad action id
+        self.time += 1 / self.config["policy_frequency"]
+        self.steps += self._hcfg.frames_per_step
+        out_info = {"speed": info["speed"][:, 0], "crashed": info["crashed"][:, 0], "action": acts if A > 1 else acts[:, 0]}
+        if A > 1:
+            out_info["agents_rewards"] = reward
+            out_info["agents_speed"], out_info["agents_crashed"] = info["speed"], info["crashed"]
+        return self._shape_obs(obs), reward[:, 0], term, trunc, out_info
+
+    def _shape_obs(self, obs):
+        return obs[:, 0] if self._hcfg.num_agents == 1 else obs
+
+    # ---- inspection --------------------------------------------------------------------------------
+    def get_state(self) -> dict:
+        return self._engine.get_state()
+
+    def set_state(self, st: dict) -> None:
+        self._ensure_engine().set_state(st)
+
+    def road(self, env_index: int = 0) -> RoadView:
+        return RoadView(self._engine.get_state(), env_index)
+
+    def rewards(self, env_index: int = 0) -> dict:
+        """HighwayEnv._rewards (highway_env.py:122-139) of one env, from the device state."""
+        st = self._engine.get_state()
+        c, i = self._hcfg, self._hcfg.agent_index[0]
+        x, y, h, v = (st[k][env_index, i] for k in ("x", "y", "heading", "speed"))
+        lane, tgt = int(st["lane"][env_index, i]), int(st["target_lane"][env_index, i])
+        fs = v * np.cos(h)
+        r0, r1 = self.config["reward_speed_range"]
+        scaled = 0 + (fs - r0) * (1 - 0) / (r1 - r0)
+        on_road = abs(y - lane * c.lane_width) <= c.lane_width / 2 and -5 <= x < c.road_length + 5
+        return {"collision_reward": float(bool(st["flags"][env_index, i] & _abi.F_CRASHED)),
+                "right_lane_reward": tgt / max(c.lanes_count - 1, 1),
+                "high_speed_reward": float(np.clip(scaled, 0, 1)),
+                "on_road_reward": float(on_road)}
+
+    def close(self) -> None:
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchedHighwayEnvFast(BatchedHighwayEnv):
+    """E parallel ``highway-fast-v0`` environments (HighwayEnvFast, highway_env.py:154-182)."""
+    FAST = True
+
+
+class _SingleEnvMixin:
+    """E == 1 with the reference's unbatched signature."""
+
+    def __init__(self, config: dict | None = None, render_mode=None, device: int = 0):
+        super().__init__(config, num_envs=1, device=device, render_mode=render_mode)
+        self.reset()  # AbstractEnv.__init__ resets (abstract.py:89)
+
+    def reset(self, *, seed=None, options=None):
+        obs, info = super().reset(seed=seed, options=options)
+        return obs[0], {"speed": float(info["speed"][0]), "crashed": bool(info["crashed"][0]),
+                        "action": self.single_action_space.sample(), "rewards": self.rewards(0)}
+
+    def step(self, action):
+        obs, reward, term, trunc, info = super().step(np.asarray([action]).reshape(1, -1))
+        return (obs[0], float(reward[0]), bool(term[0]), bool(trunc[0]),
+                {"speed": float(info["speed"][0]), "crashed": bool(info["crashed"][0]), "action": action,
+                 "rewards": self.rewards(0)})
+
+    @property
+    def vehicle(self) -> VehicleView:
+        return self.road().vehicles[self._hcfg.agent_index[0]]
+
+    @property
+    def controlled_vehicles(self):
+        vs = self.road().vehicles
+        return [vs[self._hcfg.agent_index[a]] for a in range(self._hcfg.num_agents)]
+
+
+class HighwayEnv(_SingleEnvMixin, BatchedHighwayEnv):
+    """Drop-in for ``highway_env.envs.highway_env.HighwayEnv`` (``highway-v0``)."""
+
+
+class HighwayEnvFast(_SingleEnvMixin, BatchedHighwayEnvFast):
+    """Drop-in for ``highway_env.envs.highway_env.HighwayEnvFast`` (``highway-fast-v0``)."""
+
+
+def _copy_config(cfg):
+    return copy.deepcopy(cfg)

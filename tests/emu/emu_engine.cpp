@@ -5,6 +5,24 @@
 #include <cstring>
 #include <vector>
 
+#ifdef HWY_EMU_ULP_NOISE
+// Sensitivity probe: perturb every libm result by +-1 ulp (pseudo-randomly) to mimic a different
+// libm (ocml vs glibc vs numpy) and see which discrete decisions of the simulation can flip.
+namespace emu {
+inline double noisy(double v) {
+  static thread_local uint64_t s = 0x9E3779B97F4A7C15ull;
+  s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+  const unsigned r = (unsigned)(s >> 33) % 3;  // 0: keep, 1: up, 2: down
+  return r == 0 ? v : nextafter(v, r == 1 ? INFINITY : -INFINITY);
+}
+}  // namespace emu
+#define cos(x) emu::noisy(cos(x))
+#define sin(x) emu::noisy(sin(x))
+#define tan(x) emu::noisy(tan(x))
+#define atan(x) emu::noisy(atan(x))
+#define asin(x) emu::noisy(asin(x))
+#define pow(x, y) emu::noisy(pow(x, y))
+#endif
 #include "../../highwayenv_amd/csrc/hwy_device.h"
 #include "../../highwayenv_amd/csrc/hwy_params.h"
 
@@ -40,7 +58,7 @@ void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
 #define RUN(NW)                                                                                         \
   switch (which) {                                                                                      \
-    case STEP: emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW>(q); }, E, NW * 64, p); break;     \
+    case STEP: emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW, 1>(q); }, E, NW * 64, p); break;     \
     case RESET: emu::launch([](const StepParams &q) { hwy::hwy_reset_kernel<NW>(q); }, E, NW * 64, p); break;   \
     case OBSERVE: emu::launch([](const StepParams &q) { hwy::hwy_observe_kernel<NW>(q); }, E, NW * 64, p); break; \
   }

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test (CPU) of the env sharding + packed gather used on N>1 GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from highwayenv_amd import _abi
+from highwayenv_amd.dist import PackedStepOutputs, scatter_actions, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, E, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = _abi.make_config(_abi.highway_fast_default_config(), E, fast=True)
+        out = PackedStepOutputs(cfg, "cpu", world, rank)
+        v = out.views()
+        env_ids = torch.tensor(list(shard_range(E * world, world, rank)))
+        # fake "engine outputs": every field encodes the global env id
+        v["reward"][:, 0] = env_ids.double() + 0.25
+        v["info_speed"][:, 0] = env_ids.double() * 2
+        v["obs"][:] = env_ids.float().view(-1, 1, 1, 1)
+        v["terminated"][:] = (env_ids % 2).to(torch.uint8)
+        v["truncated"][:] = (env_ids % 3 == 0).to(torch.uint8)
+        v["info_crashed"][:, 0] = (env_ids % 5 == 0).to(torch.uint8)
+        got = out.gather_to_rank0()
+        acts_global = (torch.arange(E * world, dtype=torch.int32).view(-1, 1) % 5) if rank == 0 else None
+        mine = scatter_actions(acts_global, world, rank, E, "cpu")
+        ok = bool((mine[:, 0] == (env_ids % 5).int()).all())
+        if rank == 0:
+            ids = torch.arange(E * world)
+            ok &= bool((got["reward"][:, 0] == ids.double() + 0.25).all())
+            ok &= bool((got["info_speed"][:, 0] == ids.double() * 2).all())
+            ok &= bool((got["obs"][:, 0, 2, 3] == ids.float()).all())
+            ok &= bool((got["terminated"] == (ids % 2).to(torch.uint8)).all())
+            ok &= bool((got["truncated"] == (ids % 3 == 0).to(torch.uint8)).all())
+            ok &= bool((got["info_crashed"][:, 0] == (ids % 5 == 0).to(torch.uint8)).all())
+            ok &= got["obs"].shape == (E * world, 1, 5, 5)
+        else:
+            ok &= got is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_everything():
+    for total, world in [(4096, 8), (10, 3), (7, 8)]:
+        ids = [i for r in range(world) for i in shard_range(total, world, r)]
+        assert ids == list(range(total))
+
+
+def test_packed_gather_world2_gloo():
+    world, E = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, E, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_packed_layout_is_aligned():
+    cfg = _abi.make_config(_abi.highway_fast_default_config(), 5, fast=True)
+    out = PackedStepOutputs(cfg, "cpu")
+    for name, (off, _) in out.offsets.items():
+        assert off % 8 == 0, name
+    assert len(out.pointers()) == 6

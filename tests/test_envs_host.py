@@ -1,0 +1,97 @@
+"""Host-side API mirror (highwayenv_amd/envs.py): config semantics, error behaviour, unbatched
+drop-in signatures.  CPU: the engine is replaced by the CPU emulation of the same kernel source
+(test infrastructure); `-m gpu` runs the same API on the real engine."""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi, envs
+from highwayenv_amd.engine import EngineError
+from tests.golden_util import Golden
+
+
+def _emu_factory(cfg, device, stream):
+    from tests.emu.emu import EmuEngine
+    return EmuEngine(cfg)
+
+
+class EmuFast(envs.BatchedHighwayEnvFast):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+class EmuSingleFast(envs._SingleEnvMixin, EmuFast):
+    pass
+
+
+def test_default_configs_match_reference_dicts():
+    g = Golden("cfg1_fast_default")
+    ref = g.config
+    mine = envs.BatchedHighwayEnvFast.default_config()
+    for k in ["lanes_count", "vehicles_count", "simulation_frequency", "policy_frequency", "duration", "ego_spacing",
+              "vehicles_density", "collision_reward", "right_lane_reward", "high_speed_reward", "normalize_reward",
+              "offroad_terminal", "reward_speed_range"]:
+        assert mine[k] == ref[k], k
+    v0 = envs.BatchedHighwayEnv.default_config()
+    assert (v0["simulation_frequency"], v0["lanes_count"], v0["vehicles_count"], v0["duration"]) == (15, 4, 50, 40)
+
+
+def test_unknown_types_raise_like_reference():
+    with pytest.raises(ValueError, match="Unknown action type"):
+        envs.BatchedHighwayEnv({"action": {"type": "Nope"}})
+    with pytest.raises(ValueError, match="Unknown observation type"):
+        envs.BatchedHighwayEnv({"observation": {"type": "Nope"}})
+    with pytest.raises(NotImplementedError):
+        envs.BatchedHighwayEnv({"observation": {"type": "OccupancyGrid"}})
+    with pytest.raises(NotImplementedError):
+        envs.BatchedHighwayEnv({"action": {"type": "ContinuousAction"}})
+    with pytest.raises(NotImplementedError):
+        envs.BatchedHighwayEnv(render_mode="human")
+
+
+def test_step_before_reset_raises_notimplemented():
+    env = envs.BatchedHighwayEnvFast(num_envs=2)
+    with pytest.raises(NotImplementedError):
+        env.step([1, 1])
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import highwayenv_amd._lib as L
+    if L.load().hwy_device_count() > 0:
+        pytest.skip("a GPU is present")
+    env = envs.BatchedHighwayEnvFast(num_envs=2)
+    with pytest.raises(EngineError, match="no CPU fallback"):
+        env.reset(seed=0)
+
+
+def test_single_env_dropin_matches_reference_episode():
+    """HighwayEnvFast(): reset(seed=0), golden actions -> the reference's obs/reward/flags."""
+    g = Golden("cfg1_fast_default")
+    env = EmuSingleFast()
+    obs, info = env.reset(seed=int(g.seeds[0]))
+    assert obs.shape == (5, 5) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, g.z["obs0"][0], atol=1e-6)
+    for t in range(6):
+        obs, r, te, tr, info = env.step(int(g.actions[t, 0]))
+        assert isinstance(r, float) and isinstance(te, bool) and isinstance(tr, bool)
+        np.testing.assert_allclose(obs, g.z["obs"][t, 0], atol=1e-6)
+        assert abs(r - g.z["reward"][t, 0]) < 1e-9
+        assert te == bool(g.z["terminated"][t, 0]) and tr == bool(g.z["truncated"][t, 0])
+        assert abs(info["speed"] - g.z["info_speed"][t, 0]) < 1e-9
+        assert set(info["rewards"]) == {"collision_reward", "right_lane_reward", "high_speed_reward", "on_road_reward"}
+    assert env.vehicle.lane_index[:2] == ("0", "1")
+    assert len(env.road().vehicles) == 21
+    with pytest.raises(KeyError):
+        env.step(9)
+
+
+def test_batched_reset_seed_convention_and_options_config():
+    env = EmuFast(num_envs=3)
+    obs, info = env.reset(seed=0, options={"config": {"lanes_count": 4, "vehicles_count": 50}})
+    assert obs.shape == (3, 5, 5)
+    g = Golden("cfg2_fast_n50_l4")  # seeds 0..3 of the same config
+    np.testing.assert_allclose(obs, g.z["obs0"][:3], atol=1e-6)
+    o, r, te, tr, info = env.step(g.actions[0, :3])
+    np.testing.assert_allclose(o, g.z["obs"][0, :3], atol=1e-6)
+    np.testing.assert_allclose(r, g.z["reward"][0, :3], atol=1e-9)
+    # reset() without a seed continues each env's np_random stream like the reference does
+    obs2, _ = env.reset()
+    assert not np.allclose(obs2, obs)
