@@ -30,11 +30,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("HWY_ENGINE_LIB", LIB_PATH)  # developer knob: alternative build of the same library
+    if not os.path.exists(path):
         raise EngineLibraryMissing(
-            f"{LIB_PATH} not found. Build it with `python -m highwayenv_amd.build` (needs hipcc, "
+            f"{path} not found. Build it with `python -m highwayenv_amd.build` (needs hipcc, "
             "cross-compiles for gfx950). The MI355X engine has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, u8p, f64 = C.c_void_p, C.c_int32, C.POINTER(C.c_uint8), C.c_double
     lib.hwy_abi_version.restype = C.c_int
     lib.hwy_config_size.restype = C.c_size_t

@@ -26,7 +26,8 @@ struct hwy_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int pitch = 0;
-  int waves_per_eu = 4;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
+  bool force_block_kernel = false;  // HWY_STEP_KERNEL=block: use the generic workgroup kernel even for N <= 64
+  int waves_per_eu = 2;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -145,6 +146,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->cfg = *cfg;
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
+  if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
   if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
     const int v = std::atoi(w);
     if (v >= 1 && v <= 4) eng->waves_per_eu = v;
@@ -295,7 +297,7 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
 // ---- kernel timing ----------------------------------------------------------------------------------
 static int timed_launch(hwy_engine *eng, const StepParams &p) {
   if (!eng->profiling) {
-    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
+    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel));
     return HWY_OK;
   }
   if (eng->events_used == eng->events.size()) {
@@ -306,7 +308,7 @@ static int timed_launch(hwy_engine *eng, const StepParams &p) {
   }
   auto &pr = eng->events[eng->events_used++];
   HWY_HIP(eng, hipEventRecord(pr.first, eng->stream));
-  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
+  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel));
   HWY_HIP(eng, hipEventRecord(pr.second, eng->stream));
   return HWY_OK;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hwy_device.h"
+#include "hwy_wave.h"
 #include "hwy_launch.h"
 
 namespace hwy {
@@ -31,7 +32,21 @@ static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t
   }
   return hipGetLastError();
 }
-hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
+template <int WPE>
+static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_step_wave_kernel<WPE>), dim3(num_envs), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+// N <= 64: one wavefront per environment (hwy_wave.h); otherwise ceil(N/64) wavefronts per workgroup.
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel) {
+  if (p.N <= 64 && !force_block_kernel) {
+    switch (waves_per_eu) {
+      case 1: return launch_wave_wpe<1>(p, num_envs, stream);
+      case 2: return launch_wave_wpe<2>(p, num_envs, stream);
+      case 3: return launch_wave_wpe<3>(p, num_envs, stream);
+      default: return launch_wave_wpe<4>(p, num_envs, stream);
+    }
+  }
   switch (waves_per_eu) {
     case 1: return launch_step_wpe<1>(p, num_envs, stream);
     case 2: return launch_step_wpe<2>(p, num_envs, stream);

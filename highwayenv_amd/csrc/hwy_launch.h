@@ -5,7 +5,7 @@
 #include "hwy_device.h"
 
 namespace hwy {
-hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu);
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel);
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream);
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream);
 }  // namespace hwy

@@ -1,0 +1,469 @@
+// hwy_wave.h -- the fused policy-step kernel specialised for N <= 64 vehicles: ONE 64-wide
+// wavefront per environment (the headline highway-fast-v0 4096 x 51 case).
+//
+// Same semantics as the generic workgroup kernel in hwy_device.h (which remains the path for
+// N > 64), but built around what a single CDNA4 wavefront can do without touching LDS memory:
+//
+//   * cross-vehicle reads with a wave-uniform source index (rank counting, the lane-change abort
+//     chain, ego-vs-all collision checks, observation keys) use v_readlane -- the value lands in
+//     SGPRs and feeds the f64 compare directly, no LDS round trip and no barrier;
+//   * the sort by longitudinal position is a readlane counting pass; each vehicle then SENDS its
+//     lane-membership bits to the lane whose id equals its rank (ds_permute_b32: LDS crossbar, no
+//     LDS memory), and one v_cmp/ballot per road lane yields the rank-space membership mask, which
+//     every thread keeps in registers for its own / left / right / target lane;
+//   * the only LDS-resident data is the frame snapshot stored IN RANK ORDER, so a neighbour found
+//     by bit-scan (rank) is fetched with one gather, not rank -> index -> data;
+//   * the two MOBIL candidates are evaluated side by side (independent chains) instead of one
+//     after the other, and the expensive follower-safety test runs only for candidates that pass
+//     the (pow-free) incentive test.
+#pragma once
+
+#include "hwy_device.h"
+
+namespace hwy {
+
+// ---- wave-level data movement ------------------------------------------------------------------
+// value of lane `src` (wave-uniform index) -> every lane, via v_readlane_b32 (SGPR result)
+__device__ inline int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ inline double wave_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// my value -> lane `dst` (per-lane destination, a permutation), via ds_permute_b32
+__device__ inline int wave_send_i(int v, int dst) { return __builtin_amdgcn_ds_permute(dst << 2, v); }
+
+struct WaveShared {
+  // frame snapshot in RANK order (slot r == r-th vehicle along the road)
+  double x[64], v[64], c[64], s[64], ts[64];
+  int idx[64];
+  EnvBlock<1>::Shared blk;  // scratch for the (rare) spawn path and shared helpers
+};
+
+// front / rear ranks on a lane from its rank-space membership mask; -1 if none
+__device__ inline void mask_neighbours(u64 m, int r, int *front, int *rear) {
+  const u64 above = m & ~(((u64)2 << r) - 1);  // ranks > r  (2<<63 wraps to 0 => everything cleared)
+  const u64 below = m & (((u64)1 << r) - 1);   // ranks < r
+  *front = above ? ctz64(above) : -1;
+  *rear = below ? msb64(below) : -1;
+}
+
+// Road.neighbour_vehicles literal scan for the equal-x case, reading bodies from registers
+__device__ inline void wave_neighbours_scan(const StepParams &p, double myx, double x, double y, int self, int Lq,
+                                            int *front, int *rear) {
+  int f = -1, b = -1;
+  double s_front = 0, s_rear = 0;
+  for (int j = 0; j < p.N; ++j) {  // wave-uniform j
+    const double s_v = wave_bcast(x, j), lat_v = wave_bcast(y, j) - Lq * p.lane_width;
+    if (j == self) continue;
+    if (!(fabs(lat_v) <= p.lane_width / 2 + 1.0 && -5.0 <= s_v && s_v < p.road_length + 5.0)) continue;
+    if (myx <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
+    if (s_v < myx && (b < 0 || s_v > s_rear)) { s_rear = s_v; b = j; }
+  }
+  *front = f;
+  *rear = b;
+}
+
+// KinematicObservation + reward + done for every agent, all cross-lane reads through readlane.
+__device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, bool write_reward) {
+  typedef EnvBlock<1> B;
+  const int i = threadIdx.x;
+  const bool active = i < p.N;
+  const int V = p.V, F = p.F;
+  for (int a = 0; a < p.A; ++a) {
+    const int ia = p.agent_index[a];
+    const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
+    const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
+    const double dxe = me.x - ex, dye = me.y - ey;
+    const double d_lane = me.x - ex;
+    const bool elig = active && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
+                      ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
+    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    const int n_elig = __popcll(__ballot(elig));
+    const int m = n_elig < V - 1 ? n_elig : V - 1;
+    // stable sort position among the eligible (ties keep list order)
+    int pos = 0;
+    for (int k = 0; k < p.N; ++k) {
+      const double kk = wave_bcast(key, k);
+      pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+    }
+    if (p.obs) {
+      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
+      if (active && row >= 0) {
+        for (int f = 0; f < F; ++f) {
+          const int fid = p.feat[f];
+          double val = B::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
+          const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+          if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
+            const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+            val -= origin;
+          }
+          if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
+            const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+            const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+            if (r0 > -__builtin_inf()) {
+              val = lmap(val, r0, r1, -1.0, 1.0);
+              if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
+            }
+          }
+          out[row * F + f] = (float)val;
+        }
+      }
+      for (int t = i; t < V * F; t += 64)
+        if (t / F > m) out[t] = 0.0f;
+    }
+    if (write_reward && i == ia) {
+      const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
+      const bool on_road = fabs(me.y - me.lane * p.lane_width) <= p.lane_width / 2 + 0.0 && -5.0 <= me.x &&
+                           me.x < p.road_length + 5.0;
+      const double forward_speed = me.v * me.ch;
+      const double scaled_speed = lmap(forward_speed, p.rs0, p.rs1, 0.0, 1.0);
+      const int nl = p.L - 1 > 1 ? p.L - 1 : 1;
+      double reward = 0.0;
+      reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
+      reward = reward + p.right_lane_reward * ((double)me.tgt / (double)nl);
+      reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
+      reward = reward + 0.0 * (on_road ? 1.0 : 0.0);
+      if (p.flags & HWY_C_NORMALIZE_REWARD)
+        reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
+      reward *= (on_road ? 1.0 : 0.0);
+      p.reward[(size_t)e * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      if (a == 0) {
+        const bool term = crashed || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
+        const double t = p.st.time[e] + p.policy_dt;
+        const bool trunc = t >= p.duration;
+        p.st.time[e] = t;
+        p.terminated[e] = term ? 1 : 0;
+        p.truncated[e] = trunc ? 1 : 0;
+        if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams p) {
+  typedef EnvBlock<1> B;
+  __shared__ WaveShared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  const int N = p.N;
+  const bool active = i < N;
+
+  // ---- auto-reset: re-spawn instead of stepping (rare; shares the generic helpers) -------------
+  if (p.autoreset && p.st.done[e]) {
+    Veh me = Veh{};
+    const uint32_t episode = p.st.episode[e] + 1u;
+    spawn_env<1>(p, sh.blk, e, p.rp.base_seed + (uint64_t)e, episode, me);
+    observe_wave(p, e, me, false);
+    store_vehicle<1>(p, e, me);
+    if (active && (me.flags & HWY_F_CONTROLLED)) {
+      for (int a = 0; a < p.A; ++a)
+        if (p.agent_index[a] == i) {
+          p.reward[(size_t)e * p.A + a] = 0.0;
+          if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
+          if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = 0;
+        }
+    }
+    if (i == 0) {
+      p.st.time[e] = 0.0;
+      p.st.done[e] = 0;
+      p.st.episode[e] = episode;
+      p.terminated[e] = 0;
+      p.truncated[e] = 0;
+    }
+    return;
+  }
+
+  Veh me;
+  load_vehicle<1>(p, e, me);
+  const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
+  const bool idm = active && !controlled;
+  int agent = 0;
+  if (controlled)
+    for (int a = 0; a < p.A; ++a)
+      if (p.agent_index[a] == i) agent = a;
+  const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;
+  const u64 chk = __ballot(active && i_check);
+  const bool all_check = __popcll(chk) == N;
+
+  for (int fr = 0; fr < p.n_frames; ++fr) {
+    // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315) ------------------------------
+    if (fr == 0 && p.actions && controlled) {
+      const int act = p.actions[(size_t)e * p.A + agent];
+      if (act == HWY_FASTER || act == HWY_SLOWER) {
+        const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+        int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
+        idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
+        me.sidx = idx;
+        me.ts = p.target_speeds[idx];
+      } else if (act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) {
+        int id = me.tgt + (act == HWY_LANE_RIGHT ? 1 : -1);
+        id = id < 0 ? 0 : (id > p.L - 1 ? p.L - 1 : id);
+        if (B::reachable(p, id, me.x, me.y)) me.tgt = id;
+      }
+    }
+
+    // ---- C. rank along the road (readlane counting pass) ----------------------------------------------
+    int cnt_lt = 0, cnt_le = 0;
+    for (int j = 0; j < N; ++j) {
+      const double xj = wave_bcast(me.x, j);
+      cnt_lt += (xj < me.x) ? 1 : 0;
+      cnt_le += (xj <= me.x) ? 1 : 0;
+    }
+    const bool tie = active && (cnt_le - cnt_lt) > 1;
+    const bool has_tie = __ballot(tie) != 0;
+    int rank = active ? cnt_lt : i;  // idle lanes keep their own slot so the permutation stays a bijection
+    if (has_tie) {  // equal x: order by list index, like a stable sort (wave-uniform, rare)
+      for (int j = 0; j < N; ++j) {
+        const double xj = wave_bcast(me.x, j);
+        rank += (active && xj == me.x && j < i) ? 1 : 0;
+      }
+    }
+    // lane membership (AbstractLane.on_lane, margin 1) -> bits -> sent to lane `rank` -> ballots
+    const bool inr = active && (-5.0 <= me.x) && (me.x < p.road_length + 5.0);
+    int bits = 0;
+    for (int L = 0; L < p.L; ++L)
+      bits |= (inr && (fabs(me.y - L * p.lane_width) <= p.lane_width / 2 + 1.0)) ? (1 << L) : 0;
+    const int sorted_bits = wave_send_i(bits, rank);
+    u64 m_own = 0, m_left = 0, m_right = 0, m_tgt = 0;
+    for (int L = 0; L < p.L; ++L) {
+      const u64 b = __ballot((sorted_bits >> L) & 1);
+      m_own = (L == me.lane) ? b : m_own;
+      m_left = (L == me.lane - 1) ? b : m_left;
+      m_right = (L == me.lane + 1) ? b : m_right;
+      m_tgt = (L == me.tgt) ? b : m_tgt;
+    }
+    // frame-start snapshot, stored in rank order
+    __syncthreads();  // previous frame's gathers are complete (single wave: an s_barrier no-op + waitcnt)
+    if (active) {
+      sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.ts[rank] = me.ts;
+      sh.idx[rank] = i;
+    }
+    __syncthreads();
+
+    // ---- D. Road.act: lane-change policy (behavior.py:219-263) ----------------------------------------
+    const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
+    const bool drives = idm && !crashed0;
+    const int tgt_old = me.tgt;
+    const bool changer = drives && me.lane != me.tgt;
+    const bool decide = drives && me.lane == me.tgt && (HWY_LC_DELAY < me.timer);
+    // neighbours: ranks on own / left / right / target lane (bit scans), or the literal scan on ties
+    int fo = -1, ro = -1, fl = -1, rl = -1, frt = -1, rrt = -1, ft = -1, rt_ = -1;
+    const bool left_ok = me.lane - 1 >= 0, right_ok = me.lane + 1 < p.L;
+    if (!has_tie) {
+      mask_neighbours(m_own, rank, &fo, &ro);
+      mask_neighbours(m_left, rank, &fl, &rl);
+      mask_neighbours(m_right, rank, &frt, &rrt);
+      mask_neighbours(m_tgt, rank, &ft, &rt_);
+    } else {
+      // literal scans return vehicle INDICES; convert to ranks through the (just written) table
+      int a, b;
+      wave_neighbours_scan(p, me.x, me.x, me.y, i, me.lane, &a, &b);
+      fo = a; ro = b;
+      wave_neighbours_scan(p, me.x, me.x, me.y, i, left_ok ? me.lane - 1 : me.lane, &a, &b);
+      fl = a; rl = b;
+      wave_neighbours_scan(p, me.x, me.x, me.y, i, right_ok ? me.lane + 1 : me.lane, &a, &b);
+      frt = a; rrt = b;
+      wave_neighbours_scan(p, me.x, me.x, me.y, i, me.tgt, &a, &b);
+      ft = a; rt_ = b;
+      // index -> rank: rank_of[j] == the rank lane j computed
+      const int r_fo = fo, r_fl = fl, r_fr = frt, r_ft = ft, r_rl = rl, r_rr = rrt;
+      int rk;
+      fo = fl = frt = ft = rl = rrt = -1;
+      for (int j = 0; j < N; ++j) {
+        rk = wave_bcast_i(rank, j);
+        fo = (r_fo == j) ? rk : fo; fl = (r_fl == j) ? rk : fl; frt = (r_fr == j) ? rk : frt;
+        ft = (r_ft == j) ? rk : ft; rl = (r_rl == j) ? rk : rl; rrt = (r_rr == j) ? rk : rrt;
+      }
+    }
+    // gather the leaders' bodies (rank-ordered snapshot => one LDS trip); all issued together
+    const int g_fo = fo < 0 ? 0 : fo, g_fl = fl < 0 ? 0 : fl, g_fr = frt < 0 ? 0 : frt;
+    const double fo_x = sh.x[g_fo], fo_v = sh.v[g_fo], fo_c = sh.c[g_fo], fo_s = sh.s[g_fo];
+    const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
+    const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
+
+    double free_self = 0.0, gap_own = 0.0;
+    if (drives) {
+      free_self = B::idm_free(p, me.v, me.ts, me.delta);
+      gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
+    }
+    if (decide) {
+      me.timer = 0.0;
+      // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
+      // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
+      const double self_a = free_self - gap_own;
+      const bool moving = !(fabs(me.v) < 1);
+      const bool cl = left_ok && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
+      const bool cr = right_ok && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
+      const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
+      const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
+      bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED
+      if (ok_l && rl >= 0) {
+        const double a_f = B::idm_free(p, sh.v[rl], sh.ts[rl], me.delta) -
+                           B::idm_gap(sh.x[rl], sh.v[rl], sh.c[rl], sh.s[rl], me.x, me.v, me.ch, me.sh);
+        ok_l = !(a_f < -HWY_LC_MAX_BRAKING);
+      }
+      if (ok_r && rrt >= 0) {
+        const double a_f = B::idm_free(p, sh.v[rrt], sh.ts[rrt], me.delta) -
+                           B::idm_gap(sh.x[rrt], sh.v[rrt], sh.c[rrt], sh.s[rrt], me.x, me.v, me.ch, me.sh);
+        ok_r = !(a_f < -HWY_LC_MAX_BRAKING);
+      }
+      // side_lanes order is [left, right] and the loop does not break: right wins if both pass
+      if (ok_l) me.tgt = me.lane - 1;
+      if (ok_r) me.tgt = me.lane + 1;
+    }
+    // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
+    {
+      u64 cm = __ballot(changer);
+      while (cm) {  // wave-uniform
+        const int ci = ctz64(cm);
+        cm &= cm - 1;
+        const int Tc = wave_bcast_i(tgt_old, ci);
+        const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
+        const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
+        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+        bool blk = false;
+        if (active && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+          const double d = me.x - xc;
+          const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
+          blk = (0 < d) && (d < d_star);
+        }
+        if (__ballot(blk) != 0 && i == ci) me.tgt = me.lane;  // abort
+      }
+    }
+
+    // ---- E. Road.act: low-level control ----------------------------------------------------------------
+    double tb = 0.0, accel = 0.0;
+    if (controlled || drives) {
+      const double inv_v = 1.0 / not_zero(me.v);
+      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
+    }
+    if (controlled) {
+      accel = HWY_KP_A * (me.ts - me.v);
+    } else if (drives) {
+      accel = free_self - gap_own;
+      if (me.lane != me.tgt) {
+        // leader on the target lane.  For a vehicle that was already changing lanes m_tgt is that lane's
+        // mask; for one that decided just now the target is the left/right lane evaluated above.
+        int f2 = (me.tgt == tgt_old) ? ft : (me.tgt == me.lane - 1 ? fl : frt);
+        double a2 = free_self;
+        if (f2 >= 0) a2 = free_self - B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f2], sh.v[f2], sh.c[f2], sh.s[f2]);
+        accel = (a2 < accel) ? a2 : accel;
+      }
+      accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
+    }
+
+    // ---- F. Road.step: integrate -------------------------------------------------------------------------
+    if (active) {
+      if (idm) me.timer += p.dt;
+      if (crashed0) {
+        tb = 0.0;
+        accel = -1.0 * me.v;
+      }
+      if (me.v > HWY_MAX_SPEED) accel = fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v));
+      else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
+      const double cb = 1.0 / sqrt(1.0 + tb * tb), sb = tb * cb;
+      const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
+      me.x += vx * p.dt;
+      me.y += vy * p.dt;
+      if (me.flags & HWY_F_HAS_IMPACT) {
+        me.x += me.impx;
+        me.y += me.impy;
+        me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
+        me.impx = me.impy = 0.0;
+      }
+      me.h += me.v * sb / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.v += accel * p.dt;
+      me.lane = B::closest_lane(p, me.x, me.y, me.h);
+      sincos(me.h, &me.sh, &me.ch);
+    }
+
+    // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
+    const Body mine{me.x, me.y, me.v, me.ch, me.sh};
+    if (all_check) {
+      // full pairwise: walk the partners in index order; the highest-index partner is the last writer
+      for (int q = 0; q < N; ++q) {  // wave-uniform q
+        const double qx = wave_bcast(me.x, q), qy = wave_bcast(me.y, q), qv = wave_bcast(me.v, q);
+        bool near = false;
+        if (active && q != i) {
+          const double dx = qx - me.x, dy = qy - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(qv)) * p.dt;
+          near = dx * dx + dy * dy <= lim * lim;
+        }
+        if (__ballot(near) == 0) continue;  // nobody is close to q: skip the remaining broadcasts
+        const Body other{qx, qy, qv, wave_bcast(me.ch, q), wave_bcast(me.sh, q)};
+        if (near) {
+          const bool i_first = i < q;
+          const Body &A = i_first ? mine : other, &Bb = i_first ? other : mine;
+          if (!surely_apart(A, Bb, p.dt)) {
+            double tx, ty;
+            const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
+            if (r & 2) {
+              me.impx = i_first ? tx / 2 : -tx / 2;
+              me.impy = i_first ? ty / 2 : -ty / 2;
+              me.flags |= HWY_F_HAS_IMPACT;
+            }
+            if (r & 1) me.flags |= HWY_F_CRASHED;
+          }
+        }
+      }
+    } else {
+      // sparse checkers (highway-fast-v0: the ego only)
+      u64 cm = chk;
+      while (cm) {  // wave-uniform
+        const int c = ctz64(cm);
+        cm &= cm - 1;
+        const Body other{wave_bcast(me.x, c), wave_bcast(me.y, c), wave_bcast(me.v, c), wave_bcast(me.ch, c),
+                         wave_bcast(me.sh, c)};
+        int r = 0;
+        double tx = 0, ty = 0;
+        if (active && i != c) {
+          const double dx = other.x - me.x, dy = other.y - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
+          if (dx * dx + dy * dy <= lim * lim) {
+            const bool i_first = i < c;
+            const Body &A = i_first ? mine : other, &Bb = i_first ? other : mine;
+            if (!surely_apart(A, Bb, p.dt)) {
+              r = pair_collide(A, Bb, p.dt, &tx, &ty);
+              if (!i_check) {  // my only partners are the checkers (ascending c == loop order)
+                if (r & 2) {
+                  me.impx = i_first ? tx / 2 : -tx / 2;
+                  me.impy = i_first ? ty / 2 : -ty / 2;
+                  me.flags |= HWY_F_HAS_IMPACT;
+                }
+                if (r & 1) me.flags |= HWY_F_CRASHED;
+              }
+            }
+          }
+        }
+        const u64 wm = __ballot((r & 2) != 0), im = __ballot((r & 1) != 0);
+        if (wm | im) {  // wave-uniform: the checker gathers from its partners
+          const int q = wm ? msb64(wm) : 0;  // last partner in loop order
+          const double qx = wave_bcast(tx, q), qy = wave_bcast(ty, q);
+          if (i == c) {
+            if (im) me.flags |= HWY_F_CRASHED;
+            if (wm) {
+              me.impx = (c < q) ? qx / 2 : -qx / 2;
+              me.impy = (c < q) ? qy / 2 : -qy / 2;
+              me.flags |= HWY_F_HAS_IMPACT;
+            }
+          }
+        }
+      }
+    }
+  }  // frames
+
+  // ---- H. observe / reward / done ---------------------------------------------------------------------------
+  if (p.full_step) observe_wave(p, e, me, true);
+  store_vehicle<1>(p, e, me);
+}
+
+// Reset / observe kernels for N <= 64 reuse the generic ones (not on the per-step path).
+
+}  // namespace hwy

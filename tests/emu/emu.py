@@ -23,6 +23,7 @@ _lib = None
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, "emu_engine.cpp"), os.path.join(_HERE, "hip_emu.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_params.h"),
             os.path.join(_ROOT, "include", "hwy_engine.h")]
     stale = not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs)
@@ -111,6 +112,11 @@ class EmuEngine:
                              C.c_double(vehicles_density), C.c_int(initial_lane_id), _p(obs, C.c_float))
         assert rc == 0
         return obs
+
+
+def force_block_kernel(on: bool):
+    """Use the generic workgroup kernel even for N <= 64 (the engine's HWY_STEP_KERNEL=block)."""
+    lib().emu_force_block_kernel(C.c_int(int(on)))
 
 
 def philox_uniform2(seed, vehicle, episode, draw):

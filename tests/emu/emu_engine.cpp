@@ -24,6 +24,7 @@ inline double noisy(double v) {
 #define pow(x, y) emu::noisy(pow(x, y))
 #endif
 #include "../../highwayenv_amd/csrc/hwy_device.h"
+#include "../../highwayenv_amd/csrc/hwy_wave.h"
 #include "../../highwayenv_amd/csrc/hwy_params.h"
 
 using hwy::StepParams;
@@ -54,8 +55,13 @@ struct HostImage {
 
 
 enum Which { STEP, RESET, OBSERVE };
+bool g_force_block = false;
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
+  if (which == STEP && nw == 1 && !g_force_block) {  // same dispatch rule as hwy_kernels.hip
+    emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1>(q); }, E, 64, p);
+    return;
+  }
 #define RUN(NW)                                                                                         \
   switch (which) {                                                                                      \
     case STEP: emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW, 1>(q); }, E, NW * 64, p); break;     \
@@ -134,6 +140,8 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
   img.store(*st);
   return 0;
 }
+
+void emu_force_block_kernel(int on) { g_force_block = on != 0; }
 
 // host-side Philox, for tests of the device spawn rule
 void emu_philox_uniform2(uint64_t seed, uint32_t vehicle, uint32_t episode, uint32_t draw, double *u0, double *u1) {

@@ -1,19 +1,19 @@
 // hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A minimal CPU stand-in for the handful of HIP device
-// constructs used by highwayenv_amd/csrc/hwy_device.h, so that the *same kernel source* can be
-// executed on the CPU (one std::thread per GPU thread, std::barrier for __syncthreads, a shared
-// accumulator for wave ballots) and checked against the golden traces in the build container,
+// constructs used by highwayenv_amd/csrc/hwy_device.h and hwy_wave.h, so that the *same kernel
+// source* can be executed on the CPU and checked against the golden traces in the build container,
 // which has no GPU.  Never compiled into, linked with or loaded by the product.
 //
-// Restrictions honoured by the kernels: every __ballot / __syncthreads is executed in
-// workgroup-uniform control flow.
+// Execution model: every GPU thread of a workgroup is a FIBER (ucontext) on one OS thread,
+// scheduled round-robin; __syncthreads / ballots / readlane / ds_permute are rendezvous points.
+// Workgroups run one after the other.  Restriction honoured by the kernels: every rendezvous is
+// executed in workgroup-uniform control flow.
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <ucontext.h>
 
-#include <atomic>
-#include <barrier>
+#include <cstdlib>
 #include <functional>
-#include <thread>
 #include <vector>
 
 #define __global__
@@ -23,53 +23,137 @@
 #define __launch_bounds__(...)
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };
-inline thread_local emu_dim3 threadIdx, blockIdx, blockDim;
 
 namespace emu {
-inline std::barrier<> *g_barrier = nullptr;
-inline std::atomic<unsigned long long> g_ballot[2][16];
-inline thread_local unsigned g_ballot_phase = 0;
+struct Fiber {
+  ucontext_t ctx;
+  emu_dim3 tid, bid, bdim;
+  unsigned ballot_phase = 0;
+  unsigned xchg_phase = 0;
+  bool finished = false;
+  char *stack = nullptr;
+};
+inline Fiber *cur = nullptr;
+inline std::vector<Fiber> *fibers = nullptr;
+inline ucontext_t main_ctx;
+inline int n_fibers = 0;
+// generation barrier
+inline int bar_count = 0;
+inline unsigned bar_gen = 0;
+
+inline void yield() {
+  Fiber *me = cur;
+  const int next = (me->tid.x + 1) % n_fibers;
+  cur = &(*fibers)[next];
+  swapcontext(&me->ctx, &cur->ctx);
+}
+inline void barrier() {
+  const unsigned gen = bar_gen;
+  if (++bar_count == n_fibers) {
+    bar_count = 0;
+    ++bar_gen;
+  } else {
+    while (bar_gen == gen) yield();
+  }
+}
 }  // namespace emu
 
-inline void __syncthreads() { emu::g_barrier->arrive_and_wait(); }
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::cur->bdim)
+
+inline void __syncthreads() { emu::barrier(); }
+
+namespace emu {
+inline unsigned long long g_ballot[2][16];
+inline int g_xchg[2][1024];
+}  // namespace emu
 
 inline unsigned long long __ballot(int pred) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  auto &acc = emu::g_ballot[emu::g_ballot_phase & 1][wave];
-  emu::g_ballot_phase++;
-  if (pred) acc.fetch_or(1ull << lane);
-  emu::g_barrier->arrive_and_wait();
-  const unsigned long long v = acc.load();
-  emu::g_barrier->arrive_and_wait();
-  if (lane == 0) acc.store(0);  // reused two ballots later, with >= 1 barrier in between
+  unsigned long long &acc = emu::g_ballot[emu::cur->ballot_phase & 1][wave];
+  emu::cur->ballot_phase++;
+  if (pred) acc |= 1ull << lane;
+  emu::barrier();
+  const unsigned long long v = acc;
+  emu::barrier();
+  if (lane == 0) acc = 0;  // reused two ballots later, with >= 1 rendezvous in between
   return v;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
+// ---- wave data movement (hwy_wave.h; 64-thread workgroups, workgroup-uniform calls) --------------
 namespace emu {
-// run `kernel(params)` for grid blocks of `block` threads; blocks sequentially, threads concurrently
+// double-buffered exchange: one rendezvous per call (a fiber can be at most one call ahead)
+inline int readlane(int v, int lane) {
+  int *buf = g_xchg[cur->xchg_phase++ & 1];
+  buf[threadIdx.x] = v;
+  barrier();
+  return buf[(threadIdx.x & ~63) + (lane & 63)];
+}
+inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 (a permutation in our use)
+  int *buf = g_xchg[cur->xchg_phase++ & 1];
+  buf[(threadIdx.x & ~63) + ((addr >> 2) & 63)] = v;
+  barrier();
+  return buf[threadIdx.x];
+}
+}  // namespace emu
+#define __builtin_amdgcn_readlane(v, lane) emu::readlane((v), (lane))
+#define __builtin_amdgcn_ds_permute(addr, v) emu::ds_permute((addr), (v))
+inline int __double2loint(double d) { long long b; __builtin_memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+inline int __double2hiint(double d) { long long b; __builtin_memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) {
+  const long long b = ((long long)hi << 32) | (unsigned int)lo;
+  double d; __builtin_memcpy(&d, &b, 8); return d;
+}
+
+namespace emu {
+inline std::function<void()> g_body;
+inline int g_grid = 0;
+inline int g_done = 0;
+inline void fiber_main() {
+  for (int b = 0; b < g_grid; ++b) {
+    cur->bid.x = b;
+    g_body();
+    barrier();  // the whole workgroup finishes a block before the next one starts
+  }
+  cur->finished = true;
+  if (++g_done == n_fibers) {
+    setcontext(&main_ctx);  // last fiber: back to launch()
+  }
+  for (;;) yield();
+}
+// run `kernel(params)` for `grid` workgroups of `block` threads
 template <typename K, typename P>
 void launch(K kernel, int grid, int block, const P &params) {
-  std::barrier<> bar(block);
-  g_barrier = &bar;
+  constexpr size_t kStack = 512 * 1024;
+  std::vector<Fiber> fs(block);
+  fibers = &fs;
+  n_fibers = block;
+  bar_count = 0;
+  bar_gen = 0;
+  g_done = 0;
+  g_grid = grid;
   for (auto &row : g_ballot)
-    for (auto &a : row) a.store(0);
-  std::vector<std::thread> threads;
-  threads.reserve(block);
-  for (int t = 0; t < block; ++t)
-    threads.emplace_back([&, t] {
-      threadIdx.x = t;
-      blockDim.x = block;
-      g_ballot_phase = 0;
-      for (int b = 0; b < grid; ++b) {
-        blockIdx.x = b;
-        kernel(params);
-        bar.arrive_and_wait();
-      }
-    });
-  for (auto &th : threads) th.join();
-  g_barrier = nullptr;
+    for (auto &a : row) a = 0;
+  g_body = [&] { kernel(params); };
+  for (int t = 0; t < block; ++t) {
+    Fiber &f = fs[t];
+    f.tid.x = t;
+    f.bdim.x = block;
+    f.stack = (char *)std::malloc(kStack);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+  }
+  cur = &fs[0];
+  swapcontext(&main_ctx, &fs[0].ctx);
+  for (auto &f : fs) std::free(f.stack);
+  fibers = nullptr;
+  cur = nullptr;
 }
 }  // namespace emu

@@ -164,6 +164,27 @@ def test_multi_agent_vs_oracle(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_block_kernel_for_small_envs_matches_oracle(backend, monkeypatch):
+    """N <= 64 normally runs the one-wavefront-per-env kernel (hwy_wave.h); the generic workgroup
+    kernel (hwy_device.h, the N > 64 path) must give the same answers on the same inputs."""
+    if backend == "emu":
+        from tests.emu import emu
+        emu.force_block_kernel(True)
+    else:
+        monkeypatch.setenv("HWY_STEP_KERNEL", "block")
+    try:
+        cfg = _abi.highway_fast_default_config()
+        cfg.update({"vehicles_count": 50, "lanes_count": 4})
+        _random_rollout_vs_oracle(backend, cfg, True, 6 if backend == "emu" else 256, 6 if backend == "emu" else 30, seed=4)
+        cfg = _abi.highway_default_config()
+        cfg.update({"vehicles_count": 30, "duration": 20})
+        _random_rollout_vs_oracle(backend, cfg, False, 3 if backend == "emu" else 64, 2 if backend == "emu" else 8, seed=5)
+    finally:
+        if backend == "emu":
+            emu.force_block_kernel(False)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_equal_x_ties_take_the_literal_scan_path(backend):
     """Two vehicles at the same longitudinal coordinate: Road.neighbour_vehicles tie rules
     (front: last in list wins; rear: first wins, road/road.py:539-544) must hold exactly."""
