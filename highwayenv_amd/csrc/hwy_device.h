@@ -208,7 +208,7 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 // ---- rectangle SAT with swept extension (utils.py:196-241, objects.py:122-138,169-181) -----------
 // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
 // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
-__device__ __attribute__((noinline)) inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
+__device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const double ax = A.x, ay = A.y, bx = B.x, by = B.y;
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
   const double dx = bx - ax, dy = by - ay;

@@ -82,8 +82,10 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
     const int n_elig = __popcll(__ballot(elig));
     const int m = n_elig < V - 1 ? n_elig : V - 1;
     // stable sort position among the eligible (ties keep list order)
+    // (only eligible vehicles can precede an eligible one: walk the set bits of the ballot)
     int pos = 0;
-    for (int k = 0; k < p.N; ++k) {
+    for (u64 em = __ballot(elig); em; em &= em - 1) {  // wave-uniform
+      const int k = ctz64(em);
       const double kk = wave_bcast(key, k);
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
@@ -190,6 +192,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   const u64 chk = __ballot(active && i_check);
   const bool all_check = __popcll(chk) == N;
 
+  int rank = i;          // position along the road, carried from frame to frame
+  bool has_tie = false;  // two vehicles share the same x (=> literal neighbour scans)
   for (int fr = 0; fr < p.n_frames; ++fr) {
     // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315) ------------------------------
     if (fr == 0 && p.actions && controlled) {
@@ -207,20 +211,35 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       }
     }
 
-    // ---- C. rank along the road (readlane counting pass) ----------------------------------------------
-    int cnt_lt = 0, cnt_le = 0;
-    for (int j = 0; j < N; ++j) {
-      const double xj = wave_bcast(me.x, j);
-      cnt_lt += (xj < me.x) ? 1 : 0;
-      cnt_le += (xj <= me.x) ? 1 : 0;
+    // ---- C. rank along the road -----------------------------------------------------------------------
+    // The order along the road changes in ~1 frame out of 5 (measured), and then only by adjacent
+    // swaps, so the rank of the previous frame is kept in a register and merely VERIFIED: every vehicle
+    // sends its x to lane `rank` and to lane `rank-1` (ds_permute); lane r then holds x of rank r and
+    // of rank r+1 and checks x[r] < x[r+1].  Only if some pair is out of order (or equal) does the
+    // wave fall back to the exact counting pass.
+    bool recount = (fr == 0);
+    if (!recount) {
+      const int lo = __double2loint(me.x), hi = __double2hiint(me.x);
+      const double x_r = __hiloint2double(wave_send_i(hi, rank), wave_send_i(lo, rank));
+      const double x_r1 = __hiloint2double(wave_send_i(hi, rank - 1), wave_send_i(lo, rank - 1));
+      recount = __ballot(i < N - 1 && !(x_r < x_r1)) != 0;
+      if (!recount) has_tie = false;  // strictly increasing => all x distinct
     }
-    const bool tie = active && (cnt_le - cnt_lt) > 1;
-    const bool has_tie = __ballot(tie) != 0;
-    int rank = active ? cnt_lt : i;  // idle lanes keep their own slot so the permutation stays a bijection
-    if (has_tie) {  // equal x: order by list index, like a stable sort (wave-uniform, rare)
+    if (recount) {  // wave-uniform
+      int cnt_lt = 0, cnt_le = 0;
       for (int j = 0; j < N; ++j) {
         const double xj = wave_bcast(me.x, j);
-        rank += (active && xj == me.x && j < i) ? 1 : 0;
+        cnt_lt += (xj < me.x) ? 1 : 0;
+        cnt_le += (xj <= me.x) ? 1 : 0;
+      }
+      const bool tie = active && (cnt_le - cnt_lt) > 1;
+      has_tie = __ballot(tie) != 0;
+      rank = active ? cnt_lt : i;  // idle lanes keep their own slot so the permutation stays a bijection
+      if (has_tie) {  // equal x: order by list index, like a stable sort (rare)
+        for (int j = 0; j < N; ++j) {
+          const double xj = wave_bcast(me.x, j);
+          rank += (active && xj == me.x && j < i) ? 1 : 0;
+        }
       }
     }
     // lane membership (AbstractLane.on_lane, margin 1) -> bits -> sent to lane `rank` -> ballots

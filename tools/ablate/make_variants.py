@@ -20,6 +20,44 @@ def cut(src, start, end, repl=""):
     return src[:i] + repl + src[j:]
 
 
+def wave_variants(dev, wav):
+    """Variants of the one-wavefront kernel (hwy_wave.h).  Each value is (device_h_text, wave_h_text)."""
+    v = {"wbase": (dev, wav)}
+    v["winline"] = (dev.replace("__device__ __attribute__((noinline)) inline int pair_collide", "__device__ inline int pair_collide"), wav)
+    v["wnocollide"] = (dev, cut(wav, "    const Body mine{me.x, me.y, me.v, me.ch, me.sh};", "  }  // frames", ""))
+    v["wnorank"] = (dev, cut(wav, "    int cnt_lt = 0, cnt_le = 0;", "    const bool tie = active && (cnt_le - cnt_lt) > 1;", "    int cnt_lt = i, cnt_le = i + 1;\n"))
+    v["wnomobil"] = (dev, wav.replace("    if (decide) {\n      me.timer = 0.0;", "    if (false) {\n      me.timer = 0.0;"))
+    v["wnopow"] = (dev.replace("const double rp = r > 0.0 ? exp(delta * log(r)) : 0.0;", "const double rp = r * delta;"), wav)
+    v["wnosincos"] = (dev, wav.replace("      sincos(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))
+    v["wnosteer"] = (dev, wav.replace("      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "      tb = inv_v * 1e-9;"))
+    v["wnoobs"] = (dev, wav.replace("  if (p.full_step) observe_wave(p, e, me, true);", ""))
+    # cycle-stamped variant
+    t = wav
+    t = t.replace("  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool controlled",
+                  "  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};\n"
+                  "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
+                  "  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool controlled")
+    marks = [("    // ---- A. meta-action (abstract.py:294-304", 0),
+             ("    // ---- C. rank along the road (readlane counting pass)", 1),
+             ("    // lane membership (AbstractLane.on_lane, margin 1) -> bits", 2),
+             ("    // ---- D. Road.act: lane-change policy (behavior.py:219-263)", 3),
+             ("    double free_self = 0.0, gap_own = 0.0;", 4),
+             ("    if (decide) {\n      me.timer = 0.0;", 5),
+             ("    // abort rule for ongoing lane changes: ordered chain", 6),
+             ("    // ---- E. Road.act: low-level control", 7),
+             ("    // ---- F. Road.step: integrate", 8),
+             ("    // ---- G. Road.step: collisions", 9),
+             ("  }  // frames", 10)]
+    for text, k in marks:
+        assert text in t, text
+        t = t.replace(text, f"    TICK({k})\n" + text)
+    t = t.replace("  if (p.full_step) observe_wave(p, e, me, true);\n  store_vehicle<1>(p, e, me);\n}",
+                  "  if (p.full_step) observe_wave(p, e, me, true);\n  TICK(11)\n  store_vehicle<1>(p, e, me);\n"
+                  "  if (i == 0 && p.obs) for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}")
+    v["wticks"] = (dev, t)
+    return v
+
+
 def variants(src):
     v = {"base": src}
     v["norank"] = cut(src, "    int cnt_lt = 0, cnt_le = 0;", "    if (active) sh.perm[rank] = i;",
@@ -60,10 +98,15 @@ def variants(src):
 
 
 def build(name, text):
+    wave_text = None
+    if isinstance(text, tuple):
+        text, wave_text = text
     d = os.path.join(OUT, name)
     os.makedirs(d, exist_ok=True)
-    for f in ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h"):
+    for f in ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h"):
         shutil.copy(os.path.join(CSRC, f), d)
+    if wave_text is not None:
+        open(os.path.join(d, "hwy_wave.h"), "w").write(wave_text)
     # keep relative include of ../../include working
     os.makedirs(os.path.join(OUT, "..", "..", "include_link"), exist_ok=True)
     open(os.path.join(d, "hwy_device.h"), "w").write(text.replace('#include "../../include/hwy_engine.h"', f'#include "{ROOT}/include/hwy_engine.h"'))
@@ -80,6 +123,7 @@ def build(name, text):
 if __name__ == "__main__":
     src = open(os.path.join(CSRC, "hwy_device.h")).read()
     vs = variants(src)
+    vs.update(wave_variants(src, open(os.path.join(CSRC, "hwy_wave.h")).read()))
     only = sys.argv[1:]
     os.makedirs(OUT, exist_ok=True)
     with ThreadPoolExecutor(8) as ex:
