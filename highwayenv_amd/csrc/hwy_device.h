@@ -146,6 +146,25 @@ __device__ inline double lmap(double v, double x0, double x1, double y0, double 
   return y0 + (v - x0) * (y1 - y0) / (x1 - x0);
 }
 
+// ---- reciprocal / reciprocal square root to ~1 ulp: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26
+//      relative) + two Newton steps in FMA arithmetic.  A correctly rounded IEEE division costs ~3x
+//      as many issue cycles on gfx950; the 1-ulp difference is the same order as libm-vs-libm noise.
+__device__ inline double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+__device__ inline double fast_rsqrt(double x) {  // x > 0, finite
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  return fma(y, e, y);
+}
+
 // ---- counter-based RNG for the device-side reset: Philox-4x32-10 --------------------------
 // (Salmon et al., SC'11.)  NOT numpy's PCG64 stream: see hwy_reset in hwy_engine.h.
 __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -345,15 +364,21 @@ struct EnvBlock {
   }
 
   // ---- IDM (vehicle/behavior.py:150-217) -------------------------------------------------------
-  // free-road term COMFORT_ACC_MAX*(1-(v/v0)^delta), with the CALLER's delta (behavior.py:177-183)
-  __device__ static inline double idm_free(const StepParams &p, double v, double ts, double delta) {
+  // free-road term COMFORT_ACC_MAX*(1-(v/v0)^delta), with the CALLER's delta (behavior.py:177-183).
+  // (v/v0)^delta = exp(delta*log r): r in [0, ~2], delta in [3.5, 4.5] => |delta*log r| < 4, so the result
+  // is within ~3 ulp of a correctly rounded pow at a third of the instruction count.  log r depends on
+  // the vehicle only, delta on the caller: every vehicle publishes its own log r once per frame and a
+  // MOBIL caller evaluating its would-be follower needs one exp, not a second pow.
+  __device__ static inline double idm_log_ratio(const StepParams &p, double v, double ts) {
     const double v0 = clipd(ts, 0.0, p.speed_limit);
-    // (v/v0)^delta as exp(delta*log r): r in [0, ~2], delta in [3.5, 4.5] => |delta*log r| < 4, so the
-    // result is within ~3 ulp of a correctly rounded pow at a third of the instruction count
-    // (the relative error of exp(y) with y off by e is e: 4 * 2^-53).  r == 0 -> 0 like pow(0, delta).
-    const double r = fmax(v, 0.0) / fabs(not_zero(v0));
-    const double rp = r > 0.0 ? exp(delta * log(r)) : 0.0;
-    return HWY_COMFORT_ACC_MAX * (1 - rp);
+    const double r = fmax(v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+    return r > 0.0 ? log(r) : -__builtin_inf();  // r == 0 -> exp(-inf) = 0 == pow(0, delta)
+  }
+  __device__ static inline double idm_free_from_log(double log_ratio, double delta) {
+    return HWY_COMFORT_ACC_MAX * (1 - exp(delta * log_ratio));
+  }
+  __device__ static inline double idm_free(const StepParams &p, double v, double ts, double delta) {
+    return idm_free_from_log(idm_log_ratio(p, v, ts), delta);
   }
   // desired gap d* (behavior.py:192-217): projected speed difference, velocity = speed*(cos h, sin h)
   __device__ static inline double desired_gap(double ve, double ce, double se, double vf, double cf, double sf) {
@@ -365,7 +390,7 @@ struct EnvBlock {
   // (objects.py:183-198): on the straight lane the longitudinal coordinate is x
   __device__ static inline double idm_gap(double xe, double ve, double ce, double se, double xf, double vf,
                                           double cf, double sf) {
-    const double q = desired_gap(ve, ce, se, vf, cf, sf) / not_zero(xf - xe);
+    const double q = desired_gap(ve, ce, se, vf, cf, sf) * fast_rcp(not_zero(xf - xe));
     return HWY_COMFORT_ACC_MAX * (q * q);
   }
 
@@ -386,7 +411,9 @@ struct EnvBlock {
     const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
     const double w = clipd((HWY_VEH_LENGTH / 2 * inv_v) * heading_rate_command, -1.0, 1.0);
     const double tan_max = 1.7320508075688767;  // tan(MAX_STEERING_ANGLE = fl(pi/3)) in f64
-    const double tan_steer = clipd(2 * w / sqrt(1 - w * w), -tan_max, tan_max);  // w = +-1 -> +-inf -> clipped
+    const double w2 = 1 - w * w;
+    // |w| -> 1 sends tan(slip) to infinity: clipped to +-tan_max anyway (w2 <= 1e-12 <=> |tan| >= 1e6)
+    const double tan_steer = (w2 <= 1e-12) ? copysign(tan_max, w) : clipd((2 * w) * fast_rsqrt(w2), -tan_max, tan_max);
     return 0.5 * tan_steer;
   }
 
@@ -396,6 +423,16 @@ struct EnvBlock {
   }
   // ---- RoadNetwork.get_closest_lane_index (road/road.py:55-71, lane.py:132-143) --------------------
   __device__ static inline int closest_lane(const StepParams &p, double x, double y, double h) {
+    // All lanes share the heading and longitudinal terms, so the argmin is the lane whose centre is
+    // nearest in y: k0 = round(y / width), clamped.  Unless y sits within 1e-9 of a lane boundary (where
+    // the reference's rounded sums decide, ties -> lowest id) that is provably the argmin; otherwise run
+    // the literal loop.
+    const double k0 = rint(y / p.lane_width);
+    const double off = fabs(y - k0 * p.lane_width);
+    if (off < p.lane_width / 2 - 1e-9) {
+      const int k = (int)k0;
+      return k < 0 ? 0 : (k > p.L - 1 ? p.L - 1 : k);
+    }
     const double angle = fabs(wrap_to_pi(h - 0.0));
     int best = 0;
     double bd = 0;
@@ -848,7 +885,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     // tb = tan(beta) = 1/2 tan(steering) (see steer_tan_beta); acceleration command
     double tb = 0.0, accel = 0.0;
     if (controlled || drives) {
-      const double inv_v = 1.0 / not_zero(me.v);
+      const double inv_v = fast_rcp(not_zero(me.v));
       tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
     }
     if (controlled) {
@@ -878,7 +915,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
       // beta = atan(tb):  cos(beta) = 1/sqrt(1+tb^2), sin(beta) = tb*cos(beta);
       // cos(h+beta), sin(h+beta) by angle addition against the cached cos(h), sin(h)
-      const double cb = 1.0 / sqrt(1.0 + tb * tb), sb = tb * cb;
+      const double cb = fast_rsqrt(1.0 + tb * tb), sb = tb * cb;
       const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
       me.x += vx * p.dt;
       me.y += vy * p.dt;
@@ -888,7 +925,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
         me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
         me.impx = me.impy = 0.0;
       }
-      me.h += me.v * sb / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
       me.lane = B::closest_lane(p, me.x, me.y, me.h);  // on_state_update
       sincos(me.h, &me.sh, &me.ch);

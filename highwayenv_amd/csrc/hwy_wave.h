@@ -35,7 +35,7 @@ __device__ inline int wave_send_i(int v, int dst) { return __builtin_amdgcn_ds_p
 
 struct WaveShared {
   // frame snapshot in RANK order (slot r == r-th vehicle along the road)
-  double x[64], v[64], c[64], s[64], ts[64];
+  double x[64], v[64], c[64], s[64], lr[64];  // lr = log(v/v0), see EnvBlock::idm_log_ratio
   int idx[64];
   EnvBlock<1>::Shared blk;  // scratch for the (rare) spawn path and shared helpers
 };
@@ -256,10 +256,11 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       m_right = (L == me.lane + 1) ? b : m_right;
       m_tgt = (L == me.tgt) ? b : m_tgt;
     }
-    // frame-start snapshot, stored in rank order
+    // frame-start snapshot, stored in rank order (with each vehicle's IDM log speed ratio)
+    const double log_ratio = active ? B::idm_log_ratio(p, me.v, me.ts) : 0.0;  // egos and wrecks can be followers too
     __syncthreads();  // previous frame's gathers are complete (single wave: an s_barrier no-op + waitcnt)
     if (active) {
-      sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.ts[rank] = me.ts;
+      sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
       sh.idx[rank] = i;
     }
     __syncthreads();
@@ -307,36 +308,43 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
 
     double free_self = 0.0, gap_own = 0.0;
     if (drives) {
-      free_self = B::idm_free(p, me.v, me.ts, me.delta);
+      free_self = B::idm_free_from_log(log_ratio, me.delta);
       gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
     }
+    // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
+    // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
+    bool ok_l = false, ok_r = false;
     if (decide) {
       me.timer = 0.0;
-      // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
-      // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
       const double self_a = free_self - gap_own;
       const bool moving = !(fabs(me.v) < 1);
       const bool cl = left_ok && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
       const bool cr = right_ok && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
       const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
       const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
-      bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
-      bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
-      // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED
-      if (ok_l && rl >= 0) {
-        const double a_f = B::idm_free(p, sh.v[rl], sh.ts[rl], me.delta) -
-                           B::idm_gap(sh.x[rl], sh.v[rl], sh.c[rl], sh.s[rl], me.x, me.v, me.ch, me.sh);
-        ok_l = !(a_f < -HWY_LC_MAX_BRAKING);
-      }
-      if (ok_r && rrt >= 0) {
-        const double a_f = B::idm_free(p, sh.v[rrt], sh.ts[rrt], me.delta) -
-                           B::idm_gap(sh.x[rrt], sh.v[rrt], sh.c[rrt], sh.s[rrt], me.x, me.v, me.ch, me.sh);
-        ok_r = !(a_f < -HWY_LC_MAX_BRAKING);
-      }
-      // side_lanes order is [left, right] and the loop does not break: right wins if both pass
-      if (ok_l) me.tgt = me.lane - 1;
-      if (ok_r) me.tgt = me.lane + 1;
+      ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
     }
+    // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED.
+    // Evaluated only for candidates that passed the (pow-free) incentive test, one side per pass (a
+    // vehicle that needs both sides checked -- rare -- takes a second pass); the follower's log speed
+    // ratio comes from the snapshot, so the test costs one exp and one gap term.
+    {
+      bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
+      while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
+        if (pend_l || pend_r) {
+          const bool left = pend_l;
+          const int rf = left ? rl : rrt;
+          const double a_f = B::idm_free_from_log(sh.lr[rf], me.delta) -
+                             B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
+          const bool safe = !(a_f < -HWY_LC_MAX_BRAKING);
+          if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
+        }
+      }
+    }
+    // side_lanes order is [left, right] and the loop does not break: right wins if both pass
+    if (ok_l) me.tgt = me.lane - 1;
+    if (ok_r) me.tgt = me.lane + 1;
     // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
     {
       u64 cm = __ballot(changer);
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     // ---- E. Road.act: low-level control ----------------------------------------------------------------
     double tb = 0.0, accel = 0.0;
     if (controlled || drives) {
-      const double inv_v = 1.0 / not_zero(me.v);
+      const double inv_v = fast_rcp(not_zero(me.v));
       tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
     }
     if (controlled) {
@@ -387,7 +395,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       }
       if (me.v > HWY_MAX_SPEED) accel = fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v));
       else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
-      const double cb = 1.0 / sqrt(1.0 + tb * tb), sb = tb * cb;
+      const double cb = fast_rsqrt(1.0 + tb * tb), sb = tb * cb;
       const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
       me.x += vx * p.dt;
       me.y += vy * p.dt;
@@ -397,7 +405,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
         me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
         me.impx = me.impy = 0.0;
       }
-      me.h += me.v * sb / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
       me.lane = B::closest_lane(p, me.x, me.y, me.h);
       sincos(me.h, &me.sh, &me.ch);

@@ -25,7 +25,7 @@ def wave_variants(dev, wav):
     v = {"wbase": (dev, wav)}
     v["winline"] = (dev.replace("__device__ __attribute__((noinline)) inline int pair_collide", "__device__ inline int pair_collide"), wav)
     v["wnocollide"] = (dev, cut(wav, "    const Body mine{me.x, me.y, me.v, me.ch, me.sh};", "  }  // frames", ""))
-    v["wnorank"] = (dev, cut(wav, "    int cnt_lt = 0, cnt_le = 0;", "    const bool tie = active && (cnt_le - cnt_lt) > 1;", "    int cnt_lt = i, cnt_le = i + 1;\n"))
+    v["wnorank"] = (dev, wav.replace("    bool recount = (fr == 0);", "    bool recount = false;"))
     v["wnomobil"] = (dev, wav.replace("    if (decide) {\n      me.timer = 0.0;", "    if (false) {\n      me.timer = 0.0;"))
     v["wnopow"] = (dev.replace("const double rp = r > 0.0 ? exp(delta * log(r)) : 0.0;", "const double rp = r * delta;"), wav)
     v["wnosincos"] = (dev, wav.replace("      sincos(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))
@@ -38,7 +38,7 @@ def wave_variants(dev, wav):
                   "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
                   "  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool controlled")
     marks = [("    // ---- A. meta-action (abstract.py:294-304", 0),
-             ("    // ---- C. rank along the road (readlane counting pass)", 1),
+             ("    // ---- C. rank along the road ---", 1),
              ("    // lane membership (AbstractLane.on_lane, margin 1) -> bits", 2),
              ("    // ---- D. Road.act: lane-change policy (behavior.py:219-263)", 3),
              ("    double free_self = 0.0, gap_own = 0.0;", 4),
