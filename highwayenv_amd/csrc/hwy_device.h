@@ -165,6 +165,21 @@ __device__ inline double fast_rsqrt(double x) {  // x > 0, finite
   return fma(y, e, y);
 }
 
+// asin on [-0.5, 0.5] with the classic fdlibm rational approximation (e_asin.c, < 1 ulp):
+//   asin(x) = x + x * R(x^2),  R(t) = t*P(t)/Q(t).   Larger |x| (rare: a lateral error of metres)
+// goes to the library routine.
+__device__ inline double asin_small(double x) {
+  if (fabs(x) > 0.5) return asin(x);
+  const double t = x * x;
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  const double pp = t * fma(t, fma(t, fma(t, fma(t, fma(t, pS5, pS4), pS3), pS2), pS1), pS0);
+  const double qq = fma(t, fma(t, fma(t, fma(t, qS4, qS3), qS2), qS1), 1.0);
+  return fma(x, pp * fast_rcp(qq), x);
+}
+
 // ---- counter-based RNG for the device-side reset: Philox-4x32-10 --------------------------
 // (Salmon et al., SC'11.)  NOT numpy's PCG64 stream: see hwy_reset in hwy_engine.h.
 __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -407,7 +422,7 @@ struct EnvBlock {
     const double a = clipd((-HWY_KP_LATERAL * lat) * inv_v, -1.0, 1.0);
     // clip(asin(a), +-pi/4): asin is only evaluated when it is not going to be clipped
     const double s45 = 0.7071067811865476;  // sin(pi/4) rounded up: |a| >= s45 => |asin a| >= pi/4 (clipped)
-    const double heading_ref = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin(a), -HWY_PI / 4, HWY_PI / 4));
+    const double heading_ref = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin_small(a), -HWY_PI / 4, HWY_PI / 4));
     const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
     const double w = clipd((HWY_VEH_LENGTH / 2 * inv_v) * heading_rate_command, -1.0, 1.0);
     const double tan_max = 1.7320508075688767;  // tan(MAX_STEERING_ANGLE = fl(pi/3)) in f64

@@ -66,18 +66,21 @@ def test_free_running_episodes_vs_reference(backend, name):
     for t in range(g.steps):
         obs, reward, term, trunc, info = eng.step(g.actions[t])
         what = f"{name} step {t}"
-        L = live
+        want = g.state("step", t, time=float(t + 1))
+        wreck_now = ((want["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        T_ = live            # episodes live at the start of the step: flags / termination / reward
+        L = live & ~wreck_now  # ... and collision-free during it: everything (see _random_rollout_vs_oracle)
         compared += int(L.sum())
+        np.testing.assert_array_equal(term[T_], g.z["terminated"][t].astype(bool)[T_], err_msg=what)
+        np.testing.assert_array_equal(trunc, g.z["truncated"][t].astype(bool), err_msg=what)
+        np.testing.assert_array_equal(info["crashed"][T_, 0], g.z["info_crashed"][t].astype(bool)[T_], err_msg=what)
+        np.testing.assert_allclose(reward[T_, 0], g.z["reward"][t][T_], rtol=0, atol=1e-6, err_msg=what)
         np.testing.assert_allclose(obs[L, 0], g.z["obs"][t][L], rtol=0, atol=1e-6, err_msg=what)
         np.testing.assert_allclose(reward[L, 0], g.z["reward"][t][L], rtol=0, atol=1e-9, err_msg=what)
-        np.testing.assert_array_equal(term[L], g.z["terminated"][t].astype(bool)[L], err_msg=what)
-        np.testing.assert_array_equal(trunc, g.z["truncated"][t].astype(bool), err_msg=what)
         np.testing.assert_allclose(info["speed"][L, 0], g.z["info_speed"][t][L], rtol=0, atol=1e-9, err_msg=what)
-        np.testing.assert_array_equal(info["crashed"][L, 0], g.z["info_crashed"][t].astype(bool)[L], err_msg=what)
-        want = g.state("step", t, time=float(t + 1))
         got = eng.get_state()
         assert_state_close({k: v[L] for k, v in got.items()}, {k: v[L] for k, v in want.items()}, atol=1e-7, what=what)
-        live = live & ~((want["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        live = live & ~wreck_now
         if not live.all():
             for k in got:
                 got[k][~live] = want[k][~live]
@@ -106,18 +109,26 @@ def _random_rollout_vs_oracle(backend, config, fast, E, steps, seed):
         obs, reward, term, trunc, info = eng.step(acts)
         o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
         what = f"step {t}"
+        # Envs in which a collision happened during this step: flags / termination / reward are compared,
+        # positions are not -- when two cars collide while tracking the same lane centre, the sign of the
+        # reference's minimum-translation vector is decided by rounding noise in dy ~ 1e-16 (utils.py:232-236)
+        # and the 1 m lateral push it encodes differs between any two libm's.
+        wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        ok = ~wreck
         np.testing.assert_array_equal(term, te2, err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
         np.testing.assert_array_equal(info["crashed"], i2["crashed"], err_msg=what)
-        np.testing.assert_allclose(obs, o2, rtol=0, atol=1e-6, err_msg=what)
-        np.testing.assert_allclose(reward, r2, rtol=0, atol=1e-9, err_msg=what)
-        np.testing.assert_allclose(info["speed"], i2["speed"], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(reward, r2, rtol=0, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(info["speed"][ok], i2["speed"][ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
-        assert_state_close(got, ref, atol=1e-7, what=what)
+        assert_state_close({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in ref.items()}, atol=1e-7, what=what)
+        np.testing.assert_array_equal((got["flags"] & _abi.F_CRASHED)[:, 0], (ref["flags"] & _abi.F_CRASHED)[:, 0], err_msg=what)
         # an env holding a wreck (possible without `terminated` when the crash does not involve agent 0:
         # IDM-IDM pile-ups in highway-v0, secondary agents) is retired too: resting contact is the one
         # regime where the reference itself is ill-conditioned (see the ulp-noise test below)
-        done = term | trunc | ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        done = term | trunc | wreck
         n_term += int(term.sum())
         n_trunc += int(trunc.sum())
         n_crashed_vehicles += int(((ref["flags"][done] & _abi.F_CRASHED) != 0).sum())
