@@ -649,6 +649,9 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
   }
 }
 
+// HBM traffic discipline: every dynamic word is read once and written once per policy step; the
+// pending-impact pair is only touched for vehicles that have one (flag bit), and per-vehicle constants
+// (IDM exponent, an IDM vehicle's target speed) are never written back by the step kernel.
 template <int NW>
 __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
   const int i = threadIdx.x;
@@ -657,21 +660,30 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
     const size_t k = (size_t)e * p.pitch + i;
     o.x = p.st.x[k]; o.y = p.st.y[k]; o.h = p.st.heading[k]; o.v = p.st.speed[k];
     o.timer = p.st.timer[k]; o.ts = p.st.target_speed[k]; o.delta = p.st.delta[k];
-    o.impx = p.st.impact_x[k]; o.impy = p.st.impact_y[k];
     const int w = p.st.packed[k];
     o.lane = w & 0xff; o.tgt = (w >> 8) & 0xff; o.sidx = (w >> 16) & 0xff; o.flags = (w >> 24) & 0xff;
+    if (o.flags & HWY_F_HAS_IMPACT) {
+      o.impx = p.st.impact_x[k];
+      o.impy = p.st.impact_y[k];
+    }
     sincos(o.h, &o.sh, &o.ch);
   }
 }
+// full = true: spawn / reset (every field); false: end of a step (dynamic fields only)
 template <int NW>
-__device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o) {
+__device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, bool full = true) {
   const int i = threadIdx.x;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
     p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
-    p.st.timer[k] = o.timer; p.st.target_speed[k] = o.ts; p.st.delta[k] = o.delta;
-    p.st.impact_x[k] = o.impx; p.st.impact_y[k] = o.impy;
     p.st.packed[k] = pack_word(o.lane, o.tgt, o.sidx, o.flags);
+    if (full || !(o.flags & HWY_F_CONTROLLED)) p.st.timer[k] = o.timer;
+    if (full || (o.flags & HWY_F_CONTROLLED)) p.st.target_speed[k] = o.ts;
+    if (full) p.st.delta[k] = o.delta;
+    if (full || (o.flags & HWY_F_HAS_IMPACT)) {
+      p.st.impact_x[k] = o.impx;
+      p.st.impact_y[k] = o.impy;
+    }
   }
 }
 template <int NW>
@@ -1039,7 +1051,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     }
     observe_env<NW>(p, sh, e, me, true);
   }
-  store_vehicle<NW>(p, e, me);
+  store_vehicle<NW>(p, e, me, false);
 }
 
 }  // namespace hwy

@@ -289,6 +289,11 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
       if (h->target_lane) h->target_lane[k] = (w >> 8) & 0xff;
       if (h->speed_index) h->speed_index[k] = (w >> 16) & 0xff;
       if (h->flags) h->flags[k] = (w >> 24) & 0xff;
+      // the impact pair is only maintained while the flag is set (Vehicle.impact is None otherwise)
+      if (!(((w >> 24) & 0xff) & HWY_F_HAS_IMPACT)) {
+        if (h->impact_x) h->impact_x[k] = 0.0;
+        if (h->impact_y) h->impact_y[k] = 0.0;
+      }
     }
   if (h->time) std::memcpy(h->time, tm, sizeof(double) * E);
   return HWY_OK;

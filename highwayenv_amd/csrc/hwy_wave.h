@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
 
   // ---- H. observe / reward / done ---------------------------------------------------------------------------
   if (p.full_step) observe_wave(p, e, me, true);
-  store_vehicle<1>(p, e, me);
+  store_vehicle<1>(p, e, me, false);
 }
 
 // Reset / observe kernels for N <= 64 reuse the generic ones (not on the per-step path).

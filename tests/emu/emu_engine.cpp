@@ -49,6 +49,7 @@ struct HostImage {
     for (size_t k = 0; k < plane; ++k) {
       const int32_t w = packed[k];
       h.lane[k] = w & 0xff; h.target_lane[k] = (w >> 8) & 0xff; h.speed_index[k] = (w >> 16) & 0xff; h.flags[k] = (w >> 24) & 0xff;
+      if (!(h.flags[k] & HWY_F_HAS_IMPACT)) h.impact_x[k] = h.impact_y[k] = 0.0;  // as hwy_get_state does
     }
   }
 };

@@ -62,10 +62,11 @@ def test_no_gpu_means_loud_failure_not_fallback():
         env.reset(seed=0)
 
 
-def test_single_env_dropin_matches_reference_episode():
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+def test_single_env_dropin_matches_reference_episode(real):
     """HighwayEnvFast(): reset(seed=0), golden actions -> the reference's obs/reward/flags."""
     g = Golden("cfg1_fast_default")
-    env = EmuSingleFast()
+    env = envs.HighwayEnvFast() if real else EmuSingleFast()
     obs, info = env.reset(seed=int(g.seeds[0]))
     assert obs.shape == (5, 5) and obs.dtype == np.float32
     np.testing.assert_allclose(obs, g.z["obs0"][0], atol=1e-6)
@@ -83,8 +84,9 @@ def test_single_env_dropin_matches_reference_episode():
         env.step(9)
 
 
-def test_batched_reset_seed_convention_and_options_config():
-    env = EmuFast(num_envs=3)
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+def test_batched_reset_seed_convention_and_options_config(real):
+    env = (envs.BatchedHighwayEnvFast if real else EmuFast)(num_envs=3)
     obs, info = env.reset(seed=0, options={"config": {"lanes_count": 4, "vehicles_count": 50}})
     assert obs.shape == (3, 5, 5)
     g = Golden("cfg2_fast_n50_l4")  # seeds 0..3 of the same config
@@ -95,3 +97,20 @@ def test_batched_reset_seed_convention_and_options_config():
     # reset() without a seed continues each env's np_random stream like the reference does
     obs2, _ = env.reset()
     assert not np.allclose(obs2, obs)
+
+
+@pytest.mark.gpu
+def test_batched_env_device_spawn_autoreset_runs_and_resets():
+    """spawn_mode='device' + autoreset: the pure-GPU path used by the benchmark, through the env API."""
+    env = envs.BatchedHighwayEnvFast({"vehicles_count": 50, "lanes_count": 4, "duration": 5}, num_envs=256,
+                                     spawn_mode="device", autoreset=True)
+    obs, info = env.reset(seed=7)
+    assert obs.shape == (256, 5, 5) and np.isfinite(obs).all()
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for t in range(12):
+        obs, r, te, tr, info = env.step(rng.integers(0, 5, 256))
+        assert np.isfinite(obs).all() and ((0 <= r) & (r <= 1)).all()
+        n_done += int((te | tr).sum())
+    assert n_done >= 256  # duration 5 => every env truncated (and was re-spawned) at least once
+    env.close()

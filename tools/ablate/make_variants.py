@@ -54,6 +54,9 @@ def wave_variants(dev, wav):
     t = t.replace("  if (p.full_step) observe_wave(p, e, me, true);\n  store_vehicle<1>(p, e, me);\n}",
                   "  if (p.full_step) observe_wave(p, e, me, true);\n  TICK(11)\n  store_vehicle<1>(p, e, me);\n"
                   "  if (i == 0 && p.obs) for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}")
+    t = t.replace("    if (recount) {  // wave-uniform\n", "    if (recount) {  n_recount += 1.0f;\n")
+    t = t.replace("  long long t_prev = clock64();", "  float n_recount = 0.0f; long long t_prev = clock64();")
+    t = t.replace("p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}", "p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n  if (i == 0 && p.obs) p.obs[(size_t)e * p.A * p.V * p.F + 12] = n_recount;\n}")
     v["wticks"] = (dev, t)
     return v
 

@@ -18,12 +18,12 @@ eng = Engine(cfg)
 eng.reset(base_seed=5, ego_spacing=1.5, vehicles_density=1.0)
 eng.set_autoreset(True, base_seed=99, ego_spacing=1.5, vehicles_density=1.0)  # the bench's steady-state workload
 rng = np.random.default_rng(0)
-tot = np.zeros(12)
+tot = np.zeros(13)
 n = 0
 for t in range(60):
     obs = eng.step(rng.integers(0, 5, size=(E, 1)))[0]
     if t >= 40:
-        tot += obs.reshape(E, -1)[:, :12].astype(np.float64).mean(0)
+        tot += obs.reshape(E, -1)[:, :13].astype(np.float64).mean(0)
         n += 1
 names = (["load", "A+B publish", "C rank+masks", "D neigh+free+mobil", "D' abort chain", "E control", "F integrate",
           "G collisions", "H observe", "store", "-", "-"] if os.environ.get("HWY_STEP_KERNEL") == "block" else
@@ -31,5 +31,6 @@ names = (["load", "A+B publish", "C rank+masks", "D neigh+free+mobil", "D' abort
           "D mobil", "D abort chain", "E control", "F integrate", "G collisions", "H observe"])
 tot /= n
 for k, nm in enumerate(names):
-    print(f"{nm:22s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot.sum():5.1f}%")
-print(f"{'total':22s} {tot.sum():10.0f}")
+    print(f"{nm:22s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot[:12].sum():5.1f}%")
+print(f"{'total':22s} {tot[:12].sum():10.0f}")
+print("rank recounts per step (of 5 frames):", tot[12])
