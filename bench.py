@@ -39,6 +39,21 @@ def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int) -> int:
     return 72 * n_vehicles + 110 * agents
 
 
+def measured_traffic(envs_per_gpu: int):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
+    tools/traffic_report.py -> profiles/traffic_r01.json).  PMC counters cannot be read from inside this
+    process, so the number is the one measured for the same kernel and config; None if absent or if the
+    run uses another batch size."""
+    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU:
+        return None
+    try:
+        return json.load(open(path))["traffic_bytes_per_launch_calibrated"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_dict, budget_s: float = 12.0):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
@@ -137,6 +152,18 @@ def main() -> None:
     kernel_ms, launches = eng.profile_read()
     eng.profile_enable(False)
 
+    # PCIe-inclusive rate of the host-pointer entry point (hwy_step: H2D actions, kernel, D2H results, sync);
+    # reported for DESIGN.md, never as `value`
+    host_rate = None
+    if world == 1:
+        acts_h = np.random.default_rng(5).integers(0, 5, size=(E, A)).astype(np.int32)
+        for _ in range(5):
+            eng.step(acts_h)
+        th = time.perf_counter()
+        for _ in range(40):
+            eng.step(acts_h)
+        host_rate = 40 * E / (time.perf_counter() - th)
+
     # statistics of the run (sanity: the workload really stepped and reset)
     term = out.terminated().sum().item()
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -170,10 +197,11 @@ def main() -> None:
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * VEHICLES_COUNT,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "hwy_step_kernel<1>", "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E),
+                         "kernel": "hwy_step_wave_kernel<2>  (one 64-wide wavefront per env)", "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": b_env * E},
             "terminated_in_last_step": int(term),
+            "host_path_env_steps_per_s": host_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg_dict)

@@ -37,9 +37,11 @@ for t in range(20):
 # bytes a perfect implementation moves for a frames=0 launch, at 64-byte line granularity
 row_f64 = ((N * 8 + 63) // 64) * 64
 row_i32 = ((N * 4 + 63) // 64) * 64
+# a frames=0 launch reads x,y,heading,speed,timer,target_speed,delta (+packed word; the impact pair only
+# where flagged) and writes back x,y,heading,speed,timer (+packed word): see load_vehicle / store_vehicle
 known = {"E": E, "N": N, "pitch": pitch,
-         "frames0_read_bytes": E * (9 * row_f64 + row_i32),
-         "frames0_write_bytes": E * (9 * row_f64 + row_i32),
-         "frames0_read_bytes_exact": E * N * (9 * 8 + 4),
+         "frames0_read_bytes": E * (7 * row_f64 + row_i32),
+         "frames0_write_bytes": E * (5 * row_f64 + row_i32),
+         "frames0_read_bytes_exact": E * N * (7 * 8 + 4),
          "algorithmic_bytes_per_step": (72 * N + 110) * E}
 print(json.dumps(known))
