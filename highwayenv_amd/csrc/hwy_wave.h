@@ -319,25 +319,22 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
     const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
 
-    double free_self = 0.0, gap_own = 0.0;
-    if (drives) {
-      free_self = B::idm_free_from_log(log_ratio, me.delta);
-      gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
-    }
+    // Straight-line (branch-free) evaluation for every lane: a wavefront pays for a branch as soon as one
+    // lane takes it, and nearly every frame some vehicle drives / decides, so predication costs nothing
+    // extra while giving the scheduler one large block of independent f64 chains to interleave.
+    const double free_self = B::idm_free_from_log(log_ratio, me.delta);
+    const double gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
     // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
     // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
-    bool ok_l = false, ok_r = false;
-    if (decide) {
-      me.timer = 0.0;
-      const double self_a = free_self - gap_own;
-      const bool moving = !(fabs(me.v) < 1);
-      const bool cl = left_ok && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
-      const bool cr = right_ok && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
-      const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
-      const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
-      ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
-      ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
-    }
+    const double self_a = free_self - gap_own;
+    const bool moving = !(fabs(me.v) < 1);
+    const bool cl = decide && left_ok && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
+    const bool cr = decide && right_ok && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
+    const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
+    const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
+    bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
+    bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
+    me.timer = decide ? 0.0 : me.timer;
     // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED.
     // Evaluated only for candidates that passed the (pow-free) incentive test, one side per pass (a
     // vehicle that needs both sides checked -- rare -- takes a second pass); the follower's log speed
@@ -379,35 +376,28 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     }
 
     // ---- E. Road.act: low-level control ----------------------------------------------------------------
-    double tb = 0.0, accel = 0.0;
-    if (controlled || drives) {
-      const double inv_v = fast_rcp(not_zero(me.v));
-      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
+    const double inv_v = fast_rcp(not_zero(me.v));
+    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
+    double accel = free_self - gap_own;
+    if (drives && me.lane != me.tgt) {
+      // leader on the target lane.  For a vehicle that was already changing lanes m_tgt is that lane's
+      // mask; for one that decided just now the target is the left/right lane evaluated above.
+      const int f2 = (me.tgt == tgt_old) ? ft : (me.tgt == me.lane - 1 ? fl : frt);
+      double a2 = free_self;
+      if (f2 >= 0) a2 = free_self - B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f2], sh.v[f2], sh.c[f2], sh.s[f2]);
+      accel = (a2 < accel) ? a2 : accel;  // Python min(a, b)
     }
-    if (controlled) {
-      accel = HWY_KP_A * (me.ts - me.v);
-    } else if (drives) {
-      accel = free_self - gap_own;
-      if (me.lane != me.tgt) {
-        // leader on the target lane.  For a vehicle that was already changing lanes m_tgt is that lane's
-        // mask; for one that decided just now the target is the left/right lane evaluated above.
-        int f2 = (me.tgt == tgt_old) ? ft : (me.tgt == me.lane - 1 ? fl : frt);
-        double a2 = free_self;
-        if (f2 >= 0) a2 = free_self - B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f2], sh.v[f2], sh.c[f2], sh.s[f2]);
-        accel = (a2 < accel) ? a2 : accel;
-      }
-      accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
-    }
+    accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
+    accel = controlled ? HWY_KP_A * (me.ts - me.v) : accel;  // speed_control (controller.py:189-198), not clipped
 
     // ---- F. Road.step: integrate -------------------------------------------------------------------------
-    if (active) {
-      if (idm) me.timer += p.dt;
-      if (crashed0) {
-        tb = 0.0;
-        accel = -1.0 * me.v;
-      }
-      if (me.v > HWY_MAX_SPEED) accel = fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v));
-      else if (me.v < HWY_MIN_SPEED) accel = fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v));
+    {
+      me.timer = idm ? me.timer + p.dt : me.timer;
+      // clip_actions (kinematics.py:155-168): a crashed vehicle has steering 0 (tan(beta) = 0), accel = -speed
+      tb = crashed0 ? 0.0 : tb;
+      accel = crashed0 ? -1.0 * me.v : accel;
+      accel = (me.v > HWY_MAX_SPEED) ? fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v))
+                                     : ((me.v < HWY_MIN_SPEED) ? fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v)) : accel);
       const double cb = fast_rsqrt(1.0 + tb * tb), sb = tb * cb;
       const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
       me.x += vx * p.dt;
