@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-HWY_ABI_VERSION = 1
+HWY_ABI_VERSION = 2
 HWY_MAX_AGENTS = 16
 HWY_MAX_FEATURES = 16
 HWY_MAX_TARGET_SPEEDS = 8
@@ -28,10 +28,13 @@ F_CRASHED, F_HAS_IMPACT, F_CHECK_COLLISIONS, F_CONTROLLED = 1, 2, 4, 8
 # config flags
 C_NORMALIZE_REWARD, C_OFFROAD_TERMINAL, C_OBS_ABSOLUTE, C_OBS_NORMALIZE, C_OBS_CLIP, C_OBS_SEE_BEHIND = 1, 2, 4, 8, 16, 32
 C_EGO_ONLY_COLLISIONS = 64
+C_GRID_ALIGN = 128
+OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
+HWY_MAX_GRID_CELLS = 65536
 
 FEATURE_IDS = {name: i for i, name in enumerate(
     ["presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h", "cos_d", "sin_d",
-     "long_off", "lat_off", "ang_off"])}
+     "long_off", "lat_off", "ang_off", "on_road"])}
 
 # DiscreteMetaAction.ACTIONS_ALL (envs/common/action.py:204)
 ACTIONS_ALL = {0: "LANE_LEFT", 1: "IDLE", 2: "LANE_RIGHT", 3: "FASTER", 4: "SLOWER"}
@@ -68,7 +71,19 @@ class HwyConfig(C.Structure):
         ("obs_range_y", C.c_double * 2),
         ("obs_range_vx", C.c_double * 2),
         ("obs_range_vy", C.c_double * 2),
+        ("obs_type", C.c_int32),
+        ("grid_shape", C.c_int32 * 2),
+        ("reserved1", C.c_int32),
+        ("grid_min", C.c_double * 2),
+        ("grid_step", C.c_double * 2),
     ]
+
+
+def obs_shape(cfg: "HwyConfig") -> tuple:
+    """Per-agent observation shape: (V, F) Kinematics, (F, W, H) OccupancyGrid."""
+    if cfg.obs_type == OBS_OCCUPANCY_GRID:
+        return (cfg.obs_features, cfg.grid_shape[0], cfg.grid_shape[1])
+    return (cfg.obs_vehicles, cfg.obs_features)
 
 
 _DP = C.POINTER(C.c_double)
@@ -205,13 +220,14 @@ def make_config(config: dict, num_envs: int, fast: bool = False) -> HwyConfig:
              "ExitObservation")
     if obs["type"] not in known:
         raise ValueError("Unknown observation type")
-    if obs["type"] != "Kinematics":
+    if obs["type"] not in ("Kinematics", "OccupancyGrid"):
         raise NotImplementedError(f"observation type {obs['type']} is outside the MI355X hot-path scope")
+    grid = obs["type"] == "OccupancyGrid"
     if cfg.get("other_vehicles_type", "highway_env.vehicle.behavior.IDMVehicle") != "highway_env.vehicle.behavior.IDMVehicle":
         raise NotImplementedError("only IDMVehicle traffic is in the hot-path scope")
     if cfg.get("neighbour_vehicles_connected_lanes", False):
         raise NotImplementedError("neighbour_vehicles_connected_lanes is meaningless on a single-segment highway")
-    if obs.get("order", "sorted") != "sorted":
+    if not grid and obs.get("order", "sorted") != "sorted":
         raise NotImplementedError("KinematicObservation order='shuffled' is out of scope")
 
     c = HwyConfig()
@@ -249,25 +265,44 @@ def make_config(config: dict, num_envs: int, fast: bool = False) -> HwyConfig:
     c.reward_speed_range[0], c.reward_speed_range[1] = map(float, cfg["reward_speed_range"])
     c.perception_distance = 5.0 * 40.0  # AbstractEnv.PERCEPTION_DISTANCE (abstract.py:58)
 
-    feats = obs.get("features") or ["presence", "x", "y", "vx", "vy"]
+    if grid:
+        # OccupancyGridObservation.__init__ (observation.py:286-327)
+        feats = obs["features"] if obs.get("features") is not None else ["presence", "vx", "vy", "on_road"]
+        if obs.get("absolute", False):
+            raise NotImplementedError()  # the reference raises it too (observation.py:358-359)
+        if obs.get("as_image", False):
+            raise NotImplementedError("OccupancyGrid as_image (uint8) is out of scope")
+        gs = np.array(obs["grid_size"] if obs.get("grid_size") is not None else [[-27.5, 27.5], [-27.5, 27.5]], np.float64)
+        step = np.array(obs["grid_step"] if obs.get("grid_step") is not None else [5, 5], np.float64)
+        shape = np.asarray(np.floor((gs[:, 1] - gs[:, 0]) / step), dtype=np.intp)
+        if shape.min() < 1 or int(shape[0]) * int(shape[1]) > HWY_MAX_GRID_CELLS:
+            raise ValueError(f"occupancy grid must hold 1..{HWY_MAX_GRID_CELLS} cells")
+        c.obs_type = OBS_OCCUPANCY_GRID
+        c.grid_shape[0], c.grid_shape[1] = int(shape[0]), int(shape[1])
+        c.grid_min[0], c.grid_min[1] = float(gs[0, 0]), float(gs[1, 0])
+        c.grid_step[0], c.grid_step[1] = float(step[0]), float(step[1])
+        c.obs_vehicles = 1
+        default_range = {"vx": [-80.0, 80.0], "vy": [-80.0, 80.0]}  # OccupancyGridObservation.normalize (:347-351)
+    else:
+        feats = obs.get("features") or ["presence", "x", "y", "vx", "vy"]
+        c.obs_type = OBS_KINEMATICS
+        c.obs_vehicles = int(obs.get("vehicles_count", 5))
+        # KinematicObservation.normalize_obs (observation.py:214-226): len(all_side_lanes) == lanes_count
+        default_range = {"x": [-200.0, 200.0], "y": [-4.0 * c.lanes_count, 4.0 * c.lanes_count],
+                         "vx": [-80.0, 80.0], "vy": [-80.0, 80.0]}
     if len(feats) > HWY_MAX_FEATURES:
         raise ValueError("too many observation features")
-    c.obs_vehicles = int(obs.get("vehicles_count", 5))
     c.obs_features = len(feats)
     for k, name in enumerate(feats):
-        if name not in FEATURE_IDS:
+        if name not in FEATURE_IDS or (name == "on_road" and not grid):
             raise KeyError(name)  # df[self.features] raises KeyError in the reference
         c.obs_feature_ids[k] = FEATURE_IDS[name]
-    fr = obs.get("features_range")
-    if not fr:
-        # KinematicObservation.normalize_obs (observation.py:214-226): len(all_side_lanes) == lanes_count
-        fr = {"x": [-200.0, 200.0], "y": [-4.0 * c.lanes_count, 4.0 * c.lanes_count],
-              "vx": [-80.0, 80.0], "vy": [-80.0, 80.0]}
+    fr = obs.get("features_range") or default_range
     inf = float("inf")
     for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
         if name in fr:
             field[0], field[1] = float(fr[name][0]), float(fr[name][1])
-        else:  # feature not normalised: encode as the identity map lmap(v,[-1,1],[-1,1]) is NOT exact; use +-inf sentinel
+        else:  # feature not normalised: +-inf sentinel
             field[0], field[1] = -inf, inf
     for name in fr:
         if name not in ("x", "y", "vx", "vy"):
@@ -285,6 +320,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False) -> HwyConfig:
         flags |= C_OBS_CLIP
     if obs.get("see_behind", False):
         flags |= C_OBS_SEE_BEHIND
+    if grid and obs.get("align_to_vehicle_axes", False):
+        flags |= C_GRID_ALIGN
     if fast:  # HighwayEnvFast._create_vehicles (highway_env.py:177-182)
         flags |= C_EGO_ONLY_COLLISIONS
     c.flags = flags

@@ -105,6 +105,10 @@ struct StepParams {
   double dt, policy_dt, duration, lane_width, road_length, speed_limit;
   double collision_reward, right_lane_reward, high_speed_reward, rs0, rs1, perception;
   double rx0, rx1, ry0, ry1, rvx0, rvx1, rvy0, rvy1;
+  // OccupancyGridObservation (obs_type == HWY_OBS_OCCUPANCY_GRID)
+  int32_t obs_type, gW, gH, g_nwp;  // grid shape; waypoints per lane of the on-road layer
+  double gmin_x, gmin_y, gstep_x, gstep_y, g_spacing;
+  int32_t *grid_ws;  // [E][A][2][W*H] cell owner (lowest vehicle index) / on-road flag
   DevState st;
   // per-call
   int32_t n_frames;       // frames to simulate (T for a policy step)
@@ -553,12 +557,103 @@ __device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Sha
   (void)e;
 }
 
+// ---- OccupancyGridObservation.observe (envs/common/observation.py:354-413) for one observer -----------
+// The reference scatters every vehicle's features into a [F][W][H] grid walking the vehicle list in
+// REVERSE (df[::-1]) so that the lowest index wins a contested cell, paints the on-road layer from lane
+// waypoints (fill_road_layer_by_lanes, :454-484), clips and maps NaN (empty) to 0.  Here: an atomic min
+// per vehicle elects each cell's owner, owners write their features, a cell-strided pass writes the
+// on-road layer and the zeros.  Cross-thread traffic goes through a small global workspace with
+// agent-scope atomics (L2), so the routine is the same for one- and multi-wavefront environments.
+// Observer data (position, speed, cos/sin heading) is passed in by the caller.
+__device__ inline void grid_ws_store(int32_t *q, int32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int32_t grid_ws_load(int32_t *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void grid_ws_min(int32_t *q, int32_t v) { __hip_atomic_fetch_min(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline void grid_cell(const StepParams &p, double px, double py, double ec, double es, int *ci, int *cj) {
+  if (p.flags & HWY_C_GRID_ALIGN) {  // pos_to_index: [[c, s], [-s, c]] @ position  (observation.py:431-435)
+    const double qx = ec * px + es * py, qy = -es * px + ec * py;
+    px = qx;
+    py = qy;
+  }
+  *ci = (int)floor((px - p.gmin_x) / p.gstep_x);
+  *cj = (int)floor((py - p.gmin_y) / p.gstep_y);
+}
+
+template <int NW>
+__device__ inline void observe_grid(const StepParams &p, int e, int a, const Veh &me, double ex, double ey, double ev,
+                                    double ec, double es) {
+  typedef EnvBlock<NW> B;
+  const int i = threadIdx.x, NT = NW * 64;
+  const bool active = i < p.N;
+  const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
+  int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
+  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  for (int t = i; t < WH; t += NT) {
+    grid_ws_store(own + t, 0x7fffffff);
+    grid_ws_store(road + t, 0);
+  }
+  __syncthreads();
+  // vehicles claim their cell (coordinates relative to the observer; normalised then de-normalised when
+  // x / y are in features_range, exactly like observation.py:377-396)
+  int my_ci = -1, my_cj = -1;
+  if (active) {
+    double x = me.x - ex, y = me.y - ey;
+    if (p.rx0 > -__builtin_inf()) x = lmap(lmap(x, p.rx0, p.rx1, -1.0, 1.0), -1.0, 1.0, p.rx0, p.rx1);
+    if (p.ry0 > -__builtin_inf()) y = lmap(lmap(y, p.ry0, p.ry1, -1.0, 1.0), -1.0, 1.0, p.ry0, p.ry1);
+    int ci, cj;
+    grid_cell(p, x, y, ec, es, &ci, &cj);
+    if (0 <= ci && ci < W && 0 <= cj && cj < H) {
+      my_ci = ci;
+      my_cj = cj;
+      grid_ws_min(own + ci * H + cj, i);
+    }
+  }
+  // on-road layer: waypoints every min(grid_step) within +-100 m of the observer on every lane
+  bool has_road = false;
+  for (int f = 0; f < F; ++f) has_road |= (p.feat[f] == HWY_FEAT_ON_ROAD);
+  if (has_road) {
+    const double start = ex - 100.0;  // origin = lane.local_coordinates(observer)[0] = x on the straight road
+    for (int t = i; t < p.L * p.g_nwp; t += NT) {
+      const int k = t / p.g_nwp, j = t - k * p.g_nwp;
+      const double wp = clipd(start + j * p.g_spacing, 0.0, p.road_length);
+      int ci, cj;
+      grid_cell(p, wp - ex, k * p.lane_width - ey, ec, es, &ci, &cj);  // lane.position(wp, 0) - observer.position
+      if (0 <= ci && ci < W && 0 <= cj && cj < H) grid_ws_store(road + ci * H + cj, 1);
+    }
+  }
+  __syncthreads();
+  const bool clip = (p.flags & HWY_C_OBS_CLIP) != 0;
+  if (my_ci >= 0 && grid_ws_load(own + my_ci * H + my_cj) == i) {  // I own my cell: write the vehicle layers
+    for (int f = 0; f < F; ++f) {
+      const int fid = p.feat[f];
+      if (fid == HWY_FEAT_ON_ROAD) continue;
+      double val = B::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
+      const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+      if (rel) {
+        val -= fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+        const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+        const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+        if (r0 > -__builtin_inf()) val = lmap(val, r0, r1, -1.0, 1.0);
+      }
+      if (clip) val = clipd(val, -1.0, 1.0);
+      out[(f * W + my_ci) * H + my_cj] = (float)val;
+    }
+  }
+  for (int t = i; t < F * WH; t += NT) {  // everything the owners do not write
+    const int f = t / WH, c = t - f * WH;
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
+    else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;  // NaN (empty) -> 0
+  }
+  __syncthreads();  // the workspace of this (env, agent) may be reused by the next call
+}
+
 // ---- KinematicObservation.observe (envs/common/observation.py:234-276) + Road.close_objects_to
 //      (road/road.py:421-450) + reward/termination (envs/highway_env.py:100-151) for every agent.
 //      Expects sh.x/y/v/c/s to hold the CURRENT state of all vehicles.  Block-uniform control flow.
 template <int NW>
 __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::Shared &sh, int e, const Veh &me,
                                    bool write_reward) {
+  const bool kin = p.obs_type == HWY_OBS_KINEMATICS;
   typedef EnvBlock<NW> B;
   const int i = threadIdx.x;
   const bool active = i < p.N;
@@ -588,7 +683,8 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
         pos += (kk < key) || (kk == key && k < i);
       }
     }
-    if (p.obs) {
+    if (p.obs && !kin) observe_grid<NW>(p, e, a, me, ex, ey, ev, ec, es);
+    if (p.obs && kin) {
       float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (active && row >= 0) {

@@ -41,6 +41,7 @@ struct hwy_engine {
   uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_info_crashed = nullptr;
   uint8_t *d_mask = nullptr;
   uint64_t *d_seeds = nullptr;
+  int32_t *d_grid_ws = nullptr;  // OccupancyGrid workspace [E][A][2][W*H]
   // pinned host staging
   void *h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
@@ -107,9 +108,16 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->lanes_count < 1 || c->lanes_count > HWY_MAX_LANES) BAD("lanes_count must be in [1,%d]", HWY_MAX_LANES);
   if (c->frames_per_step < 0) BAD("frames_per_step must be >= 0");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
+  if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");
+  if (c->obs_type == HWY_OBS_OCCUPANCY_GRID) {
+    if (c->grid_shape[0] < 1 || c->grid_shape[1] < 1 || (int64_t)c->grid_shape[0] * c->grid_shape[1] > HWY_MAX_GRID_CELLS)
+      BAD("grid_shape must hold 1..%d cells", HWY_MAX_GRID_CELLS);
+    if (!(c->grid_step[0] > 0) || !(c->grid_step[1] > 0)) BAD("grid_step must be positive");
+  }
   if (c->obs_features < 1 || c->obs_features > HWY_MAX_FEATURES) BAD("obs_features out of range");
   for (int f = 0; f < c->obs_features; ++f)
-    if (c->obs_feature_ids[f] < 0 || c->obs_feature_ids[f] >= HWY_FEAT_COUNT) BAD("unknown feature id");
+    if (c->obs_feature_ids[f] < 0 || c->obs_feature_ids[f] >= HWY_FEAT_COUNT ||
+        (c->obs_feature_ids[f] == HWY_FEAT_ON_ROAD && c->obs_type != HWY_OBS_OCCUPANCY_GRID)) BAD("unknown feature id");
   if (c->num_target_speeds < 2 || c->num_target_speeds > HWY_MAX_TARGET_SPEEDS) BAD("num_target_speeds must be in [2,%d]", HWY_MAX_TARGET_SPEEDS);
   if (!(c->dt > 0) || !(c->policy_dt > 0)) BAD("dt and policy_dt must be positive");
   if (!(c->lane_width > 0) || !(c->road_length > 0)) BAD("lane_width and road_length must be positive");
@@ -123,11 +131,12 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.st.packed = eng->d_packed; p.st.time = eng->d_time; p.st.done = eng->d_done; p.st.episode = eng->d_episode;
   p.autoreset = eng->autoreset;
   p.rp = eng->rp;
+  p.grid_ws = eng->d_grid_ws;
 }
 
 static size_t io_counts(const hwy_config &c, size_t *n_act, size_t *n_obs, size_t *n_ea) {
   *n_act = (size_t)c.num_envs * c.num_agents;
-  *n_obs = *n_act * (size_t)c.obs_vehicles * c.obs_features;
+  *n_obs = *n_act * hwy::obs_len(c);
   *n_ea = *n_act;
   return 0;
 }
@@ -182,6 +191,8 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   ALLOC(eng->d_info_crashed, n_ea);
   ALLOC(eng->d_mask, E);
   ALLOC(eng->d_seeds, E * sizeof(uint64_t));
+  if (cfg->obs_type == HWY_OBS_OCCUPANCY_GRID)
+    ALLOC(eng->d_grid_ws, n_act * 2 * (size_t)cfg->grid_shape[0] * cfg->grid_shape[1] * sizeof(int32_t));
 #undef ALLOC
   if ((e = hipMemsetAsync(eng->d_f64, 0, plane * 9 * sizeof(double), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMemsetAsync(eng->d_packed, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -212,7 +223,7 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_obs,
                   eng->d_reward, eng->d_info_speed, eng->d_term, eng->d_trunc, eng->d_info_crashed, eng->d_mask,
-                  eng->d_seeds};
+                  eng->d_seeds, eng->d_grid_ws};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);

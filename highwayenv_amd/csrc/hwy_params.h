@@ -1,5 +1,6 @@
 // hwy_params.h -- host helper: flatten hwy_config into the kernel-argument block.
 #pragma once
+#include <cmath>
 #include <cstring>
 
 #include "hwy_device.h"
@@ -21,6 +22,20 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.perception = c.perception_distance;
   p.rx0 = c.obs_range_x[0]; p.rx1 = c.obs_range_x[1]; p.ry0 = c.obs_range_y[0]; p.ry1 = c.obs_range_y[1];
   p.rvx0 = c.obs_range_vx[0]; p.rvx1 = c.obs_range_vx[1]; p.rvy0 = c.obs_range_vy[0]; p.rvy1 = c.obs_range_vy[1];
+  p.obs_type = c.obs_type;
+  if (c.obs_type == HWY_OBS_OCCUPANCY_GRID) {
+    p.gW = c.grid_shape[0]; p.gH = c.grid_shape[1];
+    p.gmin_x = c.grid_min[0]; p.gmin_y = c.grid_min[1]; p.gstep_x = c.grid_step[0]; p.gstep_y = c.grid_step[1];
+    p.g_spacing = c.grid_step[0] < c.grid_step[1] ? c.grid_step[0] : c.grid_step[1];  // np.amin(grid_step)
+    // len(np.arange(origin - 100, origin + 100, spacing)) == ceil(200 / spacing)
+    p.g_nwp = (int32_t)std::ceil(200.0 / p.g_spacing);
+  }
+}
+
+// observation length per agent: V*F (Kinematics) or F*W*H (OccupancyGrid)
+inline size_t obs_len(const hwy_config &c) {
+  return c.obs_type == HWY_OBS_OCCUPANCY_GRID ? (size_t)c.obs_features * c.grid_shape[0] * c.grid_shape[1]
+                                              : (size_t)c.obs_vehicles * c.obs_features;
 }
 
 // the 9 f64 planes of the device SoA live in one allocation, [field][E][pitch]

@@ -89,7 +89,8 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
       const double kk = wave_bcast(key, k);
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
-    if (p.obs) {
+    if (p.obs && p.obs_type != HWY_OBS_KINEMATICS) observe_grid<1>(p, e, a, me, ex, ey, ev, ec, es);
+    if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
       float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (active && row >= 0) {

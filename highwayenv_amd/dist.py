@@ -32,10 +32,12 @@ class PackedStepOutputs:
     """
 
     def __init__(self, cfg: _abi.HwyConfig, device, world: int = 1, rank: int = 0):
-        E, A, V, F = cfg.num_envs, cfg.num_agents, cfg.obs_vehicles, cfg.obs_features
-        self.E, self.A, self.V, self.F = E, A, V, F
+        E, A = cfg.num_envs, cfg.num_agents
+        self.obs_shape = _abi.obs_shape(cfg)
+        self.E, self.A = E, A
+        obs_len = int(torch.tensor(self.obs_shape).prod())
         self.world, self.rank = world, rank
-        sizes = [("reward", E * A * 8), ("info_speed", E * A * 8), ("obs", E * A * V * F * 4),
+        sizes = [("reward", E * A * 8), ("info_speed", E * A * 8), ("obs", E * A * obs_len * 4),
                  ("terminated", E), ("truncated", E), ("info_crashed", E * A)]
         self.offsets, off = {}, 0
         for name, nbytes in sizes:
@@ -52,11 +54,11 @@ class PackedStepOutputs:
 
     def views(self, buf=None) -> dict:
         b = self.buf if buf is None else buf
-        E, A, V, F = self.E, self.A, self.V, self.F
+        E, A = self.E, self.A
         return {
             "reward": self._view(b, "reward", torch.float64, (E, A)),
             "info_speed": self._view(b, "info_speed", torch.float64, (E, A)),
-            "obs": self._view(b, "obs", torch.float32, (E, A, V, F)),
+            "obs": self._view(b, "obs", torch.float32, (E, A, *self.obs_shape)),
             "terminated": self._view(b, "terminated", torch.uint8, (E,)),
             "truncated": self._view(b, "truncated", torch.uint8, (E,)),
             "info_crashed": self._view(b, "info_crashed", torch.uint8, (E, A)),

@@ -68,7 +68,7 @@ class Engine:
     def step(self, actions):
         E, A = self.E, self.A
         acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
-        obs = np.empty((E, A, self.V, self.F), np.float32)
+        obs = np.empty((E, A, *_abi.obs_shape(self.cfg)), np.float32)
         reward = np.empty((E, A), np.float64)
         term = np.empty(E, np.uint8)
         trunc = np.empty(E, np.uint8)
@@ -90,7 +90,7 @@ class Engine:
         self._check(self._lib.hwy_step_frames(self._h, _ptr(acts), int(n_frames)))
 
     def observe(self) -> np.ndarray:
-        obs = np.empty((self.E, self.A, self.V, self.F), np.float32)
+        obs = np.empty((self.E, self.A, *_abi.obs_shape(self.cfg)), np.float32)
         self._check(self._lib.hwy_observe(self._h, _ptr(obs)))
         return obs
 
@@ -101,7 +101,7 @@ class Engine:
             seeds = np.uint64(base_seed) + np.arange(self.E, dtype=np.uint64)
         sd = np.ascontiguousarray(seeds, np.uint64)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        obs = np.zeros((self.E, self.A, self.V, self.F), np.float32)
+        obs = np.zeros((self.E, self.A, *_abi.obs_shape(self.cfg)), np.float32)
         self._check(self._lib.hwy_reset(self._h, _ptr(mk), _ptr(sd), float(ego_spacing), float(vehicles_density),
                                         int(initial_lane_id), _ptr(obs)))
         return obs

@@ -115,8 +115,8 @@ class BatchedHighwayEnv:
     def _define_spaces(self):
         hc = _abi.make_config(self.config, self.num_envs, fast=self.FAST)
         self._hcfg = hc
-        A, V, F = hc.num_agents, hc.obs_vehicles, hc.obs_features
-        self.single_observation_shape = (V, F) if A == 1 else (A, V, F)
+        A = hc.num_agents
+        self.single_observation_shape = _abi.obs_shape(hc) if A == 1 else (A, *_abi.obs_shape(hc))
         if _gym is not None:
             self.single_action_space = _gym.spaces.Discrete(5)
             self.single_observation_space = _gym.spaces.Box(-np.inf, np.inf, self.single_observation_shape, np.float32)

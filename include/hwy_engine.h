@@ -24,7 +24,8 @@
  * HighwayEnv._create_vehicles puts them, index 0 for a single agent).  All
  * floating-point state is f64 like the reference (vehicle/objects.py:43);
  * observations are f32 (observation.py:276).  Host-side arrays are row-major
- * [E][N] (state), [E][A][V][F] (obs), [E][A] (actions) unless stated otherwise.
+ * [E][N] (state), [E][A][V][F] (Kinematics obs) or [E][A][F][W][H] (OccupancyGrid obs),
+ * [E][A] (actions) unless stated otherwise.
  */
 #ifndef HWY_ENGINE_H
 #define HWY_ENGINE_H
@@ -36,13 +37,14 @@
 extern "C" {
 #endif
 
-#define HWY_ABI_VERSION 1
+#define HWY_ABI_VERSION 2
 
 #define HWY_MAX_AGENTS 16
 #define HWY_MAX_FEATURES 16
 #define HWY_MAX_TARGET_SPEEDS 8
 #define HWY_MAX_LANES 16
 #define HWY_MAX_VEHICLES 256
+#define HWY_MAX_GRID_CELLS 65536
 
 typedef enum hwy_status {
   HWY_OK = 0,
@@ -69,15 +71,21 @@ enum {
   HWY_C_OBS_NORMALIZE = 8,    /* KinematicObservation.normalize     observation.py:169 */
   HWY_C_OBS_CLIP = 16,        /* KinematicObservation.clip          observation.py:170 */
   HWY_C_OBS_SEE_BEHIND = 32,  /* KinematicObservation.see_behind    observation.py:171 */
-  HWY_C_EGO_ONLY_COLLISIONS = 64 /* HighwayEnvFast: spawned traffic has check_collisions=False (highway_env.py:177-182) */
+  HWY_C_EGO_ONLY_COLLISIONS = 64, /* HighwayEnvFast: spawned traffic has check_collisions=False (highway_env.py:177-182) */
+  HWY_C_GRID_ALIGN = 128      /* OccupancyGridObservation.align_to_vehicle_axes  observation.py:294,431-435 */
 };
 
 /* observation feature ids (Vehicle.to_dict keys, vehicle/kinematics.py:237-261) */
 enum {
   HWY_FEAT_PRESENCE = 0, HWY_FEAT_X, HWY_FEAT_Y, HWY_FEAT_VX, HWY_FEAT_VY, HWY_FEAT_HEADING,
   HWY_FEAT_COS_H, HWY_FEAT_SIN_H, HWY_FEAT_COS_D, HWY_FEAT_SIN_D, HWY_FEAT_LONG_OFF,
-  HWY_FEAT_LAT_OFF, HWY_FEAT_ANG_OFF, HWY_FEAT_COUNT
+  HWY_FEAT_LAT_OFF, HWY_FEAT_ANG_OFF,
+  HWY_FEAT_ON_ROAD, /* OccupancyGrid only: the on-road layer (observation.py:454-484) */
+  HWY_FEAT_COUNT
 };
+
+/* observation types (hwy_config.obs_type) */
+enum { HWY_OBS_KINEMATICS = 0, HWY_OBS_OCCUPANCY_GRID = 1 };
 
 /* meta-actions: DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:204 */
 enum { HWY_LANE_LEFT = 0, HWY_IDLE = 1, HWY_LANE_RIGHT = 2, HWY_FASTER = 3, HWY_SLOWER = 4 };
@@ -112,6 +120,13 @@ typedef struct hwy_config {
   double reward_speed_range[2];        /* highway_env.py:46 */
   double perception_distance;          /* AbstractEnv.PERCEPTION_DISTANCE = 5*MAX_SPEED (abstract.py:58) */
   double obs_range_x[2], obs_range_y[2], obs_range_vx[2], obs_range_vy[2]; /* observation.py:214-226 */
+  /* OccupancyGridObservation (observation.py:279-499): obs is f32 [E][A][F][W][H]; features = obs_feature_ids
+   * (to_dict keys + HWY_FEAT_ON_ROAD); features_range in obs_range_* (default: vx, vy only, +-inf = absent) */
+  int32_t obs_type;                    /* HWY_OBS_* */
+  int32_t grid_shape[2];               /* W, H = floor((grid_size[:,1] - grid_size[:,0]) / grid_step) */
+  int32_t reserved1;
+  double grid_min[2];                  /* grid_size[:,0] */
+  double grid_step[2];                 /* grid_step */
 } hwy_config;
 
 /*

@@ -55,7 +55,7 @@ def frames(cfg: _abi.HwyConfig, st: dict, actions, n_frames: int) -> None:
 
 
 def observe(cfg: _abi.HwyConfig, st: dict) -> np.ndarray:
-    obs = np.zeros((cfg.num_envs, cfg.num_agents, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    obs = np.zeros((cfg.num_envs, cfg.num_agents, *_abi.obs_shape(cfg)), np.float32)
     s = _abi.state_struct(st)
     rc = lib().orc_observe(C.byref(cfg), C.byref(s), _p(obs, C.c_float))
     assert rc == 0, rc
@@ -66,7 +66,7 @@ def step(cfg: _abi.HwyConfig, st: dict, actions) -> tuple:
     """AbstractEnv.step for every env; returns (obs, reward, terminated, truncated, info)."""
     E, A = cfg.num_envs, cfg.num_agents
     acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
-    obs = np.zeros((E, A, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    obs = np.zeros((E, A, *_abi.obs_shape(cfg)), np.float32)
     reward = np.zeros((E, A), np.float64)
     term = np.zeros(E, np.uint8)
     trunc = np.zeros(E, np.uint8)

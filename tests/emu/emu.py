@@ -73,7 +73,7 @@ class EmuEngine:
     def _run(self, mode, n_frames, actions):
         E, A = self.E, self.A
         acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
-        obs = np.zeros((E, A, self.cfg.obs_vehicles, self.cfg.obs_features), np.float32)
+        obs = np.zeros((E, A, *_abi.obs_shape(self.cfg)), np.float32)
         reward = np.zeros((E, A))
         term = np.zeros(E, np.uint8)
         trunc = np.zeros(E, np.uint8)
@@ -103,7 +103,7 @@ class EmuEngine:
 
     def reset(self, seeds=None, mask=None, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1, base_seed=0):
         E, A = self.E, self.A
-        obs = np.zeros((E, A, self.cfg.obs_vehicles, self.cfg.obs_features), np.float32)
+        obs = np.zeros((E, A, *_abi.obs_shape(self.cfg)), np.float32)
         sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         s = _abi.state_struct(self.st)

@@ -84,6 +84,13 @@ extern "C" {
 size_t emu_config_size(void) { return sizeof(hwy_config); }
 
 // mode: 0 = frames only (hwy_step_frames), 1 = full policy step (hwy_step), 2 = observe only
+static std::vector<int32_t> g_grid_ws;
+static int32_t *grid_ws_for(const hwy_config *cfg) {
+  if (cfg->obs_type != HWY_OBS_OCCUPANCY_GRID) return nullptr;
+  g_grid_ws.assign((size_t)cfg->num_envs * cfg->num_agents * 2 * cfg->grid_shape[0] * cfg->grid_shape[1], 0);
+  return g_grid_ws.data();
+}
+
 int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episode, int mode, int n_frames,
             const int32_t *actions, float *obs, double *reward, uint8_t *term, uint8_t *trunc, double *speed,
             uint8_t *crashed, int autoreset, uint64_t base_seed, double ego_spacing, double vehicles_density,
@@ -103,6 +110,7 @@ int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episo
   p.rp.initial_lane_id = initial_lane_id;
   p.rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;
   p.rp.base_seed = base_seed;
+  p.grid_ws = grid_ws_for(cfg);
   p.actions = actions; p.obs = obs; p.reward = reward; p.terminated = term; p.truncated = trunc;
   p.info_speed = speed; p.info_crashed = crashed;
   if (mode == 2) {
@@ -137,6 +145,7 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
   p.reset_mask = mask;
   p.reset_seeds = seeds;
   p.obs = obs;
+  p.grid_ws = grid_ws_for(cfg);
   dispatch(RESET, p, cfg->num_envs);
   img.store(*st);
   return 0;

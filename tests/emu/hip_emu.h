@@ -104,6 +104,11 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt(x))
 #define __builtin_amdgcn_ds_permute(addr, v) emu::ds_permute((addr), (v))
+// agent-scope atomics (fibers run on one OS thread: plain accesses)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(ptr, v, order, scope) (*(ptr) = (v))
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __hip_atomic_fetch_min(ptr, v, order, scope) (*(ptr) = (*(ptr) < (v) ? *(ptr) : (v)))
 inline int __double2loint(double d) { long long b; __builtin_memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 inline int __double2hiint(double d) { long long b; __builtin_memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) {

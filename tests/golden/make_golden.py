@@ -97,6 +97,25 @@ SCENARIOS = [
          config={"offroad_terminal": True, "normalize_reward": False, "lanes_count": 2,
                  "vehicles_count": 10}, seeds=[0, 1, 2, 4], steps=10, action_seed=17,
          frames_for=0, action_p=[0.4, 0.1, 0.4, 0.05, 0.05]),
+    # OccupancyGridObservation on the straight highway: defaults ...
+    dict(name="grid_default", cls=HighwayEnvFast,
+         config={"vehicles_count": 30, "lanes_count": 4, "observation": {"type": "OccupancyGrid"}},
+         seeds=[0, 1, 2], steps=8, action_seed=11, frames_for=0),
+    # ... vehicle-aligned axes, finer / asymmetric grid, more features, no clipping
+    dict(name="grid_aligned_fine", cls=HighwayEnvFast,
+         config={"vehicles_count": 40, "lanes_count": 3,
+                 "observation": {"type": "OccupancyGrid", "align_to_vehicle_axes": True,
+                                 "grid_size": [[-30, 60], [-9, 9]], "grid_step": [3, 2],
+                                 "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
+                                 "clip": False}},
+         seeds=[3, 4], steps=8, action_seed=12, frames_for=0, action_p=[0.3, 0.1, 0.3, 0.2, 0.1]),
+    # ... x/y in features_range (the reference normalises then de-normalises the coordinates)
+    dict(name="grid_xy_range", cls=HighwayEnv,
+         config={"vehicles_count": 25, "lanes_count": 4, "simulation_frequency": 5, "duration": 12,
+                 "observation": {"type": "OccupancyGrid",
+                                 "features_range": {"x": [-100, 100], "y": [-20, 20], "vx": [-40, 40], "vy": [-10, 10]},
+                                 "features": ["presence", "vx", "vy", "x", "on_road"]}},
+         seeds=[5], steps=6, action_seed=13, frames_for=0),
 ]
 
 
@@ -158,6 +177,8 @@ def run_scenario(sc: dict) -> dict:
     out["cfg_right_lane_reward"] = np.float64(cfg["right_lane_reward"])
     out["cfg_high_speed_reward"] = np.float64(cfg["high_speed_reward"])
     out["cfg_reward_speed_range"] = np.asarray(cfg["reward_speed_range"], np.float64)
+    import json
+    out["cfg_observation_json"] = np.asarray(json.dumps(cfg["observation"]))
     out["obs0"] = np.stack([r["obs0"] for r in per_env])
     out["obs"] = np.stack([np.stack(r["obs"]) for r in per_env], axis=1)          # [steps,E,V,F]
     out["reward"] = np.asarray([r["reward"] for r in per_env], np.float64).T      # [steps,E]

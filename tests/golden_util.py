@@ -10,6 +10,7 @@ from highwayenv_amd import _abi
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+GRID = ["grid_default", "grid_aligned_fine", "grid_xy_range"]
 ALL = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
        "fast_idle_long", "fast_offroad_terminal"]
 WITH_FRAMES = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash"]
@@ -38,6 +39,9 @@ class Golden:
             "high_speed_reward": float(z["cfg_high_speed_reward"]),
             "reward_speed_range": [float(v) for v in z["cfg_reward_speed_range"]],
         })
+        if "cfg_observation_json" in z.files:
+            import json
+            self.config["observation"] = json.loads(str(z["cfg_observation_json"]))
         self.seeds = z["seeds"]
         self.actions = z["actions"]  # [steps, E]
 
