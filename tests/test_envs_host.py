@@ -40,7 +40,7 @@ def test_unknown_types_raise_like_reference():
     with pytest.raises(ValueError, match="Unknown observation type"):
         envs.BatchedHighwayEnv({"observation": {"type": "Nope"}})
     with pytest.raises(NotImplementedError):
-        envs.BatchedHighwayEnv({"observation": {"type": "OccupancyGrid"}})
+        envs.BatchedHighwayEnv({"observation": {"type": "TimeToCollision"}})
     with pytest.raises(NotImplementedError):
         envs.BatchedHighwayEnv({"action": {"type": "ContinuousAction"}})
     with pytest.raises(NotImplementedError):
