@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhwy_engine.so")
 SOURCES = ["hwy_kernels.hip", "hwy_engine.hip"]
-HEADERS = ["hwy_device.h", "hwy_wave.h", "hwy_launch.h", "hwy_params.h", os.path.join("..", "..", "include", "hwy_engine.h")]
+HEADERS = ["hwy_device.h", "hwy_wave.h", "hwy_math.h", "hwy_launch.h", "hwy_params.h", os.path.join("..", "..", "include", "hwy_engine.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 

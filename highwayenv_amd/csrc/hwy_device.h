@@ -33,7 +33,7 @@
 // pow); here the steering -> slip -> bicycle chain is folded with exact
 // trigonometric identities (tan(asin w) = w/sqrt(1-w^2), tan(atan u) = u,
 // cos/sin(atan t) = (1,t)/sqrt(1+t^2), angle addition against the cached
-// cos/sin of the heading) so that only asin, sincos and pow remain -- each
+// cos/sin of the heading) so that only asin, sincos, log and exp remain (hwy_math.h) -- each
 // folded expression agrees with the literal one to a few ulp, the same
 // order as ocml-vs-numpy libm differences, and is checked against the
 // literal C oracle at 1e-9 per frame.
@@ -47,6 +47,7 @@
 #include <stdint.h>
 
 #include "../../include/hwy_engine.h"
+#include "hwy_math.h"
 
 namespace hwy {
 
@@ -132,56 +133,12 @@ __device__ inline double not_zero(double x) {
   if (fabs(x) > eps) return x;
   return x >= 0 ? eps : -eps;
 }
-// Python/numpy float % (floor-mod)
-__device__ inline double py_mod(double a, double b) {
-  double m = (a >= 0 && a < b) ? a : fmod(a, b);  // fmod is exact; the guard only skips the call
-  if (m != 0.0) {
-    if ((b < 0) != (m < 0)) m += b;
-  } else {
-    m = copysign(0.0, b);
-  }
-  return m;
-}
-// utils.py:59-60
-__device__ inline double wrap_to_pi(double x) { return py_mod(x + HWY_PI, 2 * HWY_PI) - HWY_PI; }
+// utils.py:59-60: ((x + pi) % (2 pi)) - pi with Python's floor-mod (hwy_math.h: py_mod_pos)
+__device__ inline double wrap_to_pi(double x) { return py_mod_pos(x + HWY_PI, 2 * HWY_PI) - HWY_PI; }
 __device__ inline double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
 // utils.py:31-33
 __device__ inline double lmap(double v, double x0, double x1, double y0, double y1) {
   return y0 + (v - x0) * (y1 - y0) / (x1 - x0);
-}
-
-// ---- reciprocal / reciprocal square root to ~1 ulp: hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26
-//      relative) + two Newton steps in FMA arithmetic.  A correctly rounded IEEE division costs ~3x
-//      as many issue cycles on gfx950; the 1-ulp difference is the same order as libm-vs-libm noise.
-__device__ inline double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, y, 1.0);
-  y = fma(y, e, y);
-  e = fma(-x, y, 1.0);
-  return fma(y, e, y);
-}
-__device__ inline double fast_rsqrt(double x) {  // x > 0, finite
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  double e = fma(-h * y, y, 0.5);
-  y = fma(y, e, y);
-  e = fma(-h * y, y, 0.5);
-  return fma(y, e, y);
-}
-
-// asin on [-0.5, 0.5] with the classic fdlibm rational approximation (e_asin.c, < 1 ulp):
-//   asin(x) = x + x * R(x^2),  R(t) = t*P(t)/Q(t).   Larger |x| (rare: a lateral error of metres)
-// goes to the library routine.
-__device__ inline double asin_small(double x) {
-  if (fabs(x) > 0.5) return asin(x);
-  const double t = x * x;
-  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
-               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
-               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
-               qS4 = 7.70381505559019352791e-02;
-  const double pp = t * fma(t, fma(t, fma(t, fma(t, fma(t, pS5, pS4), pS3), pS2), pS1), pS0);
-  const double qq = fma(t, fma(t, fma(t, fma(t, qS4, qS3), qS2), qS1), 1.0);
-  return fma(x, pp * fast_rcp(qq), x);
 }
 
 // ---- counter-based RNG for the device-side reset: Philox-4x32-10 --------------------------
@@ -391,10 +348,10 @@ struct EnvBlock {
   __device__ static inline double idm_log_ratio(const StepParams &p, double v, double ts) {
     const double v0 = clipd(ts, 0.0, p.speed_limit);
     const double r = fmax(v, 0.0) * fast_rcp(fabs(not_zero(v0)));
-    return r > 0.0 ? log(r) : -__builtin_inf();  // r == 0 -> exp(-inf) = 0 == pow(0, delta)
+    return r > 0.0 ? log_pos(r) : -__builtin_inf();  // r == 0 -> exp(-inf) = 0 == pow(0, delta)
   }
   __device__ static inline double idm_free_from_log(double log_ratio, double delta) {
-    return HWY_COMFORT_ACC_MAX * (1 - exp(delta * log_ratio));
+    return HWY_COMFORT_ACC_MAX * (1 - exp_bounded(delta * log_ratio));
   }
   __device__ static inline double idm_free(const StepParams &p, double v, double ts, double delta) {
     return idm_free_from_log(idm_log_ratio(p, v, ts), delta);
@@ -426,7 +383,7 @@ struct EnvBlock {
     const double a = clipd((-HWY_KP_LATERAL * lat) * inv_v, -1.0, 1.0);
     // clip(asin(a), +-pi/4): asin is only evaluated when it is not going to be clipped
     const double s45 = 0.7071067811865476;  // sin(pi/4) rounded up: |a| >= s45 => |asin a| >= pi/4 (clipped)
-    const double heading_ref = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin_small(a), -HWY_PI / 4, HWY_PI / 4));
+    const double heading_ref = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin_bounded(a), -HWY_PI / 4, HWY_PI / 4));
     const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
     const double w = clipd((HWY_VEH_LENGTH / 2 * inv_v) * heading_rate_command, -1.0, 1.0);
     const double tan_max = 1.7320508075688767;  // tan(MAX_STEERING_ANGLE = fl(pi/3)) in f64
@@ -550,7 +507,7 @@ __device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Sha
   } else {
     o.sidx = 0;
     o.ts = speed;
-    o.timer = fmod((o.x + o.y) * HWY_PI, HWY_LC_DELAY);  // operands positive: % == fmod
+    o.timer = py_mod_pos((o.x + o.y) * HWY_PI, HWY_LC_DELAY);
     o.delta = 3.5 + (4.5 - 3.5) * u_delta;
     o.flags = p.rp.fast ? 0 : HWY_F_CHECK_COLLISIONS;
   }
@@ -762,7 +719,7 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
       o.impx = p.st.impact_x[k];
       o.impy = p.st.impact_y[k];
     }
-    sincos(o.h, &o.sh, &o.ch);
+    sincos_bounded(o.h, &o.sh, &o.ch);
   }
 }
 // full = true: spawn / reset (every field); false: end of a step (dynamic fields only)
@@ -1051,7 +1008,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
       me.lane = B::closest_lane(p, me.x, me.y, me.h);  // on_state_update
-      sincos(me.h, &me.sh, &me.ch);
+      sincos_bounded(me.h, &me.sh, &me.ch);
     }
 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
@@ -1150,4 +1107,18 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
   store_vehicle<NW>(p, e, me, false);
 }
 
+// ---- self-test kernel for hwy_math.h (hwy_debug_math) ------------------------------------------------
+__device__ inline double math_probe(int op, double x) {
+  double s, c;
+  switch (op) {
+    case 0: return log_pos(x);
+    case 1: return exp_bounded(x);
+    case 2: sincos_bounded(x, &s, &c); return s;
+    case 3: sincos_bounded(x, &s, &c); return c;
+    case 4: return asin_bounded(x);
+    case 5: return fast_rcp(x);
+    case 6: return fast_rsqrt(x);
+    default: return wrap_to_pi(x);
+  }
+}
 }  // namespace hwy

@@ -511,6 +511,23 @@ extern "C" int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base
   return HWY_OK;
 }
 
+extern "C" int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n) {
+  if (!eng || !in || !out || n < 0 || op < 0 || op > 7) return HWY_ERR_INVALID_ARG;
+  if (n == 0) return HWY_OK;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  double *d_in = nullptr, *d_out = nullptr;
+  HWY_HIP(eng, hipMalloc((void **)&d_in, n * sizeof(double)));
+  if (hipMalloc((void **)&d_out, n * sizeof(double)) != hipSuccess) { (void)hipFree(d_in); return fail(eng, HWY_ERR_HIP, "hipMalloc"); }
+  hipError_t e = hipMemcpyAsync(d_in, in, n * sizeof(double), hipMemcpyHostToDevice, eng->stream);
+  if (e == hipSuccess) e = hwy::launch_math_probe(op, d_in, d_out, (long long)n, eng->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, eng->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(eng, HWY_ERR_HIP, std::string("hwy_debug_math: ") + hipGetErrorString(e));
+  return HWY_OK;
+}
+
 extern "C" int hwy_sync(hwy_engine *eng) {
   if (!eng) return HWY_ERR_INVALID_ARG;
   HWY_HIP(eng, hipSetDevice(eng->device));

@@ -54,6 +54,14 @@ hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, in
     default: return launch_step_wpe<4>(p, num_envs, stream);
   }
 }
+__global__ void hwy_math_probe_kernel(int op, const double *in, double *out, long long n) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) out[k] = math_probe(op, in[k]);
+}
+hipError_t launch_math_probe(int op, const double *in, double *out, long long n, hipStream_t stream) {
+  hipLaunchKernelGGL(hwy_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, in, out, n);
+  return hipGetLastError();
+}
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_reset_kernel) }
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_observe_kernel) }
 

@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
       me.lane = B::closest_lane(p, me.x, me.y, me.h);
-      sincos(me.h, &me.sh, &me.ch);
+      sincos_bounded(me.h, &me.sh, &me.ch);
     }
 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------

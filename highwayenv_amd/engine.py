@@ -111,6 +111,13 @@ class Engine:
         self._check(self._lib.hwy_set_autoreset(self._h, int(bool(enabled)), C.c_uint64(base_seed), float(ego_spacing),
                                                 float(vehicles_density), int(initial_lane_id)))
 
+    def debug_math(self, op: int, x) -> np.ndarray:
+        """Evaluate one of the kernel's math routines (csrc/hwy_math.h) on the device (self-test hook)."""
+        xin = np.ascontiguousarray(x, np.float64).ravel()
+        out = np.empty_like(xin)
+        self._check(self._lib.hwy_debug_math(self._h, int(op), _ptr(xin), _ptr(out), xin.size))
+        return out.reshape(np.shape(x))
+
     # -- misc ---------------------------------------------------------------------------------
     def sync(self):
         self._check(self._lib.hwy_sync(self._h))

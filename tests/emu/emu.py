@@ -24,6 +24,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, "emu_engine.cpp"), os.path.join(_HERE, "hip_emu.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_math.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_params.h"),
             os.path.join(_ROOT, "include", "hwy_engine.h")]
     stale = not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs)
@@ -100,6 +101,12 @@ class EmuEngine:
 
     def observe(self):
         return self._run(2, 0, None)[0]
+
+    def debug_math(self, op, x):
+        xin = np.ascontiguousarray(x, np.float64).ravel()
+        out = np.empty_like(xin)
+        lib().emu_debug_math(C.c_int(op), _p(xin, C.c_double), _p(out, C.c_double), C.c_longlong(xin.size))
+        return out.reshape(np.shape(x))
 
     def reset(self, seeds=None, mask=None, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1, base_seed=0):
         E, A = self.E, self.A

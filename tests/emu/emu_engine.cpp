@@ -153,6 +153,10 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
 
 void emu_force_block_kernel(int on) { g_force_block = on != 0; }
 
+void emu_debug_math(int op, const double *in, double *out, long long n) {
+  for (long long k = 0; k < n; ++k) out[k] = hwy::math_probe(op, in[k]);
+}
+
 // host-side Philox, for tests of the device spawn rule
 void emu_philox_uniform2(uint64_t seed, uint32_t vehicle, uint32_t episode, uint32_t draw, double *u0, double *u1) {
   hwy::philox_uniform2(seed, vehicle, episode, draw, u0, u1);

@@ -1,0 +1,65 @@
+"""Accuracy of the step kernel's own math routines (highwayenv_amd/csrc/hwy_math.h) on their stated
+domains, against numpy, in ulps.  `emu` runs the same source on the CPU (seed = exact 1/x there);
+`hip` runs it on the MI355X through hwy_debug_math (real v_rcp_f64 / v_rsq_f64 seeds)."""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi
+from tests.backends import BACKENDS, make_engine
+
+LOG, EXP, SIN, COS, ASIN, RCP, RSQRT, WRAP = range(8)
+
+
+def ulps(got, want):
+    want = np.asarray(want, np.float64)
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+@pytest.fixture(params=BACKENDS)
+def eng(request):
+    e = make_engine(request.param, _abi.make_config(_abi.highway_fast_default_config(), 1, fast=True))
+    yield e
+    e.close()
+
+
+def test_log_exp(eng):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(1e-3, 2.5, 200000), 10.0 ** rng.uniform(-60, 2, 50000), [1.0, 0.5, 2.0, 0.7071067811865476]])
+    assert ulps(eng.debug_math(LOG, x), np.log(x)).max() <= 2.0
+    y = np.concatenate([rng.uniform(-5, 4, 200000), rng.uniform(-690, 40, 50000), [0.0, -0.0, 1.0]])
+    assert ulps(eng.debug_math(EXP, y), np.exp(y)).max() <= 2.0
+    assert (eng.debug_math(EXP, np.array([-701.0, -1e9, -np.inf])) == 0).all()
+    # the composite the kernel uses: (v/v0)^delta = exp(delta*log r)
+    r, d = rng.uniform(0.05, 1.8, 100000), rng.uniform(3.5, 4.5, 100000)
+    got = eng.debug_math(EXP, d * eng.debug_math(LOG, r))
+    assert (np.abs(got - np.power(r, d)) / np.power(r, d)).max() < 2e-15
+
+
+def test_sincos(eng):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-1.6, 1.6, 200000), rng.uniform(-50, 50, 100000), rng.uniform(-1e5, 1e5, 20000),
+                        [0.0, -0.0, np.pi / 4, -np.pi / 2, np.pi]])
+    s, c = eng.debug_math(SIN, x), eng.debug_math(COS, x)
+    # absolute error bounded by ~1 ulp of 1 (relative ulps blow up at the zeros of sin/cos for any libm)
+    assert np.abs(s - np.sin(x)).max() < 2.5e-16 * (1 + np.abs(x).max() * 1e-6)
+    assert np.abs(c - np.cos(x)).max() < 2.5e-16 * (1 + np.abs(x).max() * 1e-6)
+    small = np.abs(x) < 0.78
+    assert ulps(s[small], np.sin(x[small]))[x[small] != 0].max() <= 2.0
+    assert ulps(c[small], np.cos(x[small])).max() <= 2.0
+    assert np.abs(s * s + c * c - 1).max() < 5e-16
+
+
+def test_asin_rcp_rsqrt_wrap(eng):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-0.5, 0.5, 200000), rng.uniform(-1, 1, 100000), [0.0, 0.5, -0.5, 0.7071067811865476, 1.0, -1.0]])
+    u = ulps(eng.debug_math(ASIN, x), np.arcsin(x))
+    assert u[np.abs(x) <= 0.5][x[np.abs(x) <= 0.5] != 0].max() <= 2.0 and u[x != 0].max() <= 4.0
+    v = np.concatenate([rng.uniform(0.01, 50, 100000), -rng.uniform(0.01, 50, 100000), 10.0 ** rng.uniform(-8, 8, 50000)])
+    assert ulps(eng.debug_math(RCP, v), 1.0 / v).max() <= 1.5
+    w = np.concatenate([rng.uniform(1e-12, 4, 100000), 10.0 ** rng.uniform(-20, 20, 50000)])
+    assert ulps(eng.debug_math(RSQRT, w), 1.0 / np.sqrt(w)).max() <= 2.0
+    a = np.concatenate([rng.uniform(-10, 10, 100000), rng.uniform(-1e4, 1e4, 20000), [np.pi, -np.pi, 0.0, 3 * np.pi]])
+    ref = ((a + np.pi) % (2 * np.pi)) - np.pi  # utils.wrap_to_pi
+    assert np.abs(eng.debug_math(WRAP, a) - ref).max() < 4e-12  # |a| up to 1e4: one ulp of a + pi
+    inside = np.abs(a) < 3
+    assert (eng.debug_math(WRAP, a[inside]) == ref[inside]).all()  # no reduction needed: bit-identical
