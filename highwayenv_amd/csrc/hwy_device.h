@@ -174,6 +174,10 @@ __device__ inline int msb64(u64 m) { return 63 - __clzll((long long)m); }      /
 struct Body {
   double x, y, v, c, s;  // position, speed, cos/sin heading
 };
+// field-wise select (keeps both bodies in registers; a reference to one of two structs would force them to memory)
+__device__ inline Body select_body(bool first, const Body &p, const Body &q) {
+  return Body{first ? p.x : q.x, first ? p.y : q.y, first ? p.v : q.v, first ? p.c : q.c, first ? p.s : q.s};
+}
 
 // ---- provable non-collision, without running the SAT ---------------------------------------------
 // For a unit axis n, the projection of a rectangle is (centre . n) -+ r with
@@ -203,71 +207,58 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 // ---- rectangle SAT with swept extension (utils.py:196-241, objects.py:122-138,169-181) -----------
 // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
 // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
+//
+// The reference projects the 4+4 corners on the 8 edge normals.  The normals of a rectangle are +-its
+// two body axes (in the order -u, +w, +u, -w for the corner order of objects.py:169-181), a projection
+// interval is (centre . n) -+ (L/2 |u.n| + W/2 |w.n|), and everything the test computes is symmetric under
+// n -> -n, so four axes (u_a, w_a, u_b, w_b, in that order: the first minimum wins) give the same
+// flags and the same translation as the eight -- in ~100 flops and a dozen registers instead of a
+// 16-double corner table.  Differences to the literal corner arithmetic are at the 1e-16 level.
+struct SatAcc {
+  bool intersecting, will;
+  double min_distance, axx, axy;
+};
+__device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
+                                double vp, double cdx, double cdy) {
+  double min_a = ca_ - ra, max_a = ca_ + ra;
+  const double min_b = cb_ - rb, max_b = cb_ + rb;
+  if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) acc.intersecting = false;
+  if (vp < 0) min_a += vp; else max_a += vp;
+  const double distance = min_a < min_b ? min_b - max_a : min_a - max_b;
+  if (distance > 0) acc.will = false;
+  if (fabs(distance) < acc.min_distance) {
+    acc.min_distance = fabs(distance);
+    const bool pos = cdx * nx + cdy * ny > 0;  // translation_axis = normal if d.dot(normal) > 0 else -normal
+    acc.axx = pos ? nx : -nx;
+    acc.axy = pos ? ny : -ny;
+  }
+}
 __device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
-  const double ax = A.x, ay = A.y, bx = B.x, by = B.y;
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
-  const double dx = bx - ax, dy = by - ay;
+  const double dx = B.x - A.x, dy = B.y - A.y;
   *tx = 0;
   *ty = 0;
+  // fast spherical pre-check, with the LOWER index's speed (objects.py:124-127)
   if (sqrt(dx * dx + dy * dy) > (diagonal + diagonal) / 2 + A.v * dt) return 0;
-  const double ca = A.c, sa = A.s, cb = B.c, sb = B.s;
-  const double lx[4] = {-HWY_VEH_LENGTH / 2, -HWY_VEH_LENGTH / 2, +HWY_VEH_LENGTH / 2, +HWY_VEH_LENGTH / 2};
-  const double ly[4] = {-HWY_VEH_WIDTH / 2, +HWY_VEH_WIDTH / 2, +HWY_VEH_WIDTH / 2, -HWY_VEH_WIDTH / 2};
-  double pa[4][2], pb[4][2];
-  for (int k = 0; k < 4; ++k) {
-    pa[k][0] = (ca * lx[k] + -sa * ly[k]) + ax;
-    pa[k][1] = (sa * lx[k] + ca * ly[k]) + ay;
-    pb[k][0] = (cb * lx[k] + -sb * ly[k]) + bx;
-    pb[k][1] = (sb * lx[k] + cb * ly[k]) + by;
+  const double hl = HWY_VEH_LENGTH / 2, hw = HWY_VEH_WIDTH / 2;
+  // relative displacement over dt, velocity = speed*(cos h, sin h) (objects.py:165-167)
+  const double ddx = A.v * A.c * dt - B.v * B.c * dt, ddy = A.v * A.s * dt - B.v * B.s * dt;
+  const double cdx = A.x - B.x, cdy = A.y - B.y;  // centre difference (mean of the corners)
+  const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);  // |cos|, |sin| of (h_b - h_a)
+  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0};
+  // u_a = (cos h_a, sin h_a)
+  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
+  // w_a = (-sin h_a, cos h_a)
+  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
+  // u_b, w_b
+  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy);
+  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  if (acc.will) {
+    *tx = acc.min_distance * acc.axx;
+    *ty = acc.min_distance * acc.axy;
   }
-  // displacement_a - displacement_b, velocity = speed*(cos h, sin h)  (objects.py:165-167)
-  const double ddx = A.v * ca * dt - B.v * cb * dt;
-  const double ddy = A.v * sa * dt - B.v * sb * dt;
-  // centre difference d = mean(a) - mean(b) (row-order sum / 4)
-  const double cdx = (((pa[0][0] + pa[1][0]) + pa[2][0]) + pa[3][0]) / 4 - (((pb[0][0] + pb[1][0]) + pb[2][0]) + pb[3][0]) / 4;
-  const double cdy = (((pa[0][1] + pa[1][1]) + pa[2][1]) + pa[3][1]) / 4 - (((pb[0][1] + pb[1][1]) + pb[2][1]) + pb[3][1]) / 4;
-  bool intersecting = true, will = true;
-  double min_distance = __builtin_inf(), axx = 0, axy = 0;
-  for (int pi = 0; pi < 2; ++pi) {
-    for (int k = 0; k < 4; ++k) {
-      const int k2 = (k + 1) & 3;
-      const double p1x = pi ? pb[k][0] : pa[k][0], p1y = pi ? pb[k][1] : pa[k][1];
-      const double p2x = pi ? pb[k2][0] : pa[k2][0], p2y = pi ? pb[k2][1] : pa[k2][1];
-      double nx = -p2y + p1y, ny = p2x - p1x;
-      const double nn = sqrt(nx * nx + ny * ny);
-      nx /= nn;
-      ny /= nn;
-      // project_polygon over the closed 5-point polygons == over the 4 corners
-      double min_a = pa[0][0] * nx + pa[0][1] * ny, max_a = min_a;
-      double min_b = pb[0][0] * nx + pb[0][1] * ny, max_b = min_b;
-      for (int q = 1; q < 4; ++q) {
-        const double qa = pa[q][0] * nx + pa[q][1] * ny, qb = pb[q][0] * nx + pb[q][1] * ny;
-        min_a = qa < min_a ? qa : min_a;
-        max_a = qa > max_a ? qa : max_a;
-        min_b = qb < min_b ? qb : min_b;
-        max_b = qb > max_b ? qb : max_b;
-      }
-      if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) intersecting = false;
-      const double vp = nx * ddx + ny * ddy;
-      if (vp < 0) min_a += vp; else max_a += vp;
-      const double distance = min_a < min_b ? min_b - max_a : min_a - max_b;
-      if (distance > 0) will = false;
-      if (!intersecting && !will) break;  // leaves the edge loop of this polygon only
-      if (fabs(distance) < min_distance) {
-        min_distance = fabs(distance);
-        const bool pos = cdx * nx + cdy * ny > 0;
-        axx = pos ? nx : -nx;
-        axy = pos ? ny : -ny;
-      }
-    }
-  }
-  if (will) {
-    *tx = min_distance * axx;
-    *ty = min_distance * axy;
-  }
-  return (intersecting ? 1 : 0) | (will ? 2 : 0);
+  return (acc.intersecting ? 1 : 0) | (acc.will ? 2 : 0);
 }
-
 
 // =============================================================================================
 template <int NW>

@@ -76,7 +76,9 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
     const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
     const double dxe = me.x - ex, dye = me.y - ey;
     const double d_lane = me.x - ex;
-    const bool elig = active && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
+    // norm < distance  <=>  dx^2 + dy^2 < distance^2 when distance^2 is exact (200^2 is): sqrt is monotone and
+    // correctly rounded, so the compare can be done on the squares
+    const bool elig = active && i != ia && (dxe * dxe + dye * dye < p.perception * p.perception) &&
                       ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
     const double key = elig ? fabs(d_lane) : __builtin_inf();
     const int n_elig = __popcll(__ballot(elig));
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
         const Body other{qx, qy, qv, wave_bcast(me.ch, q), wave_bcast(me.sh, q)};
         if (near) {
           const bool i_first = i < q;
-          const Body &A = i_first ? mine : other, &Bb = i_first ? other : mine;
+          const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
           if (!surely_apart(A, Bb, p.dt)) {
             double tx, ty;
             const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
           const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
           if (dx * dx + dy * dy <= lim * lim) {
             const bool i_first = i < c;
-            const Body &A = i_first ? mine : other, &Bb = i_first ? other : mine;
+            const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
             if (!surely_apart(A, Bb, p.dt)) {
               r = pair_collide(A, Bb, p.dt, &tx, &ty);
               if (!i_check) {  // my only partners are the checkers (ascending c == loop order)

@@ -27,8 +27,8 @@ def wave_variants(dev, wav):
     v["wnocollide"] = (dev, cut(wav, "    const Body mine{me.x, me.y, me.v, me.ch, me.sh};", "  }  // frames", ""))
     v["wnorank"] = (dev, wav.replace("    bool recount = (fr == 0);", "    bool recount = false;"))
     v["wnomobil"] = (dev, wav.replace("    if (decide) {\n      me.timer = 0.0;", "    if (false) {\n      me.timer = 0.0;"))
-    v["wnopow"] = (dev.replace("const double rp = r > 0.0 ? exp(delta * log(r)) : 0.0;", "const double rp = r * delta;"), wav)
-    v["wnosincos"] = (dev, wav.replace("      sincos(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))
+    v["wnopow"] = (dev.replace("return r > 0.0 ? log_pos(r) : -__builtin_inf();", "return r;").replace("(1 - exp_bounded(delta * log_ratio))", "(1 - delta * log_ratio)"), wav)
+    v["wnosincos"] = (dev, wav.replace("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))
     v["wnosteer"] = (dev, wav.replace("      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "      tb = inv_v * 1e-9;"))
     v["wnoobs"] = (dev, wav.replace("  if (p.full_step) observe_wave(p, e, me, true);", ""))
     # cycle-stamped variant
@@ -106,7 +106,7 @@ def build(name, text):
         text, wave_text = text
     d = os.path.join(OUT, name)
     os.makedirs(d, exist_ok=True)
-    for f in ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h"):
+    for f in ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_math.h"):
         shutil.copy(os.path.join(CSRC, f), d)
     if wave_text is not None:
         open(os.path.join(d, "hwy_wave.h"), "w").write(wave_text)
