@@ -75,10 +75,17 @@ typedef unsigned long long u64;
 #define HWY_LC_MAX_BRAKING 2.0
 #define HWY_LC_DELAY 1.0
 
-// packed per-vehicle word: lane | target_lane<<8 | speed_index<<16 | flags<<24
-__host__ __device__ inline int32_t pack_word(int lane, int tgt, int sidx, int flags) {
-  return (lane & 0xff) | ((tgt & 0xff) << 8) | ((sidx & 0xff) << 16) | ((flags & 0xff) << 24);
+// packed per-vehicle word: lane[0:3] | target_lane[4:7] | speed_index[8:11] | flags[12:15] | rank[16:23]
+// rank = position along the road (a HINT carried from step to step: the one-wavefront kernel verifies it
+// every frame and recounts when it is stale; hwy_set_state / spawn write the identity permutation)
+__host__ __device__ inline int32_t pack_word(int lane, int tgt, int sidx, int flags, int rank) {
+  return (lane & 0xf) | ((tgt & 0xf) << 4) | ((sidx & 0xf) << 8) | ((flags & 0xf) << 12) | ((rank & 0xff) << 16);
 }
+__host__ __device__ inline int word_lane(int32_t w) { return w & 0xf; }
+__host__ __device__ inline int word_target(int32_t w) { return (w >> 4) & 0xf; }
+__host__ __device__ inline int word_speed_index(int32_t w) { return (w >> 8) & 0xf; }
+__host__ __device__ inline int word_flags(int32_t w) { return (w >> 12) & 0xf; }
+__host__ __device__ inline int word_rank(int32_t w) { return (w >> 16) & 0xff; }
 
 struct DevState {
   double *x, *y, *heading, *speed, *timer, *target_speed, *delta, *impact_x, *impact_y;  // [E][pitch]
@@ -444,7 +451,7 @@ struct EnvBlock {
 // Per-thread vehicle registers
 struct Veh {
   double x, y, h, v, timer, ts, delta, impx, impy, ch, sh;
-  int lane, tgt, sidx, flags;
+  int lane, tgt, sidx, flags, rank;
 };
 
 // ---- device-side spawn: HighwayEnv._create_vehicles (envs/highway_env.py:72-98) with
@@ -484,6 +491,7 @@ __device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Sha
   o.v = speed;
   o.lane = lane;
   o.tgt = lane;
+  o.rank = i & 0xff;  // x increases with the creation index: the identity is the sorted order
   o.impx = o.impy = 0.0;
   o.ch = 1.0;
   o.sh = 0.0;
@@ -705,7 +713,8 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
     o.x = p.st.x[k]; o.y = p.st.y[k]; o.h = p.st.heading[k]; o.v = p.st.speed[k];
     o.timer = p.st.timer[k]; o.ts = p.st.target_speed[k]; o.delta = p.st.delta[k];
     const int w = p.st.packed[k];
-    o.lane = w & 0xff; o.tgt = (w >> 8) & 0xff; o.sidx = (w >> 16) & 0xff; o.flags = (w >> 24) & 0xff;
+    o.lane = word_lane(w); o.tgt = word_target(w); o.sidx = word_speed_index(w); o.flags = word_flags(w);
+    o.rank = word_rank(w);
     if (o.flags & HWY_F_HAS_IMPACT) {
       o.impx = p.st.impact_x[k];
       o.impy = p.st.impact_y[k];
@@ -720,7 +729,7 @@ __device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, b
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
     p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
-    p.st.packed[k] = pack_word(o.lane, o.tgt, o.sidx, o.flags);
+    p.st.packed[k] = pack_word(o.lane, o.tgt, o.sidx, o.flags, o.rank);
     if (full || !(o.flags & HWY_F_CONTROLLED)) p.st.timer[k] = o.timer;
     if (full || (o.flags & HWY_F_CONTROLLED)) p.st.target_speed[k] = o.ts;
     if (full) p.st.delta[k] = o.delta;

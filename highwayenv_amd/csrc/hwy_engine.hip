@@ -27,7 +27,7 @@ struct hwy_engine {
   bool own_stream = false;
   int pitch = 0;
   bool force_block_kernel = false;  // HWY_STEP_KERNEL=block: use the generic workgroup kernel even for N <= 64
-  int waves_per_eu = 2;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
+  int waves_per_eu = 3;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -266,7 +266,7 @@ extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
   for (int e = 0; e < E; ++e)
     for (int i = 0; i < P; ++i) {
       const size_t k = (size_t)e * N + i;
-      pk[(size_t)e * P + i] = i < N ? hwy::pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k]) : 0;
+      pk[(size_t)e * P + i] = i < N ? hwy::pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k], i) : 0;
     }
   double *tm = (double *)(pk + plane);
   std::memcpy(tm, h->time, sizeof(double) * E);
@@ -296,12 +296,12 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
     for (int i = 0; i < N; ++i) {
       const int32_t w = pk[(size_t)e * P + i];
       const size_t k = (size_t)e * N + i;
-      if (h->lane) h->lane[k] = w & 0xff;
-      if (h->target_lane) h->target_lane[k] = (w >> 8) & 0xff;
-      if (h->speed_index) h->speed_index[k] = (w >> 16) & 0xff;
-      if (h->flags) h->flags[k] = (w >> 24) & 0xff;
+      if (h->lane) h->lane[k] = hwy::word_lane(w);
+      if (h->target_lane) h->target_lane[k] = hwy::word_target(w);
+      if (h->speed_index) h->speed_index[k] = hwy::word_speed_index(w);
+      if (h->flags) h->flags[k] = hwy::word_flags(w);
       // the impact pair is only maintained while the flag is set (Vehicle.impact is None otherwise)
-      if (!(((w >> 24) & 0xff) & HWY_F_HAS_IMPACT)) {
+      if (!(hwy::word_flags(w) & HWY_F_HAS_IMPACT)) {
         if (h->impact_x) h->impact_x[k] = 0.0;
         if (h->impact_y) h->impact_y[k] = 0.0;
       }

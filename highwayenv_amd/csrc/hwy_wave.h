@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   const u64 chk = __ballot(active && i_check);
   const bool all_check = __popcll(chk) == N;
 
-  int rank = i;          // position along the road, carried from frame to frame
+  // position along the road, carried from frame to frame AND from step to step (hint in the packed word;
+  // idle lanes keep their own slot so that the permutation stays a bijection)
+  int rank = active ? me.rank : i;
   bool has_tie = false;  // two vehicles share the same x (=> literal neighbour scans)
   for (int fr = 0; fr < p.n_frames; ++fr) {
     // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315) ------------------------------
@@ -220,8 +222,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     // sends its x to lane `rank` and to lane `rank-1` (ds_permute); lane r then holds x of rank r and
     // of rank r+1 and checks x[r] < x[r+1].  Only if some pair is out of order (or equal) does the
     // wave fall back to the exact counting pass.
-    bool recount = (fr == 0);
-    if (!recount) {
+    bool recount = false;
+    {
       const int lo = __double2loint(me.x), hi = __double2hiint(me.x);
       const double x_r = __hiloint2double(wave_send_i(hi, rank), wave_send_i(lo, rank));
       const double x_r1 = __hiloint2double(wave_send_i(hi, rank - 1), wave_send_i(lo, rank - 1));
@@ -494,6 +496,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
 
   // ---- H. observe / reward / done ---------------------------------------------------------------------------
   if (p.full_step) observe_wave(p, e, me, true);
+  me.rank = rank;
   store_vehicle<1>(p, e, me, false);
 }
 

@@ -40,7 +40,7 @@ struct HostImage {
     packed.resize(plane);
     const double *fields[9] = {h.x, h.y, h.heading, h.speed, h.timer, h.target_speed, h.delta, h.impact_x, h.impact_y};
     for (int f = 0; f < 9; ++f) std::memcpy(&f64[f * plane], fields[f], plane * sizeof(double));
-    for (size_t k = 0; k < plane; ++k) packed[k] = hwy::pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k]);
+    for (size_t k = 0; k < plane; ++k) packed[k] = hwy::pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k], (int)(k % N));
   }
   void store(hwy_state &h) const {
     const size_t plane = (size_t)E * N;
@@ -48,7 +48,7 @@ struct HostImage {
     for (int f = 0; f < 9; ++f) std::memcpy(fields[f], &f64[f * plane], plane * sizeof(double));
     for (size_t k = 0; k < plane; ++k) {
       const int32_t w = packed[k];
-      h.lane[k] = w & 0xff; h.target_lane[k] = (w >> 8) & 0xff; h.speed_index[k] = (w >> 16) & 0xff; h.flags[k] = (w >> 24) & 0xff;
+      h.lane[k] = hwy::word_lane(w); h.target_lane[k] = hwy::word_target(w); h.speed_index[k] = hwy::word_speed_index(w); h.flags[k] = hwy::word_flags(w);
       if (!(h.flags[k] & HWY_F_HAS_IMPACT)) h.impact_x[k] = h.impact_y[k] = 0.0;  // as hwy_get_state does
     }
   }

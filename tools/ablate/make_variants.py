@@ -26,7 +26,7 @@ def wave_variants(dev, wav):
     v["winline"] = (dev.replace("__device__ __attribute__((noinline)) inline int pair_collide", "__device__ inline int pair_collide"), wav)
     v["wnocollide"] = (dev, cut(wav, "    const Body mine{me.x, me.y, me.v, me.ch, me.sh};", "  }  // frames", ""))
     v["wnorank"] = (dev, wav.replace("    bool recount = (fr == 0);", "    bool recount = false;"))
-    v["wnomobil"] = (dev, wav.replace("    if (decide) {\n      me.timer = 0.0;", "    if (false) {\n      me.timer = 0.0;"))
+    v["wnomobil"] = (dev, wav.replace("    const bool cl = decide && left_ok", "    const bool cl = false && left_ok").replace("    const bool cr = decide && right_ok", "    const bool cr = false && right_ok"))
     v["wnopow"] = (dev.replace("return r > 0.0 ? log_pos(r) : -__builtin_inf();", "return r;").replace("(1 - exp_bounded(delta * log_ratio))", "(1 - delta * log_ratio)"), wav)
     v["wnosincos"] = (dev, wav.replace("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))
     v["wnosteer"] = (dev, wav.replace("      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "      tb = inv_v * 1e-9;"))
@@ -41,8 +41,8 @@ def wave_variants(dev, wav):
              ("    // ---- C. rank along the road ---", 1),
              ("    // lane membership (AbstractLane.on_lane, margin 1) -> bits", 2),
              ("    // ---- D. Road.act: lane-change policy (behavior.py:219-263)", 3),
-             ("    double free_self = 0.0, gap_own = 0.0;", 4),
-             ("    if (decide) {\n      me.timer = 0.0;", 5),
+             ("    const double free_self = B::idm_free_from_log(log_ratio, me.delta);", 4),
+             ("    const double self_a = free_self - gap_own;", 5),
              ("    // abort rule for ongoing lane changes: ordered chain", 6),
              ("    // ---- E. Road.act: low-level control", 7),
              ("    // ---- F. Road.step: integrate", 8),
@@ -51,9 +51,12 @@ def wave_variants(dev, wav):
     for text, k in marks:
         assert text in t, text
         t = t.replace(text, f"    TICK({k})\n" + text)
-    t = t.replace("  if (p.full_step) observe_wave(p, e, me, true);\n  store_vehicle<1>(p, e, me);\n}",
-                  "  if (p.full_step) observe_wave(p, e, me, true);\n  TICK(11)\n  store_vehicle<1>(p, e, me);\n"
+    tail = "  if (p.full_step) observe_wave(p, e, me, true);\n  store_vehicle<1>(p, e, me, false);\n}"
+    assert tail in t
+    t = t.replace(tail,
+                  "  if (p.full_step) observe_wave(p, e, me, true);\n  TICK(11)\n  store_vehicle<1>(p, e, me, false);\n"
                   "  if (i == 0 && p.obs) for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}")
+    assert "    if (recount) {  // wave-uniform\n" in t
     t = t.replace("    if (recount) {  // wave-uniform\n", "    if (recount) {  n_recount += 1.0f;\n")
     t = t.replace("  long long t_prev = clock64();", "  float n_recount = 0.0f; long long t_prev = clock64();")
     t = t.replace("p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}", "p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n  if (i == 0 && p.obs) p.obs[(size_t)e * p.A * p.V * p.F + 12] = n_recount;\n}")
