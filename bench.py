@@ -39,14 +39,14 @@ def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int) -> int:
     return 72 * n_vehicles + 110 * agents
 
 
-def measured_traffic(envs_per_gpu: int):
+def measured_traffic(envs_per_gpu: int, fast: bool = True):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
     tools/traffic_report.py -> profiles/traffic_r01.json).  PMC counters cannot be read from inside this
     process, so the number is the one measured for the same kernel and config; None if absent or if the
     run uses another batch size."""
     path = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU:
+    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU or not fast:
         return None
     try:
         return json.load(open(path))["traffic_bytes_per_launch_calibrated"]
@@ -54,13 +54,13 @@ def measured_traffic(envs_per_gpu: int):
         return None
 
 
-def cpu_baseline(cfg_dict, budget_s: float = 12.0):
+def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
     from highwayenv_amd import _abi, spawn
     from oracle import oracle
-    E = 64
-    cfg = _abi.make_config(cfg_dict, E, fast=True)
+    E = 64 if fast else 8
+    cfg = _abi.make_config(cfg_dict, E, fast=fast)
     st0 = spawn.spawn_reference_stream(cfg, np.arange(E) + 7, cfg_dict["ego_spacing"], cfg_dict["vehicles_density"])
     rng = np.random.default_rng(3)
     steps_done, t_used = 0, 0.0
@@ -88,6 +88,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["fast", "v0_n100"], default="fast",
+                    help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
+                         "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024)")
     args = ap.parse_args()
 
     import torch
@@ -111,10 +114,15 @@ def main() -> None:
     from highwayenv_amd.engine import Engine
     from highwayenv_amd.dist import PackedStepOutputs
 
-    cfg_dict = _abi.highway_fast_default_config()
-    cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
+    fast = args.workload == "fast"
+    if fast:
+        cfg_dict = _abi.highway_fast_default_config()
+        cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
+    else:
+        cfg_dict = _abi.highway_default_config()
+        cfg_dict.update({"vehicles_count": 100})
     E = args.envs_per_gpu
-    cfg = _abi.make_config(cfg_dict, E, fast=True)
+    cfg = _abi.make_config(cfg_dict, E, fast=fast)
     N, A = cfg.num_vehicles, cfg.num_agents
 
     stream = torch.cuda.current_stream(dev)
@@ -190,21 +198,24 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
-                                   f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
-                                   "device spawn + auto-reset",
+            "config": {"workload": (f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
+                                    f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
+                                    "device spawn + auto-reset") if fast else
+                                   (f"highway-v0, {E} envs/GPU x 100 IDM vehicles (+1 ego, N={N}), 4 lanes, 15 frames/step, full "
+                                    "pairwise collisions, random actions, Kinematics 5x5 obs, device spawn + auto-reset"),
                        "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}"},
             "vehicle_steps_per_s": value * N,
-            "vehicle_steps_per_s_excl_ego": value * VEHICLES_COUNT,
+            "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E),
-                         "kernel": "hwy_step_wave_kernel<2>  (one 64-wide wavefront per env)", "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E, fast),
+                         "kernel": ("hwy_step_wave_kernel<3>  (one 64-wide wavefront per env)" if N <= 64 else
+                                    f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": b_env * E},
             "terminated_in_last_step": int(term),
             "host_path_env_steps_per_s": host_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg_dict)
+            line["cpu_baseline"] = cpu_baseline(cfg_dict, fast)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

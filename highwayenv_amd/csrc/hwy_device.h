@@ -457,9 +457,9 @@ struct Veh {
 // ---- device-side spawn: HighwayEnv._create_vehicles (envs/highway_env.py:72-98) with
 //      Vehicle.create_random's rule (vehicle/kinematics.py:50-104), IDMVehicle ctor timer
 //      (behavior.py:64), randomize_behavior (behavior.py:66-69), MDPVehicle ladder snap
-//      (controller.py:287-293).  Thread i == vehicle i.  Needs sh.aux0 as scratch.
+//      (controller.py:287-293).  Thread i == vehicle i.  Needs two LDS scratch arrays (N and 1 doubles).
 template <int NW>
-__device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Shared &sh, int e, uint64_t seed,
+__device__ inline void spawn_env(const StepParams &p, double *scratch_step, double *scratch_base, int e, uint64_t seed,
                                  uint32_t episode, Veh &o) {
   const int i = threadIdx.x;
   const bool active = i < p.N;
@@ -478,12 +478,12 @@ __device__ inline void spawn_env(const StepParams &p, typename EnvBlock<NW>::Sha
   const double default_spacing = 12 + 1.0 * speed;
   const double offset = spacing * default_spacing * p.rp.lane_factor;
   const double step = offset * (0.9 + (1.1 - 0.9) * u_pos);  // offset * uniform(0.9, 1.1)
-  if (active) sh.aux0[i] = step;
-  if (active && i == 0) sh.aux1[0] = 3 * offset;  // first vehicle starts from 3*offset
+  if (active) scratch_step[i] = step;
+  if (active && i == 0) scratch_base[0] = 3 * offset;  // first vehicle starts from 3*offset
   __syncthreads();
   // x_k = max_x(existing) + step_k == running sum in creation order (steps are positive)
-  double x = sh.aux1[0];
-  for (int k = 0; k <= i && k < p.N; ++k) x += sh.aux0[k];
+  double x = scratch_base[0];
+  for (int k = 0; k <= i && k < p.N; ++k) x += scratch_step[k];
   __syncthreads();
   o.x = x;
   o.y = lane * p.lane_width;
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(NW * 64) hwy_reset_kernel(const StepParams p) 
   const bool active = i < p.N;
   Veh me = Veh{};
   const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
-  spawn_env<NW>(p, sh, e, seed, 0u, me);
+  spawn_env<NW>(p, sh.aux0, sh.aux1, e, seed, 0u, me);
   publish<NW>(sh, me, active);
   __syncthreads();
   observe_env<NW>(p, sh, e, me, false);
@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
   if (p.autoreset && p.st.done[e]) {  // block-uniform
     Veh me = Veh{};
     const uint32_t episode = p.st.episode[e] + 1u;
-    spawn_env<NW>(p, sh, e, p.rp.base_seed + (uint64_t)e, episode, me);
+    spawn_env<NW>(p, sh.aux0, sh.aux1, e, p.rp.base_seed + (uint64_t)e, episode, me);
     publish<NW>(sh, me, active);
     __syncthreads();
     observe_env<NW>(p, sh, e, me, false);

@@ -37,7 +37,9 @@ struct WaveShared {
   // frame snapshot in RANK order (slot r == r-th vehicle along the road)
   double x[64], v[64], c[64], s[64], lr[64];  // lr = log(v/v0), see EnvBlock::idm_log_ratio
   int idx[64];
-  EnvBlock<1>::Shared blk;  // scratch for the (rare) spawn path and shared helpers
+  // per-vehicle state touched once per frame (slot i is private to thread i: no barrier involved).
+  // Keeping it here instead of in registers trims ~10 VGPRs off the frame loop's loop-carried set.
+  double timer[64], ts[64], delta[64], impx[64], impy[64];
 };
 
 // front / rear ranks on a lane from its rank-space membership mask; -1 if none
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   if (p.autoreset && p.st.done[e]) {
     Veh me = Veh{};
     const uint32_t episode = p.st.episode[e] + 1u;
-    spawn_env<1>(p, sh.blk, e, p.rp.base_seed + (uint64_t)e, episode, me);
+    spawn_env<1>(p, sh.x, sh.v, e, p.rp.base_seed + (uint64_t)e, episode, me);
     observe_wave(p, e, me, false);
     store_vehicle<1>(p, e, me);
     if (active && (me.flags & HWY_F_CONTROLLED)) {
@@ -191,6 +193,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   if (controlled)
     for (int a = 0; a < p.A; ++a)
       if (p.agent_index[a] == i) agent = a;
+  sh.timer[i] = me.timer; sh.ts[i] = me.ts; sh.delta[i] = me.delta; sh.impx[i] = me.impx; sh.impy[i] = me.impy;
   const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;
   const u64 chk = __ballot(active && i_check);
   const bool all_check = __popcll(chk) == N;
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
         int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
         idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
         me.sidx = idx;
-        me.ts = p.target_speeds[idx];
+        sh.ts[i] = p.target_speeds[idx];
       } else if (act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) {
         int id = me.tgt + (act == HWY_LANE_RIGHT ? 1 : -1);
         id = id < 0 ? 0 : (id > p.L - 1 ? p.L - 1 : id);
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       m_tgt = (L == me.tgt) ? b : m_tgt;
     }
     // frame-start snapshot, stored in rank order (with each vehicle's IDM log speed ratio)
-    const double log_ratio = active ? B::idm_log_ratio(p, me.v, me.ts) : 0.0;  // egos and wrecks can be followers too
+    const double log_ratio = active ? B::idm_log_ratio(p, me.v, sh.ts[i]) : 0.0;  // egos and wrecks can be followers too
     __syncthreads();  // previous frame's gathers are complete (single wave: an s_barrier no-op + waitcnt)
     if (active) {
       sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
@@ -288,7 +291,10 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     const bool drives = idm && !crashed0;
     const int tgt_old = me.tgt;
     const bool changer = drives && me.lane != me.tgt;
-    const bool decide = drives && me.lane == me.tgt && (HWY_LC_DELAY < me.timer);
+    const double timer = sh.timer[i];
+    const bool decide = drives && me.lane == me.tgt && (HWY_LC_DELAY < timer);
+    // IDMVehicle timer: reset by a decision (behavior.py:248), then += dt in step (behavior.py:147)
+    sh.timer[i] = idm ? (decide ? 0.0 : timer) + p.dt : timer;
     // neighbours: ranks on own / left / right / target lane (bit scans), or the literal scan on ties
     int fo = -1, ro = -1, fl = -1, rl = -1, frt = -1, rrt = -1, ft = -1, rt_ = -1;
     const bool left_ok = me.lane - 1 >= 0, right_ok = me.lane + 1 < p.L;
@@ -327,7 +333,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     // Straight-line (branch-free) evaluation for every lane: a wavefront pays for a branch as soon as one
     // lane takes it, and nearly every frame some vehicle drives / decides, so predication costs nothing
     // extra while giving the scheduler one large block of independent f64 chains to interleave.
-    const double free_self = B::idm_free_from_log(log_ratio, me.delta);
+    const double delta = sh.delta[i];
+    const double free_self = B::idm_free_from_log(log_ratio, delta);
     const double gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
     // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
     // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
@@ -339,7 +346,6 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
     bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
     bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
-    me.timer = decide ? 0.0 : me.timer;
     // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED.
     // Evaluated only for candidates that passed the (pow-free) incentive test, one side per pass (a
     // vehicle that needs both sides checked -- rare -- takes a second pass); the follower's log speed
@@ -350,7 +356,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
         if (pend_l || pend_r) {
           const bool left = pend_l;
           const int rf = left ? rl : rrt;
-          const double a_f = B::idm_free_from_log(sh.lr[rf], me.delta) -
+          const double a_f = B::idm_free_from_log(sh.lr[rf], delta) -
                              B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
           const bool safe = !(a_f < -HWY_LC_MAX_BRAKING);
           if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
@@ -393,11 +399,10 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       accel = (a2 < accel) ? a2 : accel;  // Python min(a, b)
     }
     accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
-    accel = controlled ? HWY_KP_A * (me.ts - me.v) : accel;  // speed_control (controller.py:189-198), not clipped
+    accel = controlled ? HWY_KP_A * (sh.ts[i] - me.v) : accel;  // speed_control (controller.py:189-198), not clipped
 
     // ---- F. Road.step: integrate -------------------------------------------------------------------------
     {
-      me.timer = idm ? me.timer + p.dt : me.timer;
       // clip_actions (kinematics.py:155-168): a crashed vehicle has steering 0 (tan(beta) = 0), accel = -speed
       tb = crashed0 ? 0.0 : tb;
       accel = crashed0 ? -1.0 * me.v : accel;
@@ -408,10 +413,10 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       me.x += vx * p.dt;
       me.y += vy * p.dt;
       if (me.flags & HWY_F_HAS_IMPACT) {
-        me.x += me.impx;
-        me.y += me.impy;
+        me.x += sh.impx[i];
+        me.y += sh.impy[i];
         me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
-        me.impx = me.impy = 0.0;
+        sh.impx[i] = sh.impy[i] = 0.0;
       }
       me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
@@ -440,8 +445,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
             double tx, ty;
             const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
             if (r & 2) {
-              me.impx = i_first ? tx / 2 : -tx / 2;
-              me.impy = i_first ? ty / 2 : -ty / 2;
+              sh.impx[i] = i_first ? tx / 2 : -tx / 2;
+              sh.impy[i] = i_first ? ty / 2 : -ty / 2;
               me.flags |= HWY_F_HAS_IMPACT;
             }
             if (r & 1) me.flags |= HWY_F_CRASHED;
@@ -468,8 +473,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
               r = pair_collide(A, Bb, p.dt, &tx, &ty);
               if (!i_check) {  // my only partners are the checkers (ascending c == loop order)
                 if (r & 2) {
-                  me.impx = i_first ? tx / 2 : -tx / 2;
-                  me.impy = i_first ? ty / 2 : -ty / 2;
+                  sh.impx[i] = i_first ? tx / 2 : -tx / 2;
+                  sh.impy[i] = i_first ? ty / 2 : -ty / 2;
                   me.flags |= HWY_F_HAS_IMPACT;
                 }
                 if (r & 1) me.flags |= HWY_F_CRASHED;
@@ -484,8 +489,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
           if (i == c) {
             if (im) me.flags |= HWY_F_CRASHED;
             if (wm) {
-              me.impx = (c < q) ? qx / 2 : -qx / 2;
-              me.impy = (c < q) ? qy / 2 : -qy / 2;
+              sh.impx[i] = (c < q) ? qx / 2 : -qx / 2;
+              sh.impy[i] = (c < q) ? qy / 2 : -qy / 2;
               me.flags |= HWY_F_HAS_IMPACT;
             }
           }
@@ -497,6 +502,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   // ---- H. observe / reward / done ---------------------------------------------------------------------------
   if (p.full_step) observe_wave(p, e, me, true);
   me.rank = rank;
+  me.timer = sh.timer[i]; me.ts = sh.ts[i]; me.delta = sh.delta[i]; me.impx = sh.impx[i]; me.impy = sh.impy[i];
   store_vehicle<1>(p, e, me, false);
 }
 
