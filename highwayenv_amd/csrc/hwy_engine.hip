@@ -49,7 +49,8 @@ struct hwy_engine {
   int autoreset = 0;
   hwy::ResetParams rp{};
   // profiling
-  int profiling = 0;
+  int profiling = 0;        // 0 = off, k > 0 = HIP events around every k-th step-kernel launch
+  int64_t launch_counter = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
   double prof_ms = 0.0;
@@ -312,7 +313,7 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
 
 // ---- kernel timing ----------------------------------------------------------------------------------
 static int timed_launch(hwy_engine *eng, const StepParams &p) {
-  if (!eng->profiling) {
+  if (!eng->profiling || (eng->launch_counter++ % eng->profiling) != 0) {
     HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel));
     return HWY_OK;
   }
@@ -343,7 +344,8 @@ extern "C" int hwy_profile_enable(hwy_engine *eng, int32_t enabled) {
   if (!eng) return HWY_ERR_INVALID_ARG;
   HWY_HIP(eng, hipSetDevice(eng->device));
   if (int rc = drain_events(eng)) return rc;
-  eng->profiling = enabled ? 1 : 0;
+  eng->profiling = enabled > 0 ? enabled : 0;
+  eng->launch_counter = 0;
   if (enabled) { eng->prof_ms = 0.0; eng->prof_launches = 0; }
   return HWY_OK;
 }

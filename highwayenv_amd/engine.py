@@ -122,8 +122,9 @@ class Engine:
     def sync(self):
         self._check(self._lib.hwy_sync(self._h))
 
-    def profile_enable(self, enabled: bool = True):
-        self._check(self._lib.hwy_profile_enable(self._h, int(bool(enabled))))
+    def profile_enable(self, every: int = 1):
+        """HIP-event timing of every `every`-th step-kernel launch (0 / False = off)."""
+        self._check(self._lib.hwy_profile_enable(self._h, int(every)))
 
     def profile_read(self):
         ms, n = C.c_double(), C.c_int64()

@@ -21,17 +21,17 @@ for n in (0, 1, 2, 5, 10, 20):
     eng.reset(base_seed=5, ego_spacing=1.5, vehicles_density=1.0)
     eng.step_frames(None, n)  # warm-up
     eng.reset(base_seed=5, ego_spacing=1.5, vehicles_density=1.0)
-    eng.profile_enable(True)
+    eng.profile_enable(1)
     reps = 20
     for _ in range(reps):
         eng.step_frames(None, n)
     ms, k = eng.profile_read()
-    eng.profile_enable(False)
+    eng.profile_enable(0)
     out[f"frames_{n}_us"] = ms / k * 1e3
 acts = np.ones((E, 1), np.int32)
 eng.reset(base_seed=5, ego_spacing=1.5, vehicles_density=1.0)
 eng.step(acts)
-eng.profile_enable(True)
+eng.profile_enable(1)
 for _ in range(20):
     eng.step(acts)
 ms, k = eng.profile_read()
