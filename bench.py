@@ -89,7 +89,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fast", "v0_n100"], default="fast",
+    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
                          "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024)")
     args = ap.parse_args()
@@ -121,7 +121,8 @@ def main() -> None:
         cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
     else:
         cfg_dict = _abi.highway_default_config()
-        cfg_dict.update({"vehicles_count": 100})
+        if args.workload == "v0_n100":
+            cfg_dict.update({"vehicles_count": 100})
     E = args.envs_per_gpu
     cfg = _abi.make_config(cfg_dict, E, fast=fast)
     N, A = cfg.num_vehicles, cfg.num_agents
@@ -205,7 +206,7 @@ def main() -> None:
             "config": {"workload": (f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
                                     f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
                                     "device spawn + auto-reset") if fast else
-                                   (f"highway-v0, {E} envs/GPU x 100 IDM vehicles (+1 ego, N={N}), 4 lanes, 15 frames/step, full "
+                                   (f"highway-v0, {E} envs/GPU x {N - A} IDM vehicles (+1 ego, N={N}), 4 lanes, 15 frames/step, full "
                                     "pairwise collisions, random actions, Kinematics 5x5 obs, device spawn + auto-reset"),
                        "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}"},
             "vehicle_steps_per_s": value * N,

@@ -985,6 +985,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     }
 
     // ---- F. Road.step: integrate (behavior.py:139-148, kinematics.py:130-177) --------------------------
+    const double x_old = me.x;
     if (active) {
       if (idm) me.timer += p.dt;
       if (crashed0) {  // clip_actions: steering = 0 => tan(beta) = 0
@@ -1014,28 +1015,35 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
     __syncthreads();  // all reads of the frame-start snapshot are done
     publish<NW>(sh, me, active);
+    if (active) sh.aux0[i] = x_old;
     __syncthreads();
     if (all_check) {
-      // full pairwise: every thread walks its partners in index order; the partner with the highest
-      // index is the last writer of `impact` in the reference's (i, j>i) loop order.
+      // Full pairwise (highway-v0): outward scan in rank order from my own rank, bounded by the frame-start
+      // distance (collision radius + the most two vehicles can move relative to each other in one frame);
+      // the partner with the highest index is the last writer of `impact` in the reference's (i, j>i) loop.
+      // sh.x/y/v/c/s now hold the post-integration bodies by index, sh.aux0 the frame-start x by index.
       if (active) {
-        for (int q = 0; q < N; ++q) {
-          if (q == i) continue;
-          // conservative reject (never skips a pair the exact pre-check of objects.py:124-127 would keep):
-          // exact radius is sqrt(29) + speed_a*dt <= 5.5 + max|speed|*dt
-          const double dx = sh.x[q] - me.x, dy = sh.y[q] - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[q])) * p.dt;
-          if (dx * dx + dy * dy > lim * lim) continue;
-          const int a = i < q ? i : q, b = i < q ? q : i;
-          if (B::surely_apart(sh, a, b, p.dt)) continue;
-          double tx, ty;
-          const int r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
-          if (r & 2) {
-            me.impx = (i == a) ? tx / 2 : -tx / 2;
-            me.impy = (i == a) ? ty / 2 : -ty / 2;
-            me.flags |= HWY_F_HAS_IMPACT;
+        const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+        int best = -1;
+        for (int dir = -1; dir <= 1; dir += 2) {
+          for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {
+            const int q = sh.perm[r2];
+            if (fabs(sh.aux0[q] - x_old) > reach) break;
+            const double dx = sh.x[q] - me.x, dy = sh.y[q] - me.y;
+            const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[q])) * p.dt;
+            if (dx * dx + dy * dy > lim * lim) continue;
+            const int a = i < q ? i : q, b = i < q ? q : i;
+            if (B::surely_apart(sh, a, b, p.dt)) continue;
+            double tx, ty;
+            const int r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
+            if ((r & 2) && q > best) {
+              best = q;
+              me.impx = (i == a) ? tx / 2 : -tx / 2;
+              me.impy = (i == a) ? ty / 2 : -ty / 2;
+              me.flags |= HWY_F_HAS_IMPACT;
+            }
+            if (r & 1) me.flags |= HWY_F_CRASHED;
           }
-          if (r & 1) me.flags |= HWY_F_CRASHED;
         }
       }
     } else {

@@ -40,6 +40,8 @@ struct WaveShared {
   // per-vehicle state touched once per frame (slot i is private to thread i: no barrier involved).
   // Keeping it here instead of in registers trims ~10 VGPRs off the frame loop's loop-carried set.
   double timer[64], ts[64], delta[64], impx[64], impy[64];
+  // post-integration bodies by vehicle index (full pairwise collisions only)
+  double nx[64], ny[64], nv[64], nc[64], ns[64];
 };
 
 // front / rear ranks on a lane from its rank-space membership mask; -1 if none
@@ -402,6 +404,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     accel = controlled ? HWY_KP_A * (sh.ts[i] - me.v) : accel;  // speed_control (controller.py:189-198), not clipped
 
     // ---- F. Road.step: integrate -------------------------------------------------------------------------
+    const double x_old = me.x;
     {
       // clip_actions (kinematics.py:155-168): a crashed vehicle has steering 0 (tan(beta) = 0), accel = -speed
       tb = crashed0 ? 0.0 : tb;
@@ -427,24 +430,32 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
     const Body mine{me.x, me.y, me.v, me.ch, me.sh};
     if (all_check) {
-      // full pairwise: walk the partners in index order; the highest-index partner is the last writer
-      for (int q = 0; q < N; ++q) {  // wave-uniform q
-        const double qx = wave_bcast(me.x, q), qy = wave_bcast(me.y, q), qv = wave_bcast(me.v, q);
-        bool near = false;
-        if (active && q != i) {
-          const double dx = qx - me.x, dy = qy - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(qv)) * p.dt;
-          near = dx * dx + dy * dy <= lim * lim;
-        }
-        if (__ballot(near) == 0) continue;  // nobody is close to q: skip the remaining broadcasts
-        const Body other{qx, qy, qv, wave_bcast(me.ch, q), wave_bcast(me.sh, q)};
-        if (near) {
-          const bool i_first = i < q;
-          const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
-          if (!surely_apart(A, Bb, p.dt)) {
+      // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among my
+      // neighbours along the road, so instead of walking all N partners each thread scans outward from its
+      // own rank, in both directions, in the rank order established at the start of this frame, and stops
+      // when the partner's FRAME-START distance exceeds the collision radius plus the most two vehicles can
+      // have moved relative to each other within one frame.  Everything within reach is visited, so the
+      // result equals the full loop; "last pair in loop order wins" == the partner with the highest index.
+      sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
+      __syncthreads();
+      if (active) {
+        const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);  // radius + relative motion (speed <= 50, impact <= 3 m)
+        int best = -1;
+        for (int dir = -1; dir <= 1; dir += 2) {
+          for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {
+            if (fabs(sh.x[r2] - x_old) > reach) break;  // sh.x: frame-start x in rank order
+            const int q = sh.idx[r2];
+            const Body other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q]};
+            const double dx = other.x - me.x, dy = other.y - me.y;
+            const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
+            if (dx * dx + dy * dy > lim * lim) continue;
+            const bool i_first = i < q;
+            const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
+            if (surely_apart(A, Bb, p.dt)) continue;
             double tx, ty;
             const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
-            if (r & 2) {
+            if ((r & 2) && q > best) {
+              best = q;
               sh.impx[i] = i_first ? tx / 2 : -tx / 2;
               sh.impy[i] = i_first ? ty / 2 : -ty / 2;
               me.flags |= HWY_F_HAS_IMPACT;
