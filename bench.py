@@ -213,7 +213,7 @@ def main() -> None:
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E, fast),
-                         "kernel": ("hwy_step_wave_kernel<3>  (one 64-wide wavefront per env)" if N <= 64 else
+                         "kernel": (f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "algorithmic_bytes_per_launch": b_env * E},
             "terminated_in_last_step": int(term),

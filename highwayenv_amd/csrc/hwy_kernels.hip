@@ -34,7 +34,10 @@ static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t
 }
 template <int WPE>
 static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_step_wave_kernel<WPE>), dim3(num_envs), dim3(64), 0, stream, p);
+  if (p.flags & HWY_C_EGO_ONLY_COLLISIONS)
+    hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), 0, stream, p);
+  else
+    hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 // N <= 64: one wavefront per environment (hwy_wave.h); otherwise ceil(N/64) wavefronts per workgroup.

@@ -154,7 +154,10 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
 }
 
 // =============================================================================================
-template <int WPE>
+// FULL_SCAN = false builds the kernel without the full-pairwise window scan (every checker is handled by
+// the checker loop, which is correct for any set of checkers but O(#checkers)); the engine launches it for
+// highway-fast-v0 style configs (HWY_C_EGO_ONLY_COLLISIONS), where it keeps the frame loop at 173 VGPRs.
+template <int WPE, bool FULL_SCAN>
 __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams p) {
   typedef EnvBlock<1> B;
   __shared__ WaveShared sh;
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   sh.timer[i] = me.timer; sh.ts[i] = me.ts; sh.delta[i] = me.delta; sh.impx[i] = me.impx; sh.impy[i] = me.impy;
   const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;
   const u64 chk = __ballot(active && i_check);
-  const bool all_check = __popcll(chk) == N;
+  const bool all_check = FULL_SCAN && __popcll(chk) == N;
 
   // position along the road, carried from frame to frame AND from step to step (hint in the packed word;
   // idle lanes keep their own slot so that the permutation stays a bijection)

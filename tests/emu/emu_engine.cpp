@@ -60,7 +60,8 @@ bool g_force_block = false;
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
   if (which == STEP && nw == 1 && !g_force_block) {  // same dispatch rule as hwy_kernels.hip
-    emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1>(q); }, E, 64, p);
+    if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, false>(q); }, E, 64, p);
+    else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
     return;
   }
 #define RUN(NW)                                                                                         \
