@@ -1,0 +1,97 @@
+"""BASELINE config 2 at FULL size (4096 envs x 51 vehicles) on the MI355X: properties that do not need a
+4096-env CPU reference.
+
+* determinism: the same seeds and actions give bit-identical results on a second engine;
+* batch independence: an env's trajectory does not depend on what else is in the batch -- 24 envs re-run
+  alone (from the same state, same actions) reproduce their rows of the big batch bit-for-bit;
+* oracle spot check: those 24 envs also match the CPU oracle step by step (live episodes);
+* invariants: reward in [0, 1], observations in [-1, 1], lane indices in range, per-step displacement within the kinematic bound, episode time advances by exactly 1 per step, auto-reset restarts episodes.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+E, STEPS = 4096, 40
+
+
+def make(E_):
+    from highwayenv_amd.engine import Engine
+    cfg_d = _abi.highway_fast_default_config()
+    cfg_d.update({"vehicles_count": 50, "lanes_count": 4})
+    cfg = _abi.make_config(cfg_d, E_, fast=True)
+    return cfg_d, cfg, Engine(cfg)
+
+
+def test_full_size_determinism_independence_oracle_and_invariants():
+    cfg_d, cfg, eng = make(E)
+    _, _, eng2 = make(E)
+    seeds = np.arange(E, dtype=np.uint64) + 12345
+    for e_ in (eng, eng2):
+        e_.reset(seeds=seeds, ego_spacing=1.5, vehicles_density=1.0)
+    pick = np.sort(np.random.default_rng(0).choice(E, 24, replace=False))
+    sub_cfg = _abi.make_config(cfg_d, len(pick), fast=True)
+    from highwayenv_amd.engine import Engine
+    sub = Engine(sub_cfg)
+    st0 = eng.get_state()
+    sub.set_state({k: np.ascontiguousarray(v[pick]) for k, v in st0.items()})
+    ref = {k: np.ascontiguousarray(v[pick]).copy() for k, v in st0.items()}
+    live = np.ones(len(pick), bool)
+    rng = np.random.default_rng(1)
+    prev = st0
+    for t in range(STEPS):
+        acts = rng.integers(0, 5, size=(E, 1)).astype(np.int32)
+        out1 = eng.step(acts)
+        out2 = eng2.step(acts)
+        for a, b in zip(out1[:4], out2[:4]):
+            np.testing.assert_array_equal(a, b, err_msg=f"determinism, step {t}")
+        obs, reward, term, trunc, info = out1
+        # batch independence (bit-exact) and oracle parity (tolerances of the parity tests) on the picked envs
+        s_obs, s_rew, s_term, s_trunc, _ = sub.step(acts[pick])
+        np.testing.assert_array_equal(s_obs, obs[pick], err_msg=f"batch independence, step {t}")
+        np.testing.assert_array_equal(s_rew, reward[pick])
+        np.testing.assert_array_equal(s_term, term[pick])
+        o2, r2, te2, tr2, _ = oracle.step(sub_cfg, ref, acts[pick])
+        wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        ok = live & ~wreck
+        np.testing.assert_array_equal(s_term[live], te2[live])
+        np.testing.assert_allclose(s_obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=f"oracle, step {t}")
+        np.testing.assert_allclose(s_rew[ok], r2[ok], rtol=0, atol=1e-9)
+        live &= ~wreck & ~tr2
+        # invariants over the whole batch
+        st = eng.get_state()
+        assert np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()
+        assert ((reward >= 0) & (reward <= 1 + 1e-12)).all()
+        assert ((st["lane"] >= 0) & (st["lane"] < 4) & (st["target_lane"] >= 0) & (st["target_lane"] < 4)).all()
+        # kinematic bound: |speed| <= MAX_SPEED (+ one frame of ACC_MAX) and an impact moves a car by < 3 m per frame
+        # (IDM cars DO reverse behind a wreck -- MIN_SPEED is -40 in the reference -- so x is not monotone)
+        assert (np.abs(st["x"] - prev["x"]) <= 41.5 * 1.0 + 15.0).all()
+        np.testing.assert_array_equal(st["time"], t + 1.0)
+        assert (trunc == (t + 1 >= 30)).all()
+        prev = st
+    assert term.sum() + (prev["flags"][:, 0] & _abi.F_CRASHED).astype(bool).sum() > 100  # crashes did happen
+    for e_ in (eng, eng2, sub):
+        e_.close()
+
+
+def test_full_size_autoreset_keeps_every_env_alive():
+    cfg_d, cfg, eng = make(E)
+    eng.reset(base_seed=99, ego_spacing=1.5, vehicles_density=1.0)
+    eng.set_autoreset(True, base_seed=7, ego_spacing=1.5, vehicles_density=1.0)
+    rng = np.random.default_rng(2)
+    done_prev = np.zeros(E, bool)
+    resets = np.zeros(E, int)
+    for t in range(70):
+        obs, reward, term, trunc, info = eng.step(rng.integers(0, 5, size=(E, 1)))
+        # the step after `done` is the reset step: reward 0, flags clear, fresh traffic (ego not crashed)
+        assert (reward[done_prev] == 0).all() and not term[done_prev].any() and not trunc[done_prev].any()
+        assert not info["crashed"][done_prev].any()
+        resets += done_prev
+        done_prev = term | trunc
+    assert (resets >= 2).all()  # 70 steps, 30-step episodes: every env restarted at least twice
+    st = eng.get_state()
+    assert (st["time"] <= 30).all()
+    eng.close()
