@@ -36,6 +36,10 @@ struct hwy_engine {
   uint32_t *d_episode = nullptr;
   // device I/O buffers for the host-pointer entry points
   int32_t *d_actions = nullptr;
+  // step outputs of the host-pointer entry points live in ONE device block (reward | speed | obs | term | trunc |
+  // crashed) mirrored by one pinned host block, so that hwy_step needs a single D2H copy
+  char *d_out = nullptr;
+  size_t out_bytes = 0, off_reward = 0, off_speed = 0, off_obs = 0, off_term = 0, off_trunc = 0, off_crashed = 0;
   float *d_obs = nullptr;
   double *d_reward = nullptr, *d_info_speed = nullptr;
   uint8_t *d_term = nullptr, *d_trunc = nullptr, *d_info_crashed = nullptr;
@@ -184,12 +188,24 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   ALLOC(eng->d_done, E);
   ALLOC(eng->d_episode, E * sizeof(uint32_t));
   ALLOC(eng->d_actions, n_act * sizeof(int32_t));
-  ALLOC(eng->d_obs, n_obs * sizeof(float));
-  ALLOC(eng->d_reward, n_ea * sizeof(double));
-  ALLOC(eng->d_info_speed, n_ea * sizeof(double));
-  ALLOC(eng->d_term, E);
-  ALLOC(eng->d_trunc, E);
-  ALLOC(eng->d_info_crashed, n_ea);
+  {
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    size_t off = 0;
+    eng->off_reward = off;  off = up(off + n_ea * sizeof(double));
+    eng->off_speed = off;   off = up(off + n_ea * sizeof(double));
+    eng->off_obs = off;     off = up(off + n_obs * sizeof(float));
+    eng->off_term = off;    off = up(off + E);
+    eng->off_trunc = off;   off = up(off + E);
+    eng->off_crashed = off; off = up(off + n_ea);
+    eng->out_bytes = off;
+  }
+  ALLOC(eng->d_out, eng->out_bytes);
+  eng->d_reward = (double *)(eng->d_out + eng->off_reward);
+  eng->d_info_speed = (double *)(eng->d_out + eng->off_speed);
+  eng->d_obs = (float *)(eng->d_out + eng->off_obs);
+  eng->d_term = (uint8_t *)(eng->d_out + eng->off_term);
+  eng->d_trunc = (uint8_t *)(eng->d_out + eng->off_trunc);
+  eng->d_info_crashed = (uint8_t *)(eng->d_out + eng->off_crashed);
   ALLOC(eng->d_mask, E);
   ALLOC(eng->d_seeds, E * sizeof(uint64_t));
   if (cfg->obs_type == HWY_OBS_OCCUPANCY_GRID)
@@ -202,7 +218,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   if ((e = hipMemsetAsync(eng->d_episode, 0, E * sizeof(uint32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   // pinned staging: the largest of {state SoA, step I/O}
   const size_t state_bytes = plane * (9 * sizeof(double) + sizeof(int32_t)) + E * sizeof(double);
-  const size_t io_bytes = n_act * 4 + n_obs * 4 + n_ea * (8 + 8 + 1) + E * 2 + E * 9 + 64;
+  const size_t io_bytes = eng->out_bytes + n_act * 4 + E * 9 + 64;
   eng->h_pinned_bytes = state_bytes > io_bytes ? state_bytes : io_bytes;
   if ((e = hipHostMalloc(&eng->h_pinned, eng->h_pinned_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   if ((e = hipStreamSynchronize(eng->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -222,9 +238,8 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   (void)hipSetDevice(eng->device);
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_obs,
-                  eng->d_reward, eng->d_info_speed, eng->d_term, eng->d_trunc, eng->d_info_crashed, eng->d_mask,
-                  eng->d_seeds, eng->d_grid_ws};
+  void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out,
+                  eng->d_mask, eng->d_seeds, eng->d_grid_ws};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -389,33 +404,22 @@ extern "C" int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, dou
   for (size_t k = 0; k < n_act; ++k)
     if (actions[k] < 0 || actions[k] > 4) return fail(eng, HWY_ERR_ACTION, "meta-action outside [0,5)");
   HWY_HIP(eng, hipSetDevice(eng->device));
-  // pinned layout: obs | reward | speed | actions | term | trunc | crashed
-  char *base = (char *)eng->h_pinned;
-  float *h_obs = (float *)base;                       base += ((n_obs * 4 + 7) & ~(size_t)7);
-  double *h_reward = (double *)base;                  base += n_ea * 8;
-  double *h_speed = (double *)base;                   base += n_ea * 8;
-  int32_t *h_act = (int32_t *)base;                   base += ((n_act * 4 + 7) & ~(size_t)7);
-  uint8_t *h_term = (uint8_t *)base;                  base += E;
-  uint8_t *h_trunc = (uint8_t *)base;                 base += E;
-  uint8_t *h_crashed = (uint8_t *)base;
+  // pinned layout: [mirror of the device output block][actions]
+  char *h_out = (char *)eng->h_pinned;
+  int32_t *h_act = (int32_t *)(h_out + eng->out_bytes);
   std::memcpy(h_act, actions, n_act * 4);
   HWY_HIP(eng, hipMemcpyAsync(eng->d_actions, h_act, n_act * 4, hipMemcpyHostToDevice, eng->stream));
   if (int rc = hwy_step_device(eng, eng->d_actions, eng->d_obs, eng->d_reward, eng->d_term, eng->d_trunc,
                                eng->d_info_speed, eng->d_info_crashed))
     return rc;
-  HWY_HIP(eng, hipMemcpyAsync(h_obs, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
-  HWY_HIP(eng, hipMemcpyAsync(h_reward, eng->d_reward, n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
-  HWY_HIP(eng, hipMemcpyAsync(h_speed, eng->d_info_speed, n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
-  HWY_HIP(eng, hipMemcpyAsync(h_term, eng->d_term, E, hipMemcpyDeviceToHost, eng->stream));
-  HWY_HIP(eng, hipMemcpyAsync(h_trunc, eng->d_trunc, E, hipMemcpyDeviceToHost, eng->stream));
-  HWY_HIP(eng, hipMemcpyAsync(h_crashed, eng->d_info_crashed, n_ea, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(h_out, eng->d_out, eng->out_bytes, hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
-  std::memcpy(obs, h_obs, n_obs * 4);
-  std::memcpy(reward, h_reward, n_ea * 8);
-  std::memcpy(terminated, h_term, E);
-  std::memcpy(truncated, h_trunc, E);
-  if (info_speed) std::memcpy(info_speed, h_speed, n_ea * 8);
-  if (info_crashed) std::memcpy(info_crashed, h_crashed, n_ea);
+  std::memcpy(obs, h_out + eng->off_obs, n_obs * 4);
+  std::memcpy(reward, h_out + eng->off_reward, n_ea * 8);
+  std::memcpy(terminated, h_out + eng->off_term, E);
+  std::memcpy(truncated, h_out + eng->off_trunc, E);
+  if (info_speed) std::memcpy(info_speed, h_out + eng->off_speed, n_ea * 8);
+  if (info_crashed) std::memcpy(info_crashed, h_out + eng->off_crashed, n_ea);
   return HWY_OK;
 }
 
