@@ -16,6 +16,16 @@
 
 namespace hwy {
 
+// A loop-invariant f64 constant that must NOT be hoisted out of the frame loop into a VGPR pair: the
+// asm pins it to an SGPR pair materialised (two s_mov_b32) right where it is used.
+#ifndef HWY_KC
+__device__ inline double sgpr_const(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+#define HWY_KC(c) ::hwy::sgpr_const(c)
+#endif
+
 // ---- reciprocal / reciprocal square root: hardware seed (~2^-26) + two Newton steps ----------------
 __device__ inline double fast_rcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -61,12 +71,12 @@ __device__ inline double log_pos(double x) {
   const double f = m - 1.0;
   const double s = f * fast_rcp(2.0 + f);
   const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double t1 = w * fma(w, fma(w, HWY_KC(Lg6), HWY_KC(Lg4)), HWY_KC(Lg2));
+  const double t2 = z * fma(w, fma(w, fma(w, HWY_KC(Lg7), HWY_KC(Lg5)), HWY_KC(Lg3)), HWY_KC(Lg1));
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)k;
-  return fma(dk, ln2_hi, -((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f));
+  return fma(dk, HWY_KC(ln2_hi), -((hfsq - fma(s, hfsq + R, dk * HWY_KC(ln2_lo))) - f));
 }
 
 // ---- exp(y), y <= 40 (results are finite, no overflow handling); y < -700 flushes to 0 --------------------
@@ -75,11 +85,11 @@ __device__ inline double exp_bounded(double y) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
   const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
-  const double k = rint(y * invln2);
-  const double hi = fma(-k, ln2HI, y), lo = k * ln2LO;
+  const double k = rint(y * HWY_KC(invln2));
+  const double hi = fma(-k, HWY_KC(ln2HI), y), lo = k * HWY_KC(ln2LO);
   const double r = hi - lo;
   const double t = r * r;
-  const double c = fma(-t, fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1), r);
+  const double c = fma(-t, fma(t, fma(t, fma(t, fma(t, HWY_KC(P5), HWY_KC(P4)), HWY_KC(P3)), HWY_KC(P2)), HWY_KC(P1)), r);
   const double e = 1.0 - ((lo - (r * c) * fast_rcp(2.0 - c)) - hi);
   // scale by 2^k: e in [0.7, 1.5], k in [-1010, 58] => the result is a normal double: add k to the exponent
   return __hiloint2double(__double2hiint(e) + ((int)k << 20), __double2loint(e));
@@ -93,14 +103,14 @@ __device__ inline void sincos_bounded(double x, double *sn, double *cs) {
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double n = rint(x * invpio2);
-  double r = fma(-n, pio2_1, x);
-  r = fma(-n, pio2_2, r);
-  r = fma(-n, pio2_3, r);
+  const double n = rint(x * HWY_KC(invpio2));
+  double r = fma(-n, HWY_KC(pio2_1), x);
+  r = fma(-n, HWY_KC(pio2_2), r);
+  r = fma(-n, HWY_KC(pio2_3), r);
   const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-  const double s = fma(z * r, fma(z, ps, S1), r);
-  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  const double ps = fma(z, fma(z, fma(z, fma(z, HWY_KC(S6), HWY_KC(S5)), HWY_KC(S4)), HWY_KC(S3)), HWY_KC(S2));
+  const double s = fma(z * r, fma(z, ps, HWY_KC(S1)), r);
+  const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, HWY_KC(C6), HWY_KC(C5)), HWY_KC(C4)), HWY_KC(C3)), HWY_KC(C2)), HWY_KC(C1));
   const double c = 1.0 - fma(-z, pc, 0.5 * z);
   const int q = (int)n & 3;
   const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
@@ -114,8 +124,8 @@ __device__ inline double asin_rational(double t) {  // R(t) = t*P(t)/Q(t), asin(
                pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
                qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
                qS4 = 7.70381505559019352791e-02;
-  const double pp = t * fma(t, fma(t, fma(t, fma(t, fma(t, pS5, pS4), pS3), pS2), pS1), pS0);
-  const double qq = fma(t, fma(t, fma(t, fma(t, qS4, qS3), qS2), qS1), 1.0);
+  const double pp = t * fma(t, fma(t, fma(t, fma(t, fma(t, HWY_KC(pS5), HWY_KC(pS4)), HWY_KC(pS3)), HWY_KC(pS2)), HWY_KC(pS1)), HWY_KC(pS0));
+  const double qq = fma(t, fma(t, fma(t, fma(t, HWY_KC(qS4), HWY_KC(qS3)), HWY_KC(qS2)), HWY_KC(qS1)), 1.0);
   return pp * fast_rcp(qq);
 }
 __device__ inline double asin_bounded(double x) {
@@ -125,7 +135,7 @@ __device__ inline double asin_bounded(double x) {
   const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17;
   const double t = (1.0 - ax) * 0.5;
   const double s = t > 0.0 ? t * fast_rsqrt(t) : 0.0;
-  const double r = pio2_hi - (2.0 * fma(s, asin_rational(t), s) - pio2_lo);
+  const double r = HWY_KC(pio2_hi) - (2.0 * fma(s, asin_rational(t), s) - HWY_KC(pio2_lo));
   return x < 0 ? -r : r;
 }
 

@@ -21,6 +21,7 @@
 #define __host__
 #define __shared__ static
 #define __launch_bounds__(...)
+#define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };
 
