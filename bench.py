@@ -143,7 +143,7 @@ def main() -> None:
     def one_step(t: int) -> None:
         eng.step_device(actions[t].data_ptr(), *out.pointers())
         if world > 1:
-            out.gather_to_rank0()
+            out.gather_to_rank0(assemble=False)  # one RCCL gather of the packed block; zero-copy views on rank 0
 
     def fence() -> None:
         if world > 1:

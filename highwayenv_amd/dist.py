@@ -74,15 +74,18 @@ class PackedStepOutputs:
     def terminated(self):
         return self.views()["terminated"]
 
-    def gather_to_rank0(self):
-        """One collective per batched step.  Returns, on rank 0, the dict of global arrays
-        (env-major concatenation over ranks); None elsewhere."""
+    def gather_to_rank0(self, assemble: bool = True):
+        """One collective per batched step.  On rank 0 returns the dict of global arrays (env-major
+        concatenation over ranks) -- or, with ``assemble=False``, the list of per-rank view dicts (zero-copy:
+        rank r's envs are ``shard_range(total, world, r)``); None on the other ranks."""
         if self.world == 1:
-            return self.views()
+            return self.views() if assemble else [self.views()]
         dist.gather(self.buf, self.gathered if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         per_rank = [self.views(b) for b in self.gathered]
+        if not assemble:
+            return per_rank
         return {k: torch.cat([v[k] for v in per_rank], dim=0) for k in per_rank[0]}
 
 
