@@ -107,8 +107,11 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HWY_BENCH_FORCE_DIST=1 (developer knob): run the RCCL gather path even with a single rank
+    use_dist = world > 1 or os.environ.get("HWY_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from highwayenv_amd import _abi
@@ -138,15 +141,30 @@ def main() -> None:
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     actions = torch.randint(0, 5, (total, E, A), generator=g, device=dev, dtype=torch.int32)
-    out = PackedStepOutputs(cfg, dev, world, rank)
+    # two alternating output blocks: the RCCL gather of step t (async, on RCCL's stream) overlaps the step kernel of
+    # step t+1, which writes into the other block
+    outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist) for _ in range(2)]
+    works = [None, None]
+    out = outs[0]
 
     def one_step(t: int) -> None:
-        eng.step_device(actions[t].data_ptr(), *out.pointers())
-        if world > 1:
-            out.gather_to_rank0(assemble=False)  # one RCCL gather of the packed block; zero-copy views on rank 0
+        k = t & 1
+        if works[k] is not None:
+            works[k].wait()  # stream-level: block k was gathered, the engine may overwrite it
+            works[k] = None
+        eng.step_device(actions[t].data_ptr(), *outs[k].pointers())
+        if use_dist:
+            works[k] = outs[k].gather_async()
+
+    def drain() -> None:
+        for k in (0, 1):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
 
     def fence() -> None:
-        if world > 1:
+        drain()
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -179,7 +197,7 @@ def main() -> None:
     # statistics of the run (sanity: the workload really stepped and reset)
     term = out.terminated().sum().item()
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
 
@@ -223,7 +241,7 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(cfg_dict, fast)
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -31,12 +31,13 @@ class PackedStepOutputs:
     | terminated u8[E] | truncated u8[E] | info_crashed u8[E,A].
     """
 
-    def __init__(self, cfg: _abi.HwyConfig, device, world: int = 1, rank: int = 0):
+    def __init__(self, cfg: _abi.HwyConfig, device, world: int = 1, rank: int = 0, force_collective: bool = False):
         E, A = cfg.num_envs, cfg.num_agents
         self.obs_shape = _abi.obs_shape(cfg)
         self.E, self.A = E, A
         obs_len = int(torch.tensor(self.obs_shape).prod())
         self.world, self.rank = world, rank
+        self.collective = world > 1 or force_collective  # force: exercise the collective with a single rank
         sizes = [("reward", E * A * 8), ("info_speed", E * A * 8), ("obs", E * A * obs_len * 4),
                  ("terminated", E), ("truncated", E), ("info_crashed", E * A)]
         self.offsets, off = {}, 0
@@ -46,7 +47,7 @@ class PackedStepOutputs:
         self.nbytes = off
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.gathered = ([torch.zeros(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world)]
-                         if (world > 1 and rank == 0) else None)
+                         if (self.collective and rank == 0) else None)
 
     def _view(self, buf, name, dtype, shape):
         off, nbytes = self.offsets[name]
@@ -74,11 +75,26 @@ class PackedStepOutputs:
     def terminated(self):
         return self.views()["terminated"]
 
+    def gather_async(self):
+        """Start the gather of this block to rank 0 and return the ``Work`` handle (None for world 1).
+        With two alternating ``PackedStepOutputs`` the collective of step t overlaps the kernel of step t+1;
+        call ``work.wait()`` before the engine writes into this block again and before reading
+        ``rank0_views()``."""
+        if not self.collective:
+            return None
+        return dist.gather(self.buf, self.gathered if self.rank == 0 else None, dst=0, async_op=True)
+
+    def rank0_views(self):
+        """Per-rank view dicts of the last completed gather (rank 0), zero-copy."""
+        if not self.collective:
+            return [self.views()]
+        return [self.views(b) for b in self.gathered] if self.rank == 0 else None
+
     def gather_to_rank0(self, assemble: bool = True):
         """One collective per batched step.  On rank 0 returns the dict of global arrays (env-major
         concatenation over ranks) -- or, with ``assemble=False``, the list of per-rank view dicts (zero-copy:
         rank r's envs are ``shard_range(total, world, r)``); None on the other ranks."""
-        if self.world == 1:
+        if not self.collective:
             return self.views() if assemble else [self.views()]
         dist.gather(self.buf, self.gathered if self.rank == 0 else None, dst=0)
         if self.rank != 0:

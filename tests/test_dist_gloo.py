@@ -37,6 +37,13 @@ def _worker(rank, world, port, E, q):
         v["truncated"][:] = (env_ids % 3 == 0).to(torch.uint8)
         v["info_crashed"][:, 0] = (env_ids % 5 == 0).to(torch.uint8)
         got = out.gather_to_rank0()
+        work = out.gather_async()  # the overlapped form used by bench.py
+        work.wait()
+        per_rank = out.rank0_views()
+        if rank == 0:
+            assert len(per_rank) == world and bool((per_rank[1]["reward"][:, 0] == torch.arange(E, 2 * E).double() + 0.25).all())
+        else:
+            assert per_rank is None
         acts_global = (torch.arange(E * world, dtype=torch.int32).view(-1, 1) % 5) if rank == 0 else None
         mine = scatter_actions(acts_global, world, rank, E, "cpu")
         ok = bool((mine[:, 0] == (env_ids % 5).int()).all())
