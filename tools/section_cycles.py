@@ -25,10 +25,8 @@ for t in range(60):
     if t >= 40:
         tot += obs.reshape(E, -1)[:, :13].astype(np.float64).mean(0)
         n += 1
-names = (["load", "A+B publish", "C rank+masks", "D neigh+free+mobil", "D' abort chain", "E control", "F integrate",
-          "G collisions", "H observe", "store", "-", "-"] if os.environ.get("HWY_STEP_KERNEL") == "block" else
-         ["load+chk", "A meta-action", "C rank loop", "C membership+snapshot", "D neighbour ranks+gather", "D free+own gap",
-          "D mobil", "D abort chain", "E control", "F integrate", "G collisions", "H observe"])
+names = ["load+chk", "A meta-action", "C rank check/recount", "C membership+snapshot", "D neighbour ranks+gather",
+         "D free road + gaps", "D mobil", "D abort chain", "E control", "F integrate", "G collisions", "H observe"]
 tot /= n
 for k, nm in enumerate(names):
     print(f"{nm:22s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot[:12].sum():5.1f}%")
