@@ -66,13 +66,15 @@ def ticks(text):
              "    // ---- F. Road.step: integrate",
              "    // ---- G. Road.step: collisions",
              "  }  // frames"]
+    t = sub("    wave_update_rank(me.x, active, N, rank, has_tie);\n    // lane membership",
+            "    { const int r_before = rank; wave_update_rank(me.x, active, N, rank, has_tie);\n"
+            "      n_recount += __ballot(rank != r_before) ? 1.0f : 0.0f; }\n    // lane membership")(t)
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
-    t = sub("    if (recount) {  // wave-uniform\n", "    if (recount) {  n_recount += 1.0f;\n")(t)
-    t = sub("  if (p.full_step) observe_wave(p, e, me, true);\n  me.rank = rank;",
-            "  if (p.full_step) observe_wave(p, e, me, true);\n  TICK(11)\n  me.rank = rank;")(t)
-    t = sub("  store_vehicle<1>(p, e, me, false);\n}",
-            "  store_vehicle<1>(p, e, me, false);\n"
+    t = sub("    observe_wave<true>(q, e, me, true, rank);\n  }\n  me.rank = rank;",
+            "    observe_wave<true>(q, e, me, true, rank);\n  }\n  TICK(11)\n  me.rank = rank;")(t)
+    t = sub("  store_vehicle<1>(q, e, me, false);\n}",
+            "  store_vehicle<1>(q, e, me, false);\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
             "    p.obs[(size_t)e * p.A * p.V * p.F + 12] = n_recount; }\n}")(t)
     return t
@@ -85,13 +87,13 @@ VARIANTS = {
     # one-wavefront kernel (hwy_wave.h)
     "wbase": [],
     "wnocollide": [(W, cutter("    const Body mine{me.x, me.y, me.v, me.ch, me.sh};", "  }  // frames"))],
-    "wnorecount": [(W, cutter("    if (recount) {  // wave-uniform", "    // lane membership (AbstractLane.on_lane, margin 1) -> bits"))],
+    "wnorecount": [(W, sub("  if (recount) {  // wave-uniform", "  if (false) {"))],
     "wnomobil": [(W, sub("    const bool cl = decide && left_ok", "    const bool cl = false && left_ok")),
                  (W, sub("    const bool cr = decide && right_ok", "    const bool cr = false && right_ok"))],
     "wnologexp": NO_LOGEXP,
     "wnosincos": [(W, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))],
     "wnosteer": [(W, sub("    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "    double tb = inv_v * 1e-9;"))],
-    "wnoobs": [(W, sub("  if (p.full_step) observe_wave(p, e, me, true);", ""))],
+    "wnoobs": [(W, sub("    observe_wave<true>(q, e, me, true, rank);\n", ""))],
     "wticks": [(W, ticks)],
     # generic workgroup kernel (hwy_device.h)
     "base": [],

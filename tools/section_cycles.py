@@ -31,4 +31,4 @@ tot /= n
 for k, nm in enumerate(names):
     print(f"{nm:22s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot[:12].sum():5.1f}%")
 print(f"{'total':22s} {tot[:12].sum():10.0f}")
-print("rank recounts per step (of 5 frames):", tot[12])
+print("frames whose rank order changed, per step (of 5 frames):", tot[12])
