@@ -75,16 +75,18 @@ typedef unsigned long long u64;
 #define HWY_LC_MAX_BRAKING 2.0
 #define HWY_LC_DELAY 1.0
 
-// packed per-vehicle word: lane[0:3] | target_lane[4:7] | speed_index[8:11] | flags[12:15] | rank[16:23]
+// packed per-vehicle word: lane[0:3] | target_lane[4:7] | speed_index[8:11] | flags[12:15] | rank[16:23] | flags[24:25]
+// (flag bits 4-5 -- HWY_F_OBSTACLE, HWY_F_ABSENT, road-network scenarios only -- live in bits 24-25)
 // rank = position along the road (a HINT carried from step to step: the one-wavefront kernel verifies it
 // every frame and recounts when it is stale; hwy_set_state / spawn write the identity permutation)
 __host__ __device__ inline int32_t pack_word(int lane, int tgt, int sidx, int flags, int rank) {
-  return (lane & 0xf) | ((tgt & 0xf) << 4) | ((sidx & 0xf) << 8) | ((flags & 0xf) << 12) | ((rank & 0xff) << 16);
+  return (lane & 0xf) | ((tgt & 0xf) << 4) | ((sidx & 0xf) << 8) | ((flags & 0xf) << 12) | ((rank & 0xff) << 16) |
+         (((flags >> 4) & 0x3) << 24);
 }
 __host__ __device__ inline int word_lane(int32_t w) { return w & 0xf; }
 __host__ __device__ inline int word_target(int32_t w) { return (w >> 4) & 0xf; }
 __host__ __device__ inline int word_speed_index(int32_t w) { return (w >> 8) & 0xf; }
-__host__ __device__ inline int word_flags(int32_t w) { return (w >> 12) & 0xf; }
+__host__ __device__ inline int word_flags(int32_t w) { return ((w >> 12) & 0xf) | (((w >> 24) & 0x3) << 4); }
 __host__ __device__ inline int word_rank(int32_t w) { return (w >> 16) & 0xff; }
 
 struct DevState {

@@ -126,6 +126,23 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->num_target_speeds < 2 || c->num_target_speeds > HWY_MAX_TARGET_SPEEDS) BAD("num_target_speeds must be in [2,%d]", HWY_MAX_TARGET_SPEEDS);
   if (!(c->dt > 0) || !(c->policy_dt > 0)) BAD("dt and policy_dt must be positive");
   if (!(c->lane_width > 0) || !(c->road_length > 0)) BAD("lane_width and road_length must be positive");
+  if (c->scenario != HWY_SCENARIO_HIGHWAY) {
+    if (c->scenario != HWY_SCENARIO_MERGE && c->scenario != HWY_SCENARIO_MERGE_GENERIC) BAD("unknown scenario %d", c->scenario);
+    if (c->obs_type != HWY_OBS_KINEMATICS) BAD("road-network scenarios support the Kinematics observation only");
+    if (c->num_vehicles < 4 || c->num_vehicles > 64) BAD("road-network scenarios need 4..64 slots (one wavefront per environment)");
+    if (c->net_lanes < 1 || c->net_lanes > HWY_MAX_LANES) BAD("net_lanes must be in [1,%d]", HWY_MAX_LANES);
+    if (c->merge_lane >= c->net_lanes) BAD("merge_lane out of range");
+    if (c->net_lanes < 3 * c->lanes_count + 3) BAD("merge networks hold 3*lanes_count + 3 lanes");
+    for (int a = 0; a < c->num_agents; ++a)
+      if (c->agent_index[a] != a) BAD("road-network scenarios keep agent a in slot a");
+    for (int k = 0; k < c->net_lanes; ++k) {
+      const hwy_lane &l = c->net[k];
+      if (!(l.length > 0) || !(l.width > 0)) BAD("net[%d]: length and width must be positive", k);
+      if (l.road_first < 0 || l.road_lanes < 1 || l.road_first + l.road_lanes > c->net_lanes || l.id != k - l.road_first ||
+          l.id >= l.road_lanes) BAD("net[%d]: inconsistent road_first / road_lanes / id", k);
+      if (l.next_first >= 0 && (l.next_lanes < 1 || l.next_first + l.next_lanes > c->net_lanes)) BAD("net[%d]: successor road out of range", k);
+    }
+  }
 #undef BAD
   return HWY_OK;
 }
@@ -137,6 +154,32 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.autoreset = eng->autoreset;
   p.rp = eng->rp;
   p.grid_ws = eng->d_grid_ws;
+}
+
+static bool is_net(const hwy_engine *eng) { return eng->cfg.scenario != HWY_SCENARIO_HIGHWAY; }
+static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_net(eng)) {
+    hwy::NetParams np;
+    hwy::net_params_from_config(eng->cfg, p, np);
+    return hwy::launch_net_step(np, eng->cfg.num_envs, eng->stream, eng->waves_per_eu);
+  }
+  return hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel);
+}
+static hipError_t launch_reset_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_net(eng)) {
+    hwy::NetParams np;
+    hwy::net_params_from_config(eng->cfg, p, np);
+    return hwy::launch_net_reset(np, eng->cfg.num_envs, eng->stream);
+  }
+  return hwy::launch_reset(p, eng->cfg.num_envs, eng->stream);
+}
+static hipError_t launch_observe_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_net(eng)) {
+    hwy::NetParams np;
+    hwy::net_params_from_config(eng->cfg, p, np);
+    return hwy::launch_net_observe(np, eng->cfg.num_envs, eng->stream);
+  }
+  return hwy::launch_observe(p, eng->cfg.num_envs, eng->stream);
 }
 
 static size_t io_counts(const hwy_config &c, size_t *n_act, size_t *n_obs, size_t *n_ea) {
@@ -269,9 +312,9 @@ extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
   HWY_HIP(eng, hipSetDevice(eng->device));
   const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
   const size_t plane = (size_t)E * P;
+  const int n_lane_ids = is_net(eng) ? eng->cfg.net_lanes : eng->cfg.lanes_count;
   for (size_t k = 0; k < (size_t)E * N; ++k) {
-    if (h->lane[k] < 0 || h->lane[k] >= eng->cfg.lanes_count || h->target_lane[k] < 0 ||
-        h->target_lane[k] >= eng->cfg.lanes_count)
+    if (h->lane[k] < 0 || h->lane[k] >= n_lane_ids || h->target_lane[k] < 0 || h->target_lane[k] >= n_lane_ids)
       return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: lane index out of range");
     if (h->speed_index[k] < 0 || h->speed_index[k] >= eng->cfg.num_target_speeds)
       return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: speed_index out of range");
@@ -329,7 +372,7 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
 // ---- kernel timing ----------------------------------------------------------------------------------
 static int timed_launch(hwy_engine *eng, const StepParams &p) {
   if (!eng->profiling || (eng->launch_counter++ % eng->profiling) != 0) {
-    HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel));
+    HWY_HIP(eng, launch_step_any(eng, p));
     return HWY_OK;
   }
   if (eng->events_used == eng->events.size()) {
@@ -340,7 +383,7 @@ static int timed_launch(hwy_engine *eng, const StepParams &p) {
   }
   auto &pr = eng->events[eng->events_used++];
   HWY_HIP(eng, hipEventRecord(pr.first, eng->stream));
-  HWY_HIP(eng, hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel));
+  HWY_HIP(eng, launch_step_any(eng, p));
   HWY_HIP(eng, hipEventRecord(pr.second, eng->stream));
   return HWY_OK;
 }
@@ -455,7 +498,7 @@ extern "C" int hwy_observe(hwy_engine *eng, float *obs) {
   fill_params(eng, p);
   p.obs = eng->d_obs;
   p.reward = eng->d_reward; p.terminated = eng->d_term; p.truncated = eng->d_trunc;
-  HWY_HIP(eng, hwy::launch_observe(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, launch_observe_any(eng, p));
   HWY_HIP(eng, hipMemcpyAsync(eng->h_pinned, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
   std::memcpy(obs, eng->h_pinned, n_obs * 4);
@@ -466,6 +509,7 @@ extern "C" int hwy_observe(hwy_engine *eng, float *obs) {
 static int set_reset_params(hwy_engine *eng, double ego_spacing, double vehicles_density, int32_t initial_lane_id) {
   if (!(ego_spacing > 0) || !(vehicles_density > 0)) return fail(eng, HWY_ERR_INVALID_ARG, "spacing/density must be positive");
   if (initial_lane_id >= eng->cfg.lanes_count) return fail(eng, HWY_ERR_INVALID_ARG, "initial_lane_id out of range");
+  // (road-network scenarios: the spawn rule of MergeEnv / MergeGenericEnv has no spacing / density / lane parameters)
   eng->rp.ego_spacing = ego_spacing;
   eng->rp.other_spacing = 1 / vehicles_density;  // highway_env.py:94
   eng->rp.initial_lane_id = initial_lane_id < 0 ? -1 : initial_lane_id;
@@ -495,7 +539,7 @@ extern "C" int hwy_reset(hwy_engine *eng, const uint8_t *mask, const uint64_t *s
   }
   p.obs = eng->d_obs;
   p.reward = eng->d_reward; p.terminated = eng->d_term; p.truncated = eng->d_trunc;
-  HWY_HIP(eng, hwy::launch_reset(p, eng->cfg.num_envs, eng->stream));
+  HWY_HIP(eng, launch_reset_any(eng, p));
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
   if (obs) {
     HWY_HIP(eng, hipMemcpyAsync(eng->h_pinned, eng->d_obs, n_obs * 4, hipMemcpyDeviceToHost, eng->stream));

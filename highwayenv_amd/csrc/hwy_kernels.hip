@@ -5,6 +5,7 @@
 
 #include "hwy_device.h"
 #include "hwy_wave.h"
+#include "hwy_net.h"
 #include "hwy_launch.h"
 
 namespace hwy {
@@ -56,6 +57,23 @@ hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, in
     case 3: return launch_step_wpe<3>(p, num_envs, stream);
     default: return launch_step_wpe<4>(p, num_envs, stream);
   }
+}
+hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
+  switch (waves_per_eu) {
+    case 1: hipLaunchKernelGGL((hwy_net_step_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 2: hipLaunchKernelGGL((hwy_net_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 3: hipLaunchKernelGGL((hwy_net_step_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    default: hipLaunchKernelGGL((hwy_net_step_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_net_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  return hipGetLastError();
+}
+hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  return hipGetLastError();
 }
 __global__ void hwy_math_probe_kernel(int op, const double *in, double *out, long long n) {
   const long long k = (long long)blockIdx.x * 256 + threadIdx.x;

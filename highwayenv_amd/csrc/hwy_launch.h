@@ -3,10 +3,15 @@
 #include <hip/hip_runtime.h>
 
 #include "hwy_device.h"
+#include "hwy_net.h"
 
 namespace hwy {
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel);
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *in, double *out, long long n, hipStream_t stream);
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream);
+// road-network scenarios (hwy_net.h): one wavefront per environment
+hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu);
+hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream);
+hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream);
 }  // namespace hwy

@@ -1,0 +1,750 @@
+// hwy_net.h -- the fused policy-step kernel for ROAD-NETWORK scenarios (MergeEnv / MergeGenericEnv,
+// highway_env/envs/merge_env.py): ONE 64-wide wavefront per environment, thread i == slot i of the vehicle
+// arrays (vehicles in Road.vehicles order, HWY_F_ABSENT holes, then the Obstacle of Road.objects).
+//
+// Same wave formulation as hwy_wave.h -- rank of every vehicle along x, rank-space membership mask per lane
+// (one ballot per lane), front / rear neighbour == two bit scans + one LDS gather, ordered readlane chains for
+// the sequential bits of the reference's Python loops -- generalised from "L parallel lanes of one road" to a
+// table of x-aligned lanes (hwy_config.net -> NetParams::lane -> LDS):
+//   * every lane has its own start / length (AbstractLane.on_lane, lane.py:80-102) and, for the SineLane of
+//     the access ramp, a lateral offset amplitude*sin(pulsation*s + phase) (lane.py:236-283);
+//   * because every lane's direction is (1, 0) the longitudinal coordinate on ANY lane is x - x0, so one sort
+//     by x still orders every lane's members;
+//   * ControlledVehicle.follow_road / RoadNetwork.next_lane switch the target lane at the end of a segment
+//     (controller.py:135-143, road.py:73-146); forbidden lanes are never reachable (lane.py:110-111); the
+//     lane-change abort rule applies on the same road only (behavior.py:232); IDM clips the target speed to the
+//     limit of the ego's current lane (behavior.py:171-175);
+//   * the Obstacle (2 m x 2 m, objects.py:25-26,215-222) is a member of lane masks, a collision partner
+//     (a vehicle hitting it takes the WHOLE translation, objects.py:106-107) and observable, but never acts;
+//   * absent slots (MergeGenericEnv's rejection-sampled spawn, merge_env.py:336-352) take no part in anything.
+#pragma once
+
+#include "hwy_device.h"
+#include "hwy_wave.h"
+
+namespace hwy {
+
+struct NetParams {
+  StepParams s;                    // must stay first (load_vehicle / store_vehicle / observe helpers take it)
+  int32_t n_lanes, merge_lane, generic, pad_;  // generic: MergeGenericEnv's spawn rule (device reset)
+  double merge_end_x, merging_speed_reward, lane_change_reward;
+  hwy_lane lane[HWY_MAX_LANES];
+};
+
+struct NetShared {
+  // lane table (struct of arrays: per-thread lane indices read it with one ds_read each)
+  double lx0[HWY_MAX_LANES], ly0[HWY_MAX_LANES], llen[HWY_MAX_LANES], lwid[HWY_MAX_LANES], lamp[HWY_MAX_LANES],
+      lpuls[HWY_MAX_LANES], lphase[HWY_MAX_LANES], llimit[HWY_MAX_LANES];
+  int lroad[HWY_MAX_LANES], lid[HWY_MAX_LANES], lfirst[HWY_MAX_LANES], lcount[HWY_MAX_LANES], lnext[HWY_MAX_LANES],
+      lnextn[HWY_MAX_LANES], lforb[HWY_MAX_LANES];
+  // frame-start snapshot in RANK order
+  double x[64], v[64], c[64], s[64], lr[64], ox[64];  // lr = log(v/v0) (IDM), ox = x0 of the vehicle's own lane
+  int idx[64], kind[64];                              // kind: 1 = vehicle, 0 = obstacle
+  u64 lane_mask[HWY_MAX_LANES];
+  // post-integration bodies by slot index (collisions)
+  double nx[64], ny[64], nv[64], nc[64], ns[64];
+  double scratch[64 + 8];  // device spawn
+};
+
+// ---- lane geometry from the LDS table (per-thread lane index L) ---------------------------------------------
+// lateral coordinate on lane L (StraightLane / SineLane.local_coordinates); s = x - x0[L]
+__device__ inline double net_lat(const NetShared &sh, int L, double s, double y) {
+  double lat = y - sh.ly0[L];
+  const double amp = sh.lamp[L];
+  if (amp != 0.0) {
+    double sn, cs;
+    sincos_bounded(sh.lpuls[L] * s + sh.lphase[L], &sn, &cs);
+    lat = lat - amp * sn;
+  }
+  return lat;
+}
+// atan for the lane slope amplitude*pulsation*cos(.) (|t| <= 0.13 on the merge ramps): fdlibm s_atan.c,
+// |x| < 7/16 branch; anything larger goes to the library routine.
+__device__ inline double atan_small(double x) {
+  if (!(fabs(x) < 0.4375)) return atan(x);
+  constexpr double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                   aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                   aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                   aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+  const double z = x * x, w = z * z;
+  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, aT10, aT8), aT6), aT4), aT2), aT0);
+  const double s2 = w * fma(w, fma(w, fma(w, fma(w, aT9, aT7), aT5), aT3), aT1);
+  return x - x * (s1 + s2);
+}
+// heading of lane L at longitudinal s (StraightLane.heading_at == 0; SineLane.heading_at, lane.py:259-265)
+__device__ inline double net_heading_at(const NetShared &sh, int L, double s) {
+  const double amp = sh.lamp[L];
+  if (amp == 0.0) return 0.0;
+  double sn, cs;
+  sincos_bounded(sh.lpuls[L] * s + sh.lphase[L], &sn, &cs);
+  return 0.0 + atan_small(amp * sh.lpuls[L] * cs);
+}
+// AbstractLane.is_reachable_from (lane.py:104-118)
+__device__ inline bool net_reachable(const NetShared &sh, int L, double x, double y) {
+  if (sh.lforb[L]) return false;
+  const double s = x - sh.lx0[L];
+  const double lat = net_lat(sh, L, s, y);
+  return fabs(lat) <= 2 * sh.lwid[L] && 0 <= s && s < sh.llen[L] + 5.0;
+}
+// ControlledVehicle.follow_road (controller.py:135-143) + RoadNetwork.next_lane with route=None (road.py:73-146)
+__device__ inline int net_follow_road(const NetShared &sh, int tgt, double x, double y) {
+  const double s = x - sh.lx0[tgt];
+  if (!(s > sh.llen[tgt] - 5.0 / 2)) return tgt;  // AbstractLane.after_end (lane.py:120-125)
+  const int nf = sh.lnext[tgt];
+  if (nf < 0) return tgt;  // KeyError on graph[_to] -> current index
+  if (sh.lcount[tgt] == sh.lnextn[tgt]) return nf + sh.lid[tgt];
+  // projected position lane.position(s, 0); closest lane of the next road by AbstractLane.distance (first minimum)
+  double py = sh.ly0[tgt];
+  if (sh.lamp[tgt] != 0.0) {
+    double sn, cs;
+    sincos_bounded(sh.lpuls[tgt] * s + sh.lphase[tgt], &sn, &cs);
+    py = sh.ly0[tgt] + (0.0 + sh.lamp[tgt] * sn);
+  }
+  const double px = sh.lx0[tgt] + s;
+  int best = 0;
+  double bd = 0.0;
+  for (int k = 0; k < sh.lnextn[tgt]; ++k) {
+    const int L = nf + k;
+    const double s2 = px - sh.lx0[L];
+    const double r = net_lat(sh, L, s2, py);
+    const double d = fabs(r) + fmax(s2 - sh.llen[L], 0.0) + fmax(0 - s2, 0.0);
+    if (k == 0 || d < bd) { bd = d; best = k; }
+  }
+  return nf + best;
+}
+// RoadNetwork.get_closest_lane_index (road.py:55-71) with distance_with_heading (lane.py:132-147): first minimum
+// in table order.  n_lanes is wave-uniform; the straight lanes share the heading term.
+__device__ inline int net_closest_lane(const NetShared &sh, int n_lanes, double x, double y, double h) {
+  const double angle0 = fabs(wrap_to_pi(h - 0.0));
+  int best = 0;
+  double bd = 0.0;
+  for (int L = 0; L < n_lanes; ++L) {  // wave-uniform L: LDS broadcasts
+    const double s = x - sh.lx0[L];
+    double r = y - sh.ly0[L], angle = angle0;
+    const double amp = sh.lamp[L];
+    if (amp != 0.0) {  // wave-uniform branch
+      double sn, cs;
+      sincos_bounded(sh.lpuls[L] * s + sh.lphase[L], &sn, &cs);
+      r = r - amp * sn;
+      angle = fabs(wrap_to_pi(h - (0.0 + atan_small(amp * sh.lpuls[L] * cs))));
+    }
+    const double d = fabs(r) + fmax(s - sh.llen[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+    if (L == 0 || d < bd) { bd = d; best = L; }
+  }
+  return best;
+}
+
+// ---- IDM pieces with an explicit lane distance d (objects.py:183-198: along the EGO's current lane) -----------
+__device__ inline double net_gap_term(double d, double ve, double ce, double se, double vf, double cf, double sf) {
+  const double q = EnvBlock<1>::desired_gap(ve, ce, se, vf, cf, sf) * fast_rcp(not_zero(d));
+  return HWY_COMFORT_ACC_MAX * (q * q);
+}
+__device__ inline double net_log_ratio(double v, double ts, double limit) {
+  const double v0 = clipd(ts, 0.0, limit);
+  const double r = fmax(v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+  return r > 0.0 ? log_pos(r) : -__builtin_inf();
+}
+// steering_control (controller.py:145-187) folded with the slip / bicycle chain like EnvBlock::steer_tan_beta,
+// for a lane whose lateral offset and look-ahead heading are given
+__device__ inline double net_steer_tan_beta(double lat, double lane_heading, double h, double inv_v) {
+  const double a = clipd((-HWY_KP_LATERAL * lat) * inv_v, -1.0, 1.0);
+  const double s45 = 0.7071067811865476;
+  const double hc = a >= s45 ? HWY_PI / 4 : (a <= -s45 ? -HWY_PI / 4 : clipd(asin_bounded(a), -HWY_PI / 4, HWY_PI / 4));
+  const double heading_ref = lane_heading + hc;
+  const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - h);
+  const double w = clipd((HWY_VEH_LENGTH / 2 * inv_v) * heading_rate_command, -1.0, 1.0);
+  const double tan_max = 1.7320508075688767;
+  const double w2 = 1 - w * w;
+  const double tan_steer = (w2 <= 1e-12) ? copysign(tan_max, w) : clipd((2 * w) * fast_rsqrt(w2), -tan_max, tan_max);
+  return 0.5 * tan_steer;
+}
+
+// ---- rectangles of different sizes (vehicle 5 x 2, obstacle 2 x 2): the SAT of hwy_device.h with per-body
+//      half extents; a = the reference's `self` (lower slot), b = `other` -----------------------------------------
+struct NetBody {
+  double x, y, v, c, s, hl, hw;
+};
+__device__ inline NetBody select_nbody(bool first, const NetBody &p, const NetBody &q) {
+  return NetBody{first ? p.x : q.x, first ? p.y : q.y, first ? p.v : q.v, first ? p.c : q.c, first ? p.s : q.s,
+                 first ? p.hl : q.hl, first ? p.hw : q.hw};
+}
+__device__ inline bool net_surely_apart(const NetBody &A, const NetBody &B, double dt) {
+  const double dx = B.x - A.x, dy = B.y - A.y;
+  const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);
+  const double rvx = (A.v * A.c - B.v * B.c) * dt, rvy = (A.v * A.s - B.v * B.s) * dt;
+  const double margin = 1e-6;
+  const double gap_lat = fabs(-A.s * dx + A.c * dy) - A.hw - (B.hl * sr + B.hw * cr) - fabs(-A.s * rvx + A.c * rvy);
+  const double gap_lon = fabs(A.c * dx + A.s * dy) - A.hl - (B.hl * cr + B.hw * sr) - fabs(A.c * rvx + A.s * rvy);
+  return gap_lat > margin || gap_lon > margin;
+}
+__device__ inline int net_pair_collide(const NetBody &A, const NetBody &B, double dt, double *tx, double *ty) {
+  const double diag_a = sqrt((2 * A.hl) * (2 * A.hl) + (2 * A.hw) * (2 * A.hw));
+  const double diag_b = sqrt((2 * B.hl) * (2 * B.hl) + (2 * B.hw) * (2 * B.hw));
+  const double dx = B.x - A.x, dy = B.y - A.y;
+  *tx = 0;
+  *ty = 0;
+  if (sqrt(dx * dx + dy * dy) > (diag_a + diag_b) / 2 + A.v * dt) return 0;  // objects.py:124-127
+  const double ddx = A.v * A.c * dt - B.v * B.c * dt, ddy = A.v * A.s * dt - B.v * B.s * dt;
+  const double cdx = A.x - B.x, cdy = A.y - B.y;
+  const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);
+  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0};
+  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, A.hl, B.x * A.c + B.y * A.s, B.hl * cr + B.hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
+  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, A.hw, B.y * A.c - B.x * A.s, B.hl * sr + B.hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
+  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, A.hl * cr + A.hw * sr, B.x * B.c + B.y * B.s, B.hl, B.c * ddx + B.s * ddy, cdx, cdy);
+  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, A.hl * sr + A.hw * cr, B.y * B.c - B.x * B.s, B.hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  if (acc.will) {
+    *tx = acc.min_distance * acc.axx;
+    *ty = acc.min_distance * acc.axy;
+  }
+  return (acc.intersecting ? 1 : 0) | (acc.will ? 2 : 0);
+}
+
+// ---- rank along x among the PRESENT slots (0 = smallest x; equal x ordered by slot); absent / idle lanes take
+//      the remaining ranks so that the ds_permute sends stay a bijection ------------------------------------------
+__device__ inline void net_rank(double x, bool present, u64 pm, int &rank, bool &has_tie) {
+  const int i = threadIdx.x;
+  int cnt = 0;
+  bool tie = false;
+  for (u64 m = pm; m; m &= m - 1) {  // wave-uniform
+    const int j = ctz64(m);
+    const double xj = wave_bcast(x, j);
+    cnt += (xj < x || (xj == x && j < i)) ? 1 : 0;
+    tie = tie || (xj == x && j != i);
+  }
+  has_tie = __ballot(present && tie) != 0;
+  const u64 below = ((u64)1 << i) - 1;
+  rank = present ? cnt : __popcll(pm) + __popcll(~pm & below);
+}
+
+// Road.neighbour_vehicles literal scan on lane Lq (equal-x case only); returns slot indices
+__device__ inline void net_neighbours_scan(const NetShared &sh, u64 pm, int bits, double x, int self, int Lq, int *front,
+                                           int *rear) {
+  int f = -1, b = -1;
+  double s_front = 0, s_rear = 0;
+  const double x0 = sh.lx0[Lq];
+  const double s = x - x0;
+  for (u64 m = pm; m; m &= m - 1) {  // wave-uniform
+    const int j = ctz64(m);
+    const double s_v = wave_bcast(x, j) - x0;
+    const int bj = wave_bcast_i(bits, j);
+    if (j == self || !((bj >> Lq) & 1)) continue;
+    if (s <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
+    if (s_v < s && (b < 0 || s_v > s_rear)) { s_rear = s_v; b = j; }
+  }
+  *front = f;
+  *rear = b;
+}
+
+// ---- KinematicObservation (observation.py:234-276) with obstacles (road.py:421-450), MergeEnv reward and
+//      termination (merge_env.py:40-82).  All cross-lane reads through readlane. -------------------------------------
+__device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, const Veh &me, bool write_reward) {
+  const StepParams &p = np.s;
+  const int i = threadIdx.x;
+  const bool present = i < p.N && !(me.flags & HWY_F_ABSENT);
+  const bool obstacle = present && (me.flags & HWY_F_OBSTACLE);
+  const bool veh = present && !obstacle;
+  const int V = p.V, F = p.F;
+  // altruistic penalty: sum over Road.vehicles on merge_lane, in list order (Python sum() from 0)
+  double merging = 0.0;
+  if (write_reward) {
+    const double term = veh ? (me.ts - me.v) / me.ts : 0.0;
+    for (u64 m = __ballot(veh && me.lane == np.merge_lane); m; m &= m - 1) merging = merging + wave_bcast(term, ctz64(m));
+  }
+  for (int a = 0; a < p.A; ++a) {
+    const int ia = p.agent_index[a];
+    const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
+    const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
+    const double ox = sh.lx0[wave_bcast_i(me.lane, ia)];
+    const double dxe = me.x - ex, dye = me.y - ey;
+    const double d_lane = (me.x - ox) - (ex - ox);  // observer.lane_distance_to(me)
+    const bool near = dxe * dxe + dye * dye < p.perception * p.perception;
+    const bool elig = present && near && (obstacle ? (-2 * HWY_VEH_LENGTH < d_lane)
+                                                   : (i != ia && ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane))));
+    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    const int n_elig = __popcll(__ballot(elig));
+    const int m = n_elig < V - 1 ? n_elig : V - 1;
+    int pos = 0;  // stable sort position; obstacles sit after every vehicle slot, so slot order == list order
+    for (u64 em = __ballot(elig); em; em &= em - 1) {
+      const int k = ctz64(em);
+      const double kk = wave_bcast(key, k);
+      pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+    }
+    if (p.obs) {
+      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
+      if (present && row >= 0) {
+        for (int f = 0; f < F; ++f) {
+          const int fid = p.feat[f];
+          double val = EnvBlock<1>::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
+          const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+          if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
+            const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+            val -= origin;
+          }
+          if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
+            const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+            const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+            if (r0 > -__builtin_inf()) {
+              val = lmap(val, r0, r1, -1.0, 1.0);
+              if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
+            }
+          }
+          out[row * F + f] = (float)val;
+        }
+      }
+      for (int t = i; t < V * F; t += 64)
+        if (t / F > m) out[t] = 0.0f;
+    }
+    if (write_reward && i == ia) {
+      const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
+      const int act = p.actions ? p.actions[(size_t)e * p.A + a] : HWY_IDLE;
+      const double scaled_speed = lmap(me.v, p.rs0, p.rs1, 0.0, 1.0);
+      double reward = 0.0;
+      reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
+      reward = reward + p.right_lane_reward * ((double)sh.lid[me.lane] / 1);
+      reward = reward + p.high_speed_reward * scaled_speed;
+      reward = reward + np.lane_change_reward * ((act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) ? 1.0 : 0.0);
+      reward = reward + np.merging_speed_reward * merging;
+      reward = lmap(reward, p.collision_reward + np.merging_speed_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
+      p.reward[(size_t)e * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      if (a == 0) {
+        const bool term = crashed || (me.x > np.merge_end_x);  // merge_env.py:77-79 / :365-369
+        const double t = p.st.time[e] + p.policy_dt;
+        const bool trunc = t >= p.duration;  // duration == +inf: MergeEnv never truncates (merge_env.py:81-82)
+        p.st.time[e] = t;
+        p.terminated[e] = term ? 1 : 0;
+        p.truncated[e] = trunc ? 1 : 0;
+        if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+      }
+    }
+  }
+}
+
+__device__ inline void net_load_table(const NetParams &np, NetShared &sh) {
+  const int i = threadIdx.x;
+  if (i < np.n_lanes) {
+    const hwy_lane &l = np.lane[i];
+    sh.lx0[i] = l.x0; sh.ly0[i] = l.y0; sh.llen[i] = l.length; sh.lwid[i] = l.width; sh.lamp[i] = l.amplitude;
+    sh.lpuls[i] = l.pulsation; sh.lphase[i] = l.phase; sh.llimit[i] = l.speed_limit;
+    sh.lroad[i] = l.road; sh.lid[i] = l.id; sh.lfirst[i] = l.road_first; sh.lcount[i] = l.road_lanes;
+    sh.lnext[i] = l.next_first; sh.lnextn[i] = l.next_lanes; sh.lforb[i] = l.forbidden;
+  }
+  __syncthreads();
+}
+
+// ---- device-side spawn: MergeEnv._make_vehicles (merge_env.py:162-187) / MergeGenericEnv._make_vehicles
+//      (:320-363) on Philox uniforms (NOT numpy's stream; the stream-identical reset is highwayenv_amd/merge.py).
+//      Slot layout as in merge.py: [ego, traffic (A-1 of them controlled), merging vehicle, obstacle]. --------------
+__device__ inline void net_spawn_env(const NetParams &np, NetShared &sh, uint64_t seed, uint32_t episode, Veh &o) {
+  const StepParams &p = np.s;
+  const int i = threadIdx.x;
+  const int N = p.N, lanes = p.L;
+  const int n_traffic = N - 3;
+  const bool generic = np.generic != 0;
+  const double w = 4.0;
+  // traffic positions: thread 0 replays the sequential rejection sampling (each try consumes one Philox block)
+  double *pos = sh.scratch;  // [n_traffic] longitudinal or -1 (gave up)
+  int *lane_of = sh.idx;     // [n_traffic]
+  if (generic && i == 0) {
+    const double max_pos = sh.lx0[2 * lanes] + sh.llen[2 * lanes];  // pre + converge + parallel
+    for (int k = 0; k < n_traffic; ++k) {
+      pos[k] = -1.0;
+      lane_of[k] = 0;
+      for (int t = 0; t < 10; ++t) {
+        double u_lane, u_pos;
+        philox_uniform2(seed, (uint32_t)(k + 1), episode, (uint32_t)t, &u_lane, &u_pos);
+        int L = (int)(u_lane * lanes);
+        L = L > lanes - 1 ? lanes - 1 : L;
+        const double lon = 0.0 + (max_pos - 0.0) * u_pos;
+        bool ok = !(L == lanes - 1) || fabs(lon - 30.0) > 15.0;  // the ego sits at 30 m on the last lane
+        for (int q = 0; q < k && ok; ++q)
+          if (pos[q] >= 0 && lane_of[q] == L && !(fabs(lon - pos[q]) > 15.0)) ok = false;
+        if (ok) {
+          pos[k] = lon;
+          lane_of[k] = L;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  o = Veh{};
+  o.ch = 1.0;
+  o.sh = 0.0;
+  o.rank = i & 0xff;
+  o.flags = HWY_F_ABSENT;
+  double x = 0, y = 0, speed = 0, ts = -1;
+  bool exists = false, controlled = false;
+  if (i == 0) {  // ego on ("a","b",lanes-1) at s = 30, speed 30
+    x = 30.0; y = (lanes - 1) * w; speed = 30.0; exists = true; controlled = true;
+  } else if (i <= n_traffic) {
+    const int k = i - 1;
+    double u0, u1;
+    philox_uniform2(seed, (uint32_t)i, episode, 100u, &u0, &u1);
+    if (generic) {
+      if (pos[k] >= 0) {
+        x = pos[k]; y = lane_of[k] * w; speed = 30.0 + (-2.0 + (2.0 - -2.0) * u0); exists = true;
+      }
+    } else {  // (90, 29), (70, 31), (5, 31.5): lane = integers(2), position += uniform(-5, 5), speed += uniform(-1, 1)
+      double u2, u3;
+      philox_uniform2(seed, (uint32_t)i, episode, 101u, &u2, &u3);
+      const double bp = k == 0 ? 90.0 : (k == 1 ? 70.0 : 5.0), bs = k == 0 ? 29.0 : (k == 1 ? 31.0 : 31.5);
+      int L = (int)(u2 * 2);
+      L = L > 1 ? 1 : L;
+      x = bp + (-5.0 + (5.0 - -5.0) * u0); y = L * w; speed = bs + (-1.0 + (1.0 - -1.0) * u1); exists = true;
+    }
+    controlled = exists && i < p.A;
+  } else if (i == N - 2) {  // merging vehicle on ("j","k",0)
+    const int jk = np.n_lanes - 2;
+    x = generic ? 30.0 + 30 : 110.0; y = sh.ly0[jk]; speed = 20.0; ts = 30.0; exists = true;
+  } else if (i == N - 1) {  // Obstacle at the end of the acceleration lane ("b","c",lanes)
+    const int acc = 2 * lanes;
+    o.x = sh.lx0[acc] + sh.llen[acc]; o.y = sh.ly0[acc];
+    o.flags = HWY_F_OBSTACLE | HWY_F_CHECK_COLLISIONS;
+  }
+  if (exists) {
+    o.x = x; o.y = y; o.v = speed;
+    if (controlled) {
+      const double xs = (speed - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+      o.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
+      o.ts = p.target_speeds[o.sidx];
+      o.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
+    } else {
+      o.ts = ts > 0 ? ts : speed;
+      o.timer = py_mod_pos((o.x + o.y) * HWY_PI, HWY_LC_DELAY);
+      o.delta = 4.0;  // IDMVehicle.DELTA class default: no randomize_behavior in the merge scenarios
+      o.flags = HWY_F_CHECK_COLLISIONS;
+    }
+  }
+  // lane_index = get_closest_lane_index(position, heading 0) for everything that exists (objects.py:46-51)
+  const int cl = net_closest_lane(sh, np.n_lanes, o.x, o.y, 0.0);
+  if (!(o.flags & HWY_F_ABSENT)) o.lane = o.tgt = cl;
+  __syncthreads();
+}
+
+// =============================================================================================================
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams np) {
+  const StepParams &p = np.s;
+  __shared__ NetShared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  const int N = p.N;
+  net_load_table(np, sh);
+
+  // ---- auto-reset --------------------------------------------------------------------------------------------
+  if (p.autoreset && p.st.done[e]) {
+    Veh me;
+    const uint32_t episode = p.st.episode[e] + 1u;
+    net_spawn_env(np, sh, p.rp.base_seed + (uint64_t)e, episode, me);
+    net_observe(np, sh, e, me, false);
+    store_vehicle<1>(p, e, me);
+    if (i < p.A) {  // agent a == slot a
+      p.reward[(size_t)e * p.A + i] = 0.0;
+      if (p.info_speed) p.info_speed[(size_t)e * p.A + i] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + i] = 0;
+    }
+    if (i == 0) {
+      p.st.time[e] = 0.0;
+      p.st.done[e] = 0;
+      p.st.episode[e] = episode;
+      p.terminated[e] = 0;
+      p.truncated[e] = 0;
+    }
+    return;
+  }
+
+  Veh me;
+  load_vehicle<1>(p, e, me);
+  const bool present = i < N && !(me.flags & HWY_F_ABSENT);
+  const bool obstacle = present && (me.flags & HWY_F_OBSTACLE);
+  const bool veh = present && !obstacle;
+  const bool controlled = veh && (me.flags & HWY_F_CONTROLLED);
+  const bool idm = veh && !controlled;
+  const u64 pm = __ballot(present);
+  const int n_present = __popcll(pm);
+  int agent = 0;
+  if (controlled)
+    for (int a = 0; a < p.A; ++a)
+      if (p.agent_index[a] == i) agent = a;
+  const bool i_check = present && (me.flags & HWY_F_CHECK_COLLISIONS);
+  const u64 chk = __ballot(i_check);
+  const double my_hl = obstacle ? 1.0 : HWY_VEH_LENGTH / 2, my_hw = obstacle ? 1.0 : HWY_VEH_WIDTH / 2;
+
+  for (int fr = 0; fr < p.n_frames; ++fr) {
+    // ---- A. meta-actions of all agents (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315;
+    //         ControlledVehicle.act starts with follow_road, :98) ---------------------------------------------
+    if (fr == 0 && p.actions && controlled) {
+      const int act = p.actions[(size_t)e * p.A + agent];
+      me.tgt = net_follow_road(sh, me.tgt, me.x, me.y);
+      if (act == HWY_FASTER || act == HWY_SLOWER) {
+        const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+        int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
+        idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
+        me.sidx = idx;
+        me.ts = p.target_speeds[idx];
+      } else if (act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) {
+        int id = sh.lid[me.tgt] + (act == HWY_LANE_RIGHT ? 1 : -1);
+        id = id < 0 ? 0 : (id > sh.lcount[me.tgt] - 1 ? sh.lcount[me.tgt] - 1 : id);
+        const int cand = sh.lfirst[me.tgt] + id;
+        if (net_reachable(sh, cand, me.x, me.y)) me.tgt = cand;
+      }
+    }
+
+    // ---- B. rank along x, lane membership masks, frame-start snapshot ----------------------------------------
+    int rank;
+    bool has_tie;
+    net_rank(me.x, present, pm, rank, has_tie);
+    int bits = 0;
+    for (int L = 0; L < np.n_lanes; ++L) {  // AbstractLane.on_lane(margin=1), lane.py:80-102
+      const double s = me.x - sh.lx0[L];
+      double lat = me.y - sh.ly0[L];
+      const double amp = sh.lamp[L];
+      if (amp != 0.0) {  // wave-uniform
+        double sn, cs;
+        sincos_bounded(sh.lpuls[L] * s + sh.lphase[L], &sn, &cs);
+        lat = lat - amp * sn;
+      }
+      const bool on = present && fabs(lat) <= sh.lwid[L] / 2 + 1.0 && -5.0 <= s && s < sh.llen[L] + 5.0;
+      bits |= on ? (1 << L) : 0;
+    }
+    const int sorted_bits = wave_send_i(bits, rank);
+    u64 m_pub = 0;
+    for (int L = 0; L < np.n_lanes; ++L) {
+      const u64 b = __ballot((sorted_bits >> L) & 1) & (n_present >= 64 ? ~(u64)0 : (((u64)1 << n_present) - 1));
+      m_pub = (i == L) ? b : m_pub;
+    }
+    const double log_ratio = veh ? net_log_ratio(me.v, me.ts, sh.llimit[me.lane]) : 0.0;
+    __syncthreads();
+    if (present) {
+      sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
+      sh.ox[rank] = sh.lx0[me.lane];
+      sh.idx[rank] = i;
+      sh.kind[rank] = veh ? 1 : 0;
+    }
+    if (i < np.n_lanes) sh.lane_mask[i] = m_pub;
+    __syncthreads();
+
+    // ---- C. Road.act -------------------------------------------------------------------------------------------
+    const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
+    const bool drives = idm && !crashed0;  // IDMVehicle.act returns early when crashed (behavior.py:102-103)
+    const int tgt_old = me.tgt;            // what vehicles later in the list read from me (abort rule)
+    // follow_road for every acting vehicle (behavior.py:106, controller.py:98)
+    if (drives || controlled) me.tgt = net_follow_road(sh, me.tgt, me.x, me.y);
+    const int tgt_f = me.tgt;
+    const bool changer = drives && me.lane != tgt_f;
+    const bool same_road = sh.lroad[me.lane] == sh.lroad[tgt_f];
+    const bool decide = drives && me.lane == tgt_f && (HWY_LC_DELAY < me.timer);
+    if (idm) me.timer = (decide ? 0.0 : me.timer) + p.dt;  // behavior.py:248, then :147
+    // side lanes of my current lane (road.py:200-211): same road, id -+ 1 == table index -+ 1
+    const int my_id = sh.lid[me.lane], my_cnt = sh.lcount[me.lane];
+    const bool left_ok = my_id - 1 >= 0, right_ok = my_id + 1 < my_cnt;
+    const int L_left = left_ok ? me.lane - 1 : me.lane, L_right = right_ok ? me.lane + 1 : me.lane;
+    const double ox_me = sh.lx0[me.lane];
+    // neighbours (ranks) on own / left / right / target lane
+    int fo = -1, ro = -1, fl = -1, rl = -1, frt = -1, rrt = -1, ft = -1, rt_ = -1;
+    if (!has_tie) {  // wave-uniform
+      mask_neighbours(sh.lane_mask[me.lane], rank, &fo, &ro);
+      mask_neighbours(sh.lane_mask[L_left], rank, &fl, &rl);
+      mask_neighbours(sh.lane_mask[L_right], rank, &frt, &rrt);
+      mask_neighbours(sh.lane_mask[tgt_f], rank, &ft, &rt_);
+    } else {
+      int a, b, q[8];
+      net_neighbours_scan(sh, pm, bits, me.x, i, me.lane, &a, &b); q[0] = a; q[1] = b;
+      net_neighbours_scan(sh, pm, bits, me.x, i, L_left, &a, &b); q[2] = a; q[3] = b;
+      net_neighbours_scan(sh, pm, bits, me.x, i, L_right, &a, &b); q[4] = a; q[5] = b;
+      net_neighbours_scan(sh, pm, bits, me.x, i, tgt_f, &a, &b); q[6] = a; q[7] = b;
+      int r8[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+      for (u64 m = pm; m; m &= m - 1) {  // slot index -> rank
+        const int j = ctz64(m);
+        const int rk = wave_bcast_i(rank, j);
+        for (int k = 0; k < 8; ++k) r8[k] = (q[k] == j) ? rk : r8[k];
+      }
+      fo = r8[0]; ro = r8[1]; fl = r8[2]; rl = r8[3]; frt = r8[4]; rrt = r8[5]; ft = r8[6]; rt_ = r8[7];
+    }
+    (void)ro; (void)rt_;
+    const double delta = me.delta;
+    const double free_self = EnvBlock<1>::idm_free_from_log(log_ratio, delta);
+    // IDM interaction term behind the leader at rank r (an Obstacle leader has speed 0, heading 0)
+#define HWY_NET_GAP(r) \
+  ((r) >= 0 ? net_gap_term((sh.x[(r)] - ox_me) - (me.x - ox_me), me.v, me.ch, me.sh, sh.v[(r)], sh.c[(r)], sh.s[(r)]) : 0.0)
+    const double gap_own = HWY_NET_GAP(fo);
+    const double self_a = free_self - gap_own;
+    // MOBIL (behavior.py:265-324), both side lanes; the right one wins if both pass (side_lanes order, no break)
+    const bool moving = !(fabs(me.v) < 1);
+    const bool cl = decide && left_ok && moving && net_reachable(sh, L_left, me.x, me.y);
+    const bool cr = decide && right_ok && moving && net_reachable(sh, L_right, me.x, me.y);
+    bool ok_l = cl && !(((free_self - HWY_NET_GAP(fl)) - self_a) < HWY_LC_MIN_ACC_GAIN);
+    bool ok_r = cr && !(((free_self - HWY_NET_GAP(frt)) - self_a) < HWY_LC_MIN_ACC_GAIN);
+    {
+      // safety: the new follower (a Vehicle: an Obstacle "follower" accelerates 0, behavior.py:168-169) must not
+      // brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED; its lane distance is measured on ITS current lane
+      bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
+      while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
+        if (pend_l || pend_r) {
+          const bool left = pend_l;
+          const int rf = left ? rl : rrt;
+          const double oxf = sh.ox[rf];
+          const double a_f = sh.kind[rf] ? EnvBlock<1>::idm_free_from_log(sh.lr[rf], delta) -
+                                               net_gap_term((me.x - oxf) - (sh.x[rf] - oxf), sh.v[rf], sh.c[rf], sh.s[rf],
+                                                            me.v, me.ch, me.sh)
+                                         : 0.0;
+          const bool safe = !(a_f < -HWY_LC_MAX_BRAKING);
+          if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
+        }
+      }
+    }
+    if (ok_l) me.tgt = L_left;
+    if (ok_r) me.tgt = L_right;
+    // abort rule for ongoing lane changes on the same road: ordered chain over Road.vehicles (behavior.py:229-244)
+    {
+      u64 cm = __ballot(changer && same_road);
+      while (cm) {  // wave-uniform
+        const int ci = ctz64(cm);
+        cm &= cm - 1;
+        const int Tc = wave_bcast_i(tgt_f, ci);
+        const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
+        const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
+        const double oxc = wave_bcast(ox_me, ci);
+        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+        bool blk = false;
+        if (veh && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+          const double d = (me.x - oxc) - (xc - oxc);
+          const double d_star = EnvBlock<1>::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
+          blk = (0 < d) && (d < d_star);
+        }
+        // `break` at the first hit does not change the outcome: the target is reset once
+        if (__ballot(blk) != 0 && i == ci) me.tgt = me.lane;
+      }
+    }
+
+    // ---- D. low-level control: steering towards the target lane, IDM / speed control --------------------------
+    const double inv_v = fast_rcp(not_zero(me.v));
+    double tb;
+    {
+      const double s_t = me.x - sh.lx0[me.tgt];
+      const double lat_t = net_lat(sh, me.tgt, s_t, me.y);
+      const double head_t = net_heading_at(sh, me.tgt, s_t + me.v * (0.5 * 0.2));  // TAU_PURSUIT = 0.5 * TAU_HEADING
+      tb = net_steer_tan_beta(lat_t, head_t, me.h, inv_v);
+    }
+    double accel = free_self - gap_own;
+    if (drives && me.lane != me.tgt) {
+      // leader on the target lane: tgt_f's mask for an ongoing change, the side lane's for a decision just taken
+      const int f2 = (me.tgt == tgt_f) ? ft : (me.tgt == L_left ? fl : frt);
+      const double a2 = free_self - HWY_NET_GAP(f2);
+      accel = (a2 < accel) ? a2 : accel;
+    }
+#undef HWY_NET_GAP
+    accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
+    accel = controlled ? HWY_KP_A * (me.ts - me.v) : accel;
+
+    // ---- E. Road.step: integrate (kinematics.py:130-177) ------------------------------------------------------
+    const double x_old = me.x;
+    if (veh) {
+      if (!(drives || controlled)) {  // a crashed IDM vehicle keeps its previous action, then clip_actions overrides it
+        tb = 0.0;
+      }
+      tb = crashed0 ? 0.0 : tb;
+      accel = crashed0 ? -1.0 * me.v : accel;
+      accel = (me.v > HWY_MAX_SPEED) ? fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v))
+                                     : ((me.v < HWY_MIN_SPEED) ? fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v)) : accel);
+      const double cb = fast_rsqrt(1.0 + tb * tb), sb = tb * cb;
+      const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
+      me.x += vx * p.dt;
+      me.y += vy * p.dt;
+      if (me.flags & HWY_F_HAS_IMPACT) {
+        me.x += me.impx;
+        me.y += me.impy;
+        me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
+        me.impx = me.impy = 0.0;
+      }
+      me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
+      me.v += accel * p.dt;
+      sincos_bounded(me.h, &me.sh, &me.ch);
+    }
+    {
+      const int cl_new = net_closest_lane(sh, np.n_lanes, me.x, me.y, me.h);  // on_state_update
+      if (veh) me.lane = cl_new;
+    }
+
+    // ---- F. Road.step: collisions (road.py:477-481, objects.py:92-138) ----------------------------------------
+    // Outward scan in rank order bounded by the frame-start distance, like hwy_wave.h; "last pair in loop
+    // order wins" == the partner with the highest slot (the obstacle, being last, beats every vehicle).
+    sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
+    __syncthreads();
+    if (present) {
+      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, my_hl, my_hw};
+      const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      int best = -1;
+      for (int dir = -1; dir <= 1; dir += 2) {
+        for (int r2 = rank + dir; r2 >= 0 && r2 < n_present; r2 += dir) {
+          if (fabs(sh.x[r2] - x_old) > reach) break;
+          const int q = sh.idx[r2];
+          const bool q_obs = sh.kind[r2] == 0;
+          if (obstacle && q_obs) continue;  // road.py:477-481: vehicle-vehicle and vehicle-object pairs only
+          const NetBody other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
+                              q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
+          const double dx = other.x - me.x, dy = other.y - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
+          if (dx * dx + dy * dy > lim * lim) continue;
+          if (!(i_check || ((chk >> q) & 1))) continue;  // objects.py:98
+          const bool i_first = i < q;
+          const NetBody A = select_nbody(i_first, mine, other), Bb = select_nbody(i_first, other, mine);
+          if (net_surely_apart(A, Bb, p.dt)) continue;
+          double tx, ty;
+          const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
+          if ((r & 2) && q > best && veh) {
+            best = q;
+            // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
+            const double share = q_obs ? 1.0 : 0.5;
+            me.impx = i_first ? tx * share : -tx * share;
+            me.impy = i_first ? ty * share : -ty * share;
+            me.flags |= HWY_F_HAS_IMPACT;
+          }
+          if (r & 1) me.flags |= HWY_F_CRASHED;
+        }
+      }
+    }
+  }  // frames
+
+  // ---- G. observe / reward / done ------------------------------------------------------------------------------
+  if (p.full_step) net_observe(np, sh, e, me, true);
+  {
+    // rank hint for the next step is not used by this kernel; keep the slot index
+    me.rank = i & 0xff;
+    store_vehicle<1>(p, e, me, false);
+  }
+}
+
+// Reset kernel: AbstractEnv.reset for the masked environments + first observation.
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_net_reset_kernel(const NetParams np) {
+  const StepParams &p = np.s;
+  __shared__ NetShared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  net_load_table(np, sh);
+  if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
+  Veh me;
+  const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
+  net_spawn_env(np, sh, seed, 0u, me);
+  net_observe(np, sh, e, me, false);
+  store_vehicle<1>(p, e, me);
+  if (i == 0) {
+    p.st.time[e] = 0.0;
+    p.st.done[e] = 0;
+    p.st.episode[e] = 0;
+  }
+}
+
+// Observation-only kernel (hwy_observe).
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_net_observe_kernel(const NetParams np) {
+  __shared__ NetShared sh;
+  net_load_table(np, sh);
+  Veh me;
+  load_vehicle<1>(np.s, blockIdx.x, me);
+  net_observe(np, sh, blockIdx.x, me, false);
+}
+
+}  // namespace hwy

@@ -32,6 +32,20 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   }
 }
 
+// road-network scenarios: the lane table and merge reward / termination constants next to the StepParams
+template <typename NP>
+inline void net_params_from_config(const hwy_config &c, const StepParams &p, NP &np) {
+  std::memset(&np, 0, sizeof np);
+  np.s = p;
+  np.n_lanes = c.net_lanes;
+  np.merge_lane = c.merge_lane;
+  np.generic = c.scenario == HWY_SCENARIO_MERGE_GENERIC ? 1 : 0;
+  np.merge_end_x = c.merge_end_x;
+  np.merging_speed_reward = c.merging_speed_reward;
+  np.lane_change_reward = c.lane_change_reward;
+  for (int k = 0; k < HWY_MAX_LANES; ++k) np.lane[k] = c.net[k];
+}
+
 // observation length per agent: V*F (Kinematics) or F*W*H (OccupancyGrid)
 inline size_t obs_len(const hwy_config &c) {
   return c.obs_type == HWY_OBS_OCCUPANCY_GRID ? (size_t)c.obs_features * c.grid_shape[0] * c.grid_shape[1]

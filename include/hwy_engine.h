@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HWY_ABI_VERSION 2
+#define HWY_ABI_VERSION 3
 
 #define HWY_MAX_AGENTS 16
 #define HWY_MAX_FEATURES 16
@@ -60,7 +60,13 @@ enum {
   HWY_F_CRASHED = 1,          /* RoadObject.crashed            vehicle/objects.py:64  */
   HWY_F_HAS_IMPACT = 2,       /* Vehicle.impact is not None    vehicle/kinematics.py:47,145-148 */
   HWY_F_CHECK_COLLISIONS = 4, /* RoadObject.check_collisions   vehicle/objects.py:61 (HighwayEnvFast clears it, highway_env.py:177-182) */
-  HWY_F_CONTROLLED = 8        /* MDPVehicle (ego) instead of IDMVehicle */
+  HWY_F_CONTROLLED = 8,       /* MDPVehicle (ego) instead of IDMVehicle */
+  /* road-network scenarios (hwy_config.scenario != HWY_SCENARIO_HIGHWAY) only: */
+  HWY_F_OBSTACLE = 16,        /* the slot is an Obstacle of Road.objects (vehicle/objects.py:215-222): 2 m x 2 m,
+                                 never acts or moves; slots of obstacles come AFTER every vehicle slot, like
+                                 `self.vehicles + self.objects` in road.py:531 */
+  HWY_F_ABSENT = 32           /* empty slot: MergeGenericEnv's rejection-sampled spawn (merge_env.py:336-352)
+                                 creates a different number of vehicles per episode */
 };
 
 /* config flag bits (hwy_config.flags) */
@@ -87,6 +93,36 @@ enum {
 /* observation types (hwy_config.obs_type) */
 enum { HWY_OBS_KINEMATICS = 0, HWY_OBS_OCCUPANCY_GRID = 1 };
 
+/* scenarios (hwy_config.scenario) */
+enum {
+  HWY_SCENARIO_HIGHWAY = 0, /* HighwayEnv / HighwayEnvFast: one straight road, lanes_count lanes (highway_env.py:59-70) */
+  HWY_SCENARIO_MERGE = 1,   /* MergeEnv: x-aligned road network in hwy_config.net (merge_env.py:90-160), 3 + 1 traffic vehicles */
+  HWY_SCENARIO_MERGE_GENERIC = 2 /* MergeGenericEnv (merge_env.py:233-363): same kernels, rejection-sampled spawn */
+};
+
+/*
+ * One lane of an x-aligned RoadNetwork (road/road.py:16-38): StraightLane (road/lane.py:150-233) when
+ * amplitude == 0, else SineLane (road/lane.py:236-283).  direction == (1, 0) for every lane, so
+ * local_coordinates(p) = (p.x - x0, p.y - y0 [- amplitude*sin(pulsation*(p.x - x0) + phase)]).
+ * Table order == iteration order of RoadNetwork.get_closest_lane_index (road.py:55-71: graph[from][to][id]),
+ * which is what its argmin tie-break depends on; lanes of one road (from, to) are consecutive, ordered by id.
+ */
+typedef struct hwy_lane {
+  double x0, y0;                      /* lane.start */
+  double length;                      /* |end - start| */
+  double width;                       /* AbstractLane.DEFAULT_WIDTH = 4 */
+  double amplitude, pulsation, phase; /* SineLane; amplitude == 0 => StraightLane */
+  double speed_limit;                 /* lane.speed_limit (20 unless given, lane.py:166) */
+  int32_t road;                       /* id of the (from, to) pair */
+  int32_t id;                         /* lane id on that road: lane_index[2] */
+  int32_t road_first;                 /* table index of lane 0 of the same road */
+  int32_t road_lanes;                 /* len(graph[from][to]) */
+  int32_t next_first;                 /* table index of lane 0 of the road that starts at `to`, -1 if none */
+  int32_t next_lanes;                 /* its lane count (RoadNetwork.next_lane, road.py:73-127) */
+  int32_t forbidden;                  /* lane.forbidden (is_reachable_from, lane.py:110-111) */
+  int32_t reserved;
+} hwy_lane;
+
 /* meta-actions: DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:204 */
 enum { HWY_LANE_LEFT = 0, HWY_IDLE = 1, HWY_LANE_RIGHT = 2, HWY_FASTER = 3, HWY_SLOWER = 4 };
 
@@ -101,7 +137,7 @@ typedef struct hwy_config {
   int32_t num_vehicles;                /* N = vehicles_count + controlled_vehicles */
   int32_t num_agents;                  /* A = controlled_vehicles */
   int32_t agent_index[HWY_MAX_AGENTS]; /* index of each controlled vehicle in the vehicle list */
-  int32_t lanes_count;                 /* L: lane k is centred on y = k*lane_width (road.py:291-321) */
+  int32_t lanes_count;                 /* L: lane k is centred on y = k*lane_width (road.py:291-321); merge: highway lanes */
   int32_t frames_per_step;             /* T = simulation_frequency // policy_frequency (abstract.py:289-291) */
   int32_t flags;                       /* HWY_C_* */
   int32_t obs_vehicles;                /* V = observation.vehicles_count */
@@ -127,6 +163,16 @@ typedef struct hwy_config {
   int32_t reserved1;
   double grid_min[2];                  /* grid_size[:,0] */
   double grid_step[2];                 /* grid_step */
+  /* road-network scenarios (ABI v3).  scenario == HWY_SCENARIO_HIGHWAY ignores everything below. */
+  int32_t scenario;                    /* HWY_SCENARIO_* */
+  int32_t net_lanes;                   /* entries used in net[] (<= HWY_MAX_LANES) */
+  int32_t merge_lane;                  /* table index of ("b","c",2) -- literally id 2, merge_env.py:72 -- whose vehicles
+                                          pay the altruistic penalty of MergeEnv._rewards (:68-75); -1 if absent */
+  int32_t reserved2;
+  double merge_end_x;                  /* _is_terminated: ego x > 370 (merge_env.py:79) / end_position (:369) */
+  double merging_speed_reward;         /* merge_env.py:35 */
+  double lane_change_reward;           /* merge_env.py:36 */
+  hwy_lane net[HWY_MAX_LANES];
 } hwy_config;
 
 /*
@@ -143,8 +189,8 @@ typedef struct hwy_state {
   double *target_speed;                 /* ControlledVehicle.target_speed        controller.py:47 */
   double *delta;                        /* IDMVehicle.DELTA (randomize_behavior) behavior.py:66-69 */
   double *impact_x, *impact_y;          /* Vehicle.impact (valid iff HWY_F_HAS_IMPACT) */
-  int32_t *lane;                        /* lane_index[2]                         */
-  int32_t *target_lane;                 /* target_lane_index[2]                  */
+  int32_t *lane;                        /* lane_index[2]; road-network scenarios: index into hwy_config.net */
+  int32_t *target_lane;                 /* target_lane_index[2]; likewise        */
   int32_t *speed_index;                 /* MDPVehicle.speed_index (controlled vehicles) */
   int32_t *flags;                       /* HWY_F_* */
   double *time;                         /* AbstractEnv.time [E]                  abstract.py:274 */

@@ -25,6 +25,7 @@ inline double noisy(double v) {
 #endif
 #include "../../highwayenv_amd/csrc/hwy_device.h"
 #include "../../highwayenv_amd/csrc/hwy_wave.h"
+#include "../../highwayenv_amd/csrc/hwy_net.h"
 #include "../../highwayenv_amd/csrc/hwy_params.h"
 
 using hwy::StepParams;
@@ -57,8 +58,19 @@ struct HostImage {
 
 enum Which { STEP, RESET, OBSERVE };
 bool g_force_block = false;
+const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road-network scenarios need the lane table)
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
+  if (g_cfg && g_cfg->scenario != HWY_SCENARIO_HIGHWAY) {  // same dispatch rule as hwy_engine.hip
+    hwy::NetParams np;
+    hwy::net_params_from_config(*g_cfg, p, np);
+    switch (which) {
+      case STEP: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1>(q); }, E, 64, np); break;
+      case RESET: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_reset_kernel<1>(q); }, E, 64, np); break;
+      case OBSERVE: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_observe_kernel<1>(q); }, E, 64, np); break;
+    }
+    return;
+  }
   if (which == STEP && nw == 1 && !g_force_block) {  // same dispatch rule as hwy_kernels.hip
     if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, false>(q); }, E, 64, p);
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
@@ -97,6 +109,7 @@ int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episo
             uint8_t *crashed, int autoreset, uint64_t base_seed, double ego_spacing, double vehicles_density,
             int initial_lane_id) {
   HostImage img(*cfg, *st);
+  g_cfg = cfg;
   StepParams p;
   hwy::params_from_config(*cfg, cfg->num_vehicles, p);
   hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);
@@ -130,6 +143,7 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
               const uint64_t *seeds, uint64_t base_seed, double ego_spacing, double vehicles_density,
               int initial_lane_id, float *obs) {
   HostImage img(*cfg, *st);
+  g_cfg = cfg;
   StepParams p;
   hwy::params_from_config(*cfg, cfg->num_vehicles, p);
   hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);

@@ -1,0 +1,85 @@
+"""Pin the road-network C oracle (oracle/hwy_oracle_net.c) against traces of the unmodified reference's
+MergeEnv / MergeGenericEnv, and the product's own lane table + stream-identical reset against the
+reference's RoadNetwork and reset(seed=s).
+
+CPU only.  Golden fixtures: tests/golden/merge_*.npz (tests/golden/make_golden_merge.py).
+Tolerances as in test_oracle_golden.py: f64 with glibc libm vs numpy's libm; flags / lane indices exact.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi, merge
+from oracle import oracle
+from tests.golden_util import MERGE, GoldenMerge, assert_net_state_close
+
+
+@pytest.mark.parametrize("name", MERGE)
+def test_lane_table_is_the_reference_network(name):
+    """hwy_config.net built by highwayenv_amd.merge == the reference's RoadNetwork, bit for bit, in
+    get_closest_lane_index order (road.py:55-71)."""
+    g = GoldenMerge(name)
+    c = g.hwy_config()
+    tab = merge.table_from_config(c)
+    for k in _abi.LANE_F64 + _abi.LANE_I32:
+        np.testing.assert_array_equal(tab[k], g.z["lane_" + k], err_msg=k)
+    assert c.num_vehicles == g.N
+    assert c.merge_end_x == float(g.z["end_position"])
+
+
+@pytest.mark.parametrize("name", MERGE)
+def test_reset_replays_the_reference_stream(name):
+    """merge.spawn_reference_stream(seed) == the reference's reset(seed=seed), bit for bit (the reference
+    appends vehicles compactly; the engine leaves HWY_F_ABSENT slots where the spawn gave up)."""
+    g = GoldenMerge(name)
+    c = g.hwy_config()
+    st = merge.spawn_reference_stream(c, g.config, g.generic, g.seeds)
+    want = g.state("init")
+    for e in range(g.E):
+        a = (st["flags"][e] & _abi.F_ABSENT) == 0
+        b = (want["flags"][e] & _abi.F_ABSENT) == 0
+        assert a.sum() == b.sum()
+        for k in _abi.STATE_F64 + _abi.STATE_I32:
+            np.testing.assert_array_equal(st[k][e][a], want[k][e][b], err_msg=f"{name} env {e}: {k}")
+
+
+@pytest.mark.parametrize("name", MERGE)
+def test_oracle_teacher_forced_frames(name):
+    """Every single frame, started from the reference's own state: Road.act + Road.step."""
+    g = GoldenMerge(name)
+    Ef = g.frames_for
+    cfg = g.hwy_config(Ef)
+    envs = slice(0, Ef)
+    for step in range(g.steps):
+        for fr in range(g.T):
+            k = step * g.T + fr
+            st = g.state("init", envs=envs) if k == 0 else g.state("frame", k - 1)
+            acts = g.actions[step, :Ef] if fr == 0 else None
+            oracle.frames(cfg, st, acts, 1)
+            assert_net_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}")
+
+
+@pytest.mark.parametrize("name", MERGE)
+def test_oracle_free_running_steps(name):
+    """Whole episodes from the reset state, compared while the episode is live (up to and including the
+    terminal step; see DESIGN.md section 4 on post-termination wrecks)."""
+    g = GoldenMerge(name)
+    cfg = g.hwy_config()
+    st = g.state("init")
+    np.testing.assert_allclose(oracle.observe(cfg, st), g.z["obs0"], rtol=0, atol=1e-6)
+    live = np.ones(g.E, bool)
+    for t in range(g.steps):
+        obs, reward, term, trunc, info = oracle.step(cfg, st, g.actions[t])
+        what = f"{name} step {t}"
+        np.testing.assert_array_equal(term[live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
+        np.testing.assert_array_equal(trunc[live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
+        np.testing.assert_allclose(obs[live], g.z["obs"][t][live], rtol=0, atol=1e-6, err_msg=what)
+        # the reference evaluates `action in [0, 2]` on the joint action tuple (never true) when A > 1
+        ok = live & ((g.A == 1) | ~np.isin(g.actions[t, :, 0], [0, 2]))
+        np.testing.assert_allclose(reward[ok, 0], g.z["reward"][t][ok], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(info["speed"][live, 0], g.z["info_speed"][t][live], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_array_equal(info["crashed"][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
+        want = g.state("step", t)
+        sub = lambda d: {k: v[live] for k, v in d.items()}  # noqa: E731
+        assert_net_state_close(sub(st), sub(want), atol=1e-8, what=what)
+        live &= ~g.z["terminated"][t].astype(bool)
+    assert not live.all() or g.steps < 12  # the fixtures do reach termination
