@@ -47,7 +47,7 @@ def measured_traffic(envs_per_gpu: int, fast: bool = True):
     process, so the number is the one measured for the same kernel and config; None if absent or if the
     run uses another batch size."""
     path = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU or not fast:
+    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU or not fast:  # (fast is False for every non-headline workload)
         return None
     try:
         return json.load(open(path))["traffic_bytes_per_launch_calibrated"]
@@ -55,22 +55,26 @@ def measured_traffic(envs_per_gpu: int, fast: bool = True):
         return None
 
 
-def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0):
+def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: str = "highway"):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
-    from highwayenv_amd import _abi, spawn
+    from highwayenv_amd import _abi, merge, spawn
     from oracle import oracle
     E = 64 if fast else 8
-    cfg = _abi.make_config(cfg_dict, E, fast=fast)
-    st0 = spawn.spawn_reference_stream(cfg, np.arange(E) + 7, cfg_dict["ego_spacing"], cfg_dict["vehicles_density"])
+    cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario)
+    if scenario == "highway":
+        st0 = spawn.spawn_reference_stream(cfg, np.arange(E) + 7, cfg_dict["ego_spacing"], cfg_dict["vehicles_density"])
+        episode_len = int(cfg_dict["duration"])
+    else:
+        st0 = merge.spawn_reference_stream(cfg, cfg_dict, scenario == "merge-generic", np.arange(E) + 7)
+        episode_len = 8  # the ego reaches the end of the merge section (or crashes) after ~8-10 policy steps
     rng = np.random.default_rng(3)
     steps_done, t_used = 0, 0.0
     st = _abi.copy_state(st0)
-    episode_len = int(cfg_dict["duration"])
     while t_used < budget_s:
         if steps_done % episode_len == 0:
             st = _abi.copy_state(st0)  # bounded stand-in for per-env resets: restart the batch
-        acts = rng.integers(0, 5, size=(E, 1)).astype(np.int32)
+        acts = rng.integers(0, 5, size=(E, cfg.num_agents)).astype(np.int32)
         t0 = time.perf_counter()
         oracle.step(cfg, st, acts)
         t_used += time.perf_counter() - t0
@@ -78,7 +82,7 @@ def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0):
     rate = steps_done * E / t_used
     return {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{E} envs x {steps_done} policy steps of the same workload on 1 host core "
-                      f"(oracle/hwy_oracle.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
+                      f"(oracle/hwy_oracle{'' if scenario == 'highway' else '_net'}.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
             "vehicle_steps_per_s": rate * cfg.num_vehicles}
 
 
@@ -89,9 +93,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100"], default="fast",
+    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
-                         "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024)")
+                         "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024); "
+                         "merge_ma4 = BASELINE config 5 (merge-generic, 4 lanes, 40 traffic vehicles, 4 controlled agents "
+                         "per env); merge = merge-v0 defaults")
     args = ap.parse_args()
 
     import torch
@@ -119,23 +125,34 @@ def main() -> None:
     from highwayenv_amd.dist import PackedStepOutputs
 
     fast = args.workload == "fast"
+    scenario = "highway"
     if fast:
         cfg_dict = _abi.highway_fast_default_config()
         cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
+    elif args.workload in ("merge", "merge_ma4"):
+        from highwayenv_amd import merge
+        if args.workload == "merge":
+            scenario, cfg_dict = "merge", merge.merge_default_config()
+        else:
+            scenario, cfg_dict = "merge-generic", merge.merge_generic_default_config()
+            cfg_dict.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+                             "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+                             "observation": {"type": "MultiAgentObservation",
+                                             "observation_config": {"type": "Kinematics"}}})
     else:
         cfg_dict = _abi.highway_default_config()
         if args.workload == "v0_n100":
             cfg_dict.update({"vehicles_count": 100})
     E = args.envs_per_gpu
-    cfg = _abi.make_config(cfg_dict, E, fast=fast)
+    cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario)
     N, A = cfg.num_vehicles, cfg.num_agents
+    spawn_kw = ({"ego_spacing": cfg_dict["ego_spacing"], "vehicles_density": cfg_dict["vehicles_density"]}
+                if scenario == "highway" else {})
 
     stream = torch.cuda.current_stream(dev)
     eng = Engine(cfg, device=local_rank, stream=stream.cuda_stream)
-    eng.reset(base_seed=1_000_003 * (rank + 1), ego_spacing=cfg_dict["ego_spacing"],
-              vehicles_density=cfg_dict["vehicles_density"])
-    eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), ego_spacing=cfg_dict["ego_spacing"],
-                      vehicles_density=cfg_dict["vehicles_density"])
+    eng.reset(base_seed=1_000_003 * (rank + 1), **spawn_kw)
+    eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), **spawn_kw)
 
     total = args.warmup + args.steps
     g = torch.Generator(device=dev)
@@ -224,6 +241,11 @@ def main() -> None:
             "config": {"workload": (f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
                                     f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
                                     "device spawn + auto-reset") if fast else
+                                   (f"{'merge-v0' if scenario == 'merge' else 'merge-generic-v0'}, {E} envs/GPU x {N} slots "
+                                    f"({A} controlled MDP vehicles, {N - A - 2} IDM traffic slots of which the rejection-sampled "
+                                    f"spawn fills most, 1 merging IDM vehicle, 1 obstacle), {cfg.lanes_count} highway lanes + ramp "
+                                    f"({cfg.net_lanes} network lanes), {cfg.frames_per_step} frames/step, full pairwise collisions, "
+                                    f"random actions, per-agent Kinematics 5x5 obs, device spawn + auto-reset") if scenario != "highway" else
                                    (f"highway-v0, {E} envs/GPU x {N - A} IDM vehicles (+1 ego, N={N}), 4 lanes, 15 frames/step, full "
                                     "pairwise collisions, random actions, Kinematics 5x5 obs, device spawn + auto-reset"),
                        "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}"},
@@ -231,14 +253,15 @@ def main() -> None:
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E, fast),
-                         "kernel": (f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
+                         "kernel": ("hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
+                                    f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "algorithmic_bytes_per_launch": b_env * E},
             "terminated_in_last_step": int(term),
             "host_path_env_steps_per_s": host_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg_dict, fast)
+            line["cpu_baseline"] = cpu_baseline(cfg_dict, fast, scenario=scenario)
         print(json.dumps(line), flush=True)
     eng.close()
     if use_dist:

@@ -18,6 +18,7 @@ import copy
 import numpy as np
 
 from . import _abi, spawn
+from . import merge as _merge
 from .engine import Engine
 
 try:  # optional: only to expose real spaces when gymnasium is installed
@@ -79,6 +80,8 @@ class BatchedHighwayEnv:
 
     #: ``HighwayEnvFast`` semantics (ego-only collision checks, highway_env.py:177-182)
     FAST = False
+    #: "highway" | "merge" | "merge-generic" (``_abi.make_config``)
+    SCENARIO = "highway"
     PERCEPTION_DISTANCE = 5.0 * 40.0
     #: the HIP engine; tests substitute the CPU emulation of the same kernel source
     _engine_factory = staticmethod(lambda cfg, device, stream: Engine(cfg, device=device, stream=stream))
@@ -113,7 +116,7 @@ class BatchedHighwayEnv:
             self.config.update(config)
 
     def _define_spaces(self):
-        hc = _abi.make_config(self.config, self.num_envs, fast=self.FAST)
+        hc = _abi.make_config(self.config, self.num_envs, fast=self.FAST, scenario=self.SCENARIO)
         self._hcfg = hc
         A = hc.num_agents
         self.single_observation_shape = _abi.obs_shape(hc) if A == 1 else (A, *_abi.obs_shape(hc))
@@ -149,24 +152,18 @@ class BatchedHighwayEnv:
             seeds = list(seed)
             if len(seeds) != E:
                 raise ValueError("one seed per env expected")
-        cfg = self.config
-        lane_id = cfg["initial_lane_id"]
         if self.spawn_mode == "reference":
             for e, s in enumerate(seeds):
                 if s is not None or self.np_random[e] is None:
                     # gymnasium.utils.seeding.np_random(seed): Generator(PCG64(SeedSequence(seed)))
                     self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
-            st = spawn.spawn_reference_stream(self._hcfg, self.np_random, cfg["ego_spacing"], cfg["vehicles_density"],
-                                              lane_id)
-            eng.set_state(st)
+            eng.set_state(self._spawn_reference(self.np_random))
             obs = eng.observe()
         else:
             sd = np.array([np.random.SeedSequence(s).generate_state(1, np.uint64)[0] if s is None else s
                            for s in seeds], np.uint64)
-            obs = eng.reset(seeds=sd, ego_spacing=cfg["ego_spacing"], vehicles_density=cfg["vehicles_density"],
-                            initial_lane_id=-1 if lane_id is None else lane_id)
-        eng.set_autoreset(self.autoreset, base_seed=int(seeds[0] or 0) + 0x9E3779B9, ego_spacing=cfg["ego_spacing"],
-                          vehicles_density=cfg["vehicles_density"], initial_lane_id=-1 if lane_id is None else lane_id)
+            obs = eng.reset(seeds=sd, **self._device_spawn_args())
+        eng.set_autoreset(self.autoreset, base_seed=int(seeds[0] or 0) + 0x9E3779B9, **self._device_spawn_args())
         self.time[:] = 0
         self.steps = 0
         st = eng.get_state()
@@ -174,6 +171,18 @@ class BatchedHighwayEnv:
         info = {"speed": st["speed"][:, ego].copy(), "crashed": (st["flags"][:, ego] & _abi.F_CRASHED) != 0,
                 "action": None}
         return self._shape_obs(obs), info
+
+    def _spawn_reference(self, generators) -> dict:
+        """``_create_vehicles`` replayed on each env's numpy Generator (highway_env.py:72-98)."""
+        cfg = self.config
+        return spawn.spawn_reference_stream(self._hcfg, generators, cfg["ego_spacing"], cfg["vehicles_density"],
+                                            cfg["initial_lane_id"])
+
+    def _device_spawn_args(self) -> dict:
+        cfg = self.config
+        lane_id = cfg["initial_lane_id"]
+        return {"ego_spacing": cfg["ego_spacing"], "vehicles_density": cfg["vehicles_density"],
+                "initial_lane_id": -1 if lane_id is None else lane_id}
 
     # ---- step (abstract.py:259-285) ---------------------------------------------------------------
     def step(self, action):
@@ -237,6 +246,49 @@ class BatchedHighwayEnvFast(BatchedHighwayEnv):
     FAST = True
 
 
+class BatchedMergeEnv(BatchedHighwayEnv):
+    """E parallel ``merge-v0`` environments (MergeEnv, highway_env/envs/merge_env.py:15-190): a two-lane highway,
+    an access ramp (``SineLane``) converging onto a forbidden acceleration lane that ends in an ``Obstacle``."""
+    SCENARIO = "merge"
+    GENERIC = False
+
+    @classmethod
+    def default_config(cls) -> dict:
+        return _merge.merge_generic_default_config() if cls.GENERIC else _merge.merge_default_config()
+
+    def _spawn_reference(self, generators) -> dict:
+        return _merge.spawn_reference_stream(self._hcfg, self.config, self.GENERIC, generators)
+
+    def _device_spawn_args(self) -> dict:
+        return {}  # _make_vehicles has no spacing / density / lane parameters (merge_env.py:162-187, 320-363)
+
+    def rewards(self, env_index: int = 0, action=None) -> dict:
+        """MergeEnv._rewards (merge_env.py:62-77) of one env, from the device state.  ``action``: the ego's last
+        meta-action (the reference evaluates ``action in [0, 2]``); None -> lane_change_reward False."""
+        st = self._engine.get_state()
+        c = self._hcfg
+        e = env_index
+        v = st["speed"][e, 0]
+        r0, r1 = self.config["reward_speed_range"]
+        tab = _merge.table_from_config(c)
+        present = (st["flags"][e] & (_abi.F_ABSENT | _abi.F_OBSTACLE)) == 0
+        on_merge = present & (st["lane"][e] == c.merge_lane) if c.merge_lane >= 0 else np.zeros_like(present)
+        ts, sp = st["target_speed"][e][on_merge], st["speed"][e][on_merge]
+        return {"collision_reward": float(bool(st["flags"][e, 0] & _abi.F_CRASHED)),
+                "right_lane_reward": float(tab["id"][st["lane"][e, 0]]) / 1,
+                "high_speed_reward": float(0 + (v - r0) * (1 - 0) / (r1 - r0)),
+                "lane_change_reward": bool(action is not None and np.ndim(action) == 0 and int(action) in (0, 2)),
+                "merging_speed_reward": float(np.sum((ts - sp) / ts))}
+
+
+class BatchedMergeGenericEnv(BatchedMergeEnv):
+    """E parallel ``merge-generic-v0`` environments (MergeGenericEnv, merge_env.py:193-371): configurable lane
+    count, traffic count and section lengths; ``controlled_vehicles`` > 1 gives BASELINE config 5's multi-agent
+    variant (see highwayenv_amd/merge.py)."""
+    SCENARIO = "merge-generic"
+    GENERIC = True
+
+
 class _SingleEnvMixin:
     """E == 1 with the reference's unbatched signature."""
 
@@ -271,6 +323,22 @@ class HighwayEnv(_SingleEnvMixin, BatchedHighwayEnv):
 
 class HighwayEnvFast(_SingleEnvMixin, BatchedHighwayEnvFast):
     """Drop-in for ``highway_env.envs.highway_env.HighwayEnvFast`` (``highway-fast-v0``)."""
+
+
+class _SingleMergeMixin(_SingleEnvMixin):
+    def step(self, action):
+        obs, reward, term, trunc, info = BatchedHighwayEnv.step(self, np.asarray([action]).reshape(1, -1))
+        return (obs[0], float(reward[0]), bool(term[0]), bool(trunc[0]),
+                {"speed": float(info["speed"][0]), "crashed": bool(info["crashed"][0]), "action": action,
+                 "rewards": self.rewards(0, action)})
+
+
+class MergeEnv(_SingleMergeMixin, BatchedMergeEnv):
+    """Drop-in for ``highway_env.envs.merge_env.MergeEnv`` (``merge-v0``)."""
+
+
+class MergeGenericEnv(_SingleMergeMixin, BatchedMergeGenericEnv):
+    """Drop-in for ``highway_env.envs.merge_env.MergeGenericEnv`` (``merge-generic-v0``)."""
 
 
 def _copy_config(cfg):

@@ -114,3 +114,70 @@ def test_batched_env_device_spawn_autoreset_runs_and_resets():
         n_done += int((te | tr).sum())
     assert n_done >= 256  # duration 5 => every env truncated (and was re-spawned) at least once
     env.close()
+
+
+# ---- merge-v0 / merge-generic-v0 (highway_env/envs/merge_env.py) ------------------------------------------
+class EmuMerge(envs._SingleMergeMixin, envs.BatchedMergeEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+class EmuMergeGeneric(envs._SingleMergeMixin, envs.BatchedMergeGenericEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+class EmuBatchedMergeGeneric(envs.BatchedMergeGenericEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+@pytest.mark.parametrize("name", ["merge_default", "merge_generic_l3"])
+def test_single_merge_env_dropin_matches_reference_episode(real, name):
+    """MergeEnv() / MergeGenericEnv(config): reset(seed=s), golden actions -> the reference's obs/reward/flags."""
+    from tests.golden_util import GoldenMerge
+    g = GoldenMerge(name)
+    over = {k: v for k, v in g.config.items() if envs.BatchedMergeGenericEnv.default_config().get(k) != v} if g.generic else None
+    cls = {(False, False): EmuMerge, (False, True): EmuMergeGeneric,
+           (True, False): envs.MergeEnv, (True, True): envs.MergeGenericEnv}[(real, g.generic)]
+    env = cls(over)
+    e = 1
+    obs, info = env.reset(seed=int(g.seeds[e]))
+    assert obs.shape == (5, 5) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, g.z["obs0"][e, 0], atol=1e-6)
+    for t in range(g.steps):
+        a = int(g.actions[t, e, 0])
+        obs, r, te, tr, info = env.step(a)
+        assert isinstance(r, float) and isinstance(te, bool) and tr is False
+        np.testing.assert_allclose(obs, g.z["obs"][t, e, 0], atol=1e-6)
+        assert abs(r - g.z["reward"][t, e]) < 1e-9
+        assert te == bool(g.z["terminated"][t, e])
+        assert abs(info["speed"] - g.z["info_speed"][t, e]) < 1e-9
+        assert set(info["rewards"]) == {"collision_reward", "right_lane_reward", "high_speed_reward",
+                                        "lane_change_reward", "merging_speed_reward"}
+        # MergeEnv._reward (merge_env.py:40-60): lmap of the weighted sum of _rewards
+        c = env.config
+        raw = sum(c.get(k, 0) * v for k, v in info["rewards"].items())
+        lo, hi = c["collision_reward"] + c["merging_speed_reward"], c["high_speed_reward"] + c["right_lane_reward"]
+        assert abs((raw - lo) / (hi - lo) - r) < 1e-9
+        if te:
+            break
+    assert env.vehicle.crashed in (False, True) and len(env.controlled_vehicles) == 1
+    env.close()
+
+
+def test_batched_merge_generic_multi_agent_shapes_and_errors():
+    cfg = {"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+           "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+           "observation": {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}}
+    env = EmuBatchedMergeGeneric(cfg, num_envs=3)
+    obs, info = env.reset(seed=5)
+    assert obs.shape == (3, 4, 5, 5) and np.isfinite(obs).all()
+    o, r, te, tr, info = env.step(np.ones((3, 4), int))
+    assert o.shape == (3, 4, 5, 5) and r.shape == (3,) and info["agents_rewards"].shape == (3, 4)
+    assert not tr.any()
+    with pytest.raises(KeyError):
+        env.step(np.full((3, 4), 7))
+    env.close()
+    with pytest.raises(AssertionError):  # the reference's own assert (merge_env.py:241-244)
+        EmuBatchedMergeGeneric({"after_merge_length": 50}, num_envs=1)
+    with pytest.raises(NotImplementedError):
+        EmuBatchedMergeGeneric({"observation": {"type": "OccupancyGrid"}}, num_envs=1)
