@@ -204,6 +204,8 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
   if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
+  // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
+  if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
   if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
     const int v = std::atoi(w);
     if (v >= 1 && v <= 4) eng->waves_per_eu = v;

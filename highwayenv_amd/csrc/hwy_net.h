@@ -31,7 +31,12 @@ struct NetParams {
   hwy_lane lane[HWY_MAX_LANES];
 };
 
+// one row of the lane table as the per-frame table walk reads it (three ds_read_b128 with a wave-uniform address)
+struct alignas(16) NetLaneRow {
+  double x0, y0, length, len5, hw1, pad;  // len5 = length + 5 (on_lane's upper bound), hw1 = width / 2 + 1
+};
 struct NetShared {
+  NetLaneRow row[HWY_MAX_LANES];
   // lane table (struct of arrays: per-thread lane indices read it with one ds_read each)
   double lx0[HWY_MAX_LANES], ly0[HWY_MAX_LANES], llen[HWY_MAX_LANES], lwid[HWY_MAX_LANES], lamp[HWY_MAX_LANES],
       lpuls[HWY_MAX_LANES], lphase[HWY_MAX_LANES], llimit[HWY_MAX_LANES];
@@ -178,8 +183,10 @@ __device__ inline bool net_surely_apart(const NetBody &A, const NetBody &B, doub
   return gap_lat > margin || gap_lon > margin;
 }
 __device__ inline int net_pair_collide(const NetBody &A, const NetBody &B, double dt, double *tx, double *ty) {
-  const double diag_a = sqrt((2 * A.hl) * (2 * A.hl) + (2 * A.hw) * (2 * A.hw));
-  const double diag_b = sqrt((2 * B.hl) * (2 * B.hl) + (2 * B.hw) * (2 * B.hw));
+  // np.linalg.norm([LENGTH, WIDTH]) of a Vehicle (5 x 2) or an Obstacle (2 x 2): two constants, not two square roots
+  const double diag_veh = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH), diag_obs = sqrt(2.0 * 2.0 + 2.0 * 2.0);
+  const double diag_a = A.hl == 1.0 ? diag_obs : diag_veh;
+  const double diag_b = B.hl == 1.0 ? diag_obs : diag_veh;
   const double dx = B.x - A.x, dy = B.y - A.y;
   *tx = 0;
   *ty = 0;
@@ -214,6 +221,96 @@ __device__ inline void net_rank(double x, bool present, u64 pm, int &rank, bool 
   has_tie = __ballot(present && tie) != 0;
   const u64 below = ((u64)1 << i) - 1;
   rank = present ? cnt : __popcll(pm) + __popcll(~pm & below);
+}
+
+// The rank of the previous frame, re-validated like hwy_wave.h's wave_update_rank: every present slot sends its x to
+// lanes `rank` and `rank - 1` (ds_permute); lane r then holds x of rank r and of rank r + 1 and checks the order.
+// Disjoint adjacent inversions (an overtake somewhere on the road) are repaired by swapping the two ranks;
+// anything else (overlapping inversions, equal x) goes back to the counting pass.
+__device__ inline void net_update_rank(double x, bool present, u64 pm, int n_present, int &rank, bool &has_tie) {
+  const int i = threadIdx.x;
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const double x_r = __hiloint2double(wave_send_i(hi, rank), wave_send_i(lo, rank));
+  const double x_r1 = __hiloint2double(wave_send_i(hi, rank - 1), wave_send_i(lo, rank - 1));
+  bool recount = __ballot(i < n_present - 1 && !(x_r < x_r1)) != 0;
+  if (recount) {  // wave-uniform
+    const u64 inv = __ballot(i < n_present - 1 && x_r > x_r1);
+    if (inv != 0 && (inv & (inv << 1)) == 0) {
+      const bool up = present && ((inv >> rank) & 1);
+      const bool down = present && rank > 0 && ((inv >> (rank - 1)) & 1);
+      rank += up ? 1 : (down ? -1 : 0);
+      const double y_r = __hiloint2double(wave_send_i(hi, rank), wave_send_i(lo, rank));
+      const double y_r1 = __hiloint2double(wave_send_i(hi, rank - 1), wave_send_i(lo, rank - 1));
+      recount = __ballot(i < n_present - 1 && !(y_r < y_r1)) != 0;
+    }
+  }
+  if (!recount) has_tie = false;  // strictly increasing => all x distinct
+  if (recount) net_rank(x, present, pm, rank, has_tie);
+}
+
+// One pass over the lane table for a body at (x, y) with heading h:
+//   * bits:    AbstractLane.on_lane with margin 1 (lane.py:80-102) for every lane -- what Road.neighbour_vehicles
+//              tests for each candidate (road.py:503-519);
+//   * closest: RoadNetwork.get_closest_lane_index (road.py:55-71) with distance_with_heading (lane.py:132-147),
+//              first minimum in table order; the straight lanes share the heading term.
+// Straight lanes are walked first (branch-free), the SineLanes (bit set in sine_mask) afterwards.
+template <bool CLOSEST>
+__device__ inline void net_lane_pass(const NetParams &np, const NetShared &sh, unsigned sine_mask, double x, double y, double h,
+                                     int *bits_out, int *closest_out) {
+  const double angle0 = CLOSEST ? fabs(wrap_to_pi(h - 0.0)) : 0.0;
+  const int n = np.n_lanes;
+  int bits = 0, best = 0;
+  double bd = __builtin_inf();
+  // straight lanes, four table rows per trip: the rows are fetched from LDS together (wave-uniform addresses:
+  // broadcasts), so the walk pays one LDS round trip per four lanes instead of one per lane.  HWY_MAX_LANES is a
+  // multiple of 4; rows past n_lanes are read and masked out.
+  static_assert(HWY_MAX_LANES % 4 == 0, "the lane table is walked in groups of 4");
+  for (int L0 = 0; L0 < n; L0 += 4) {
+    NetLaneRow row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) row[k] = sh.row[L0 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int L = L0 + k;
+      const NetLaneRow &cur = row[k];
+      const bool valid = L < n && !((sine_mask >> L) & 1);  // wave-uniform
+      const double s = x - cur.x0, r = y - cur.y0;
+      const bool on = valid && fabs(r) <= cur.hw1 && -5.0 <= s && s < cur.len5;
+      bits |= on ? (1 << L) : 0;
+      if (CLOSEST) {
+        const double d = fabs(r) + fmax(s - cur.length, 0.0) + fmax(0 - s, 0.0) + 1.0 * angle0;
+        const bool take = valid && d < bd;  // strict: the first minimum in table order
+        bd = take ? d : bd;
+        best = take ? L : best;
+      }
+    }
+  }
+  // SineLanes (lane.py:236-283): one sincos (+ one atan for the heading term) each
+  for (unsigned m = sine_mask; m; m &= m - 1) {  // wave-uniform
+    const int L = __builtin_ctz(m);
+    const hwy_lane &l = np.lane[L];
+    const double s = x - l.x0;
+    double sn, cs;
+    sincos_bounded(l.pulsation * s + l.phase, &sn, &cs);
+    const double r = (y - l.y0) - l.amplitude * sn;
+    const bool on = fabs(r) <= l.width / 2 + 1.0 && -5.0 <= s && s < l.length + 5.0;
+    bits |= on ? (1 << L) : 0;
+    if (CLOSEST) {
+      const double angle = fabs(wrap_to_pi(h - (0.0 + atan_small(l.amplitude * l.pulsation * cs))));
+      const double d = fabs(r) + fmax(s - l.length, 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+      const bool take = d < bd || (d == bd && L < best);
+      bd = take ? d : bd;
+      best = take ? L : best;
+    }
+  }
+  *bits_out = bits;
+  *closest_out = best;
+}
+// lanes of the table with a lateral sine offset (bit L), once per kernel
+__device__ inline unsigned net_sine_mask(const NetParams &np) {
+  unsigned m = 0;
+  for (int L = 0; L < np.n_lanes; ++L) m |= (np.lane[L].amplitude != 0.0) ? (1u << L) : 0u;
+  return m;
 }
 
 // Road.neighbour_vehicles literal scan on lane Lq (equal-x case only); returns slot indices
@@ -328,6 +425,7 @@ __device__ inline void net_load_table(const NetParams &np, NetShared &sh) {
     const hwy_lane &l = np.lane[i];
     sh.lx0[i] = l.x0; sh.ly0[i] = l.y0; sh.llen[i] = l.length; sh.lwid[i] = l.width; sh.lamp[i] = l.amplitude;
     sh.lpuls[i] = l.pulsation; sh.lphase[i] = l.phase; sh.llimit[i] = l.speed_limit;
+    sh.row[i] = NetLaneRow{l.x0, l.y0, l.length, l.length + 5.0, l.width / 2 + 1.0, 0.0};
     sh.lroad[i] = l.road; sh.lid[i] = l.id; sh.lfirst[i] = l.road_first; sh.lcount[i] = l.road_lanes;
     sh.lnext[i] = l.next_first; sh.lnextn[i] = l.next_lanes; sh.lforb[i] = l.forbidden;
   }
@@ -471,6 +569,18 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
   const bool i_check = present && (me.flags & HWY_F_CHECK_COLLISIONS);
   const u64 chk = __ballot(i_check);
   const double my_hl = obstacle ? 1.0 : HWY_VEH_LENGTH / 2, my_hw = obstacle ? 1.0 : HWY_VEH_WIDTH / 2;
+  // lane membership bits of the current position: from the loaded state for the first frame, afterwards from the
+  // same table pass that re-indexes the lane after the integration (on_state_update) -- the position does not
+  // change between the end of a frame and the start of the next one
+  const unsigned sine_mask = net_sine_mask(np);
+  int bits;
+  {
+    int unused;
+    net_lane_pass<false>(np, sh, sine_mask, me.x, me.y, me.h, &bits, &unused);
+    bits = present ? bits : 0;
+  }
+  int rank = 0;
+  bool has_tie = false;
 
   for (int fr = 0; fr < p.n_frames; ++fr) {
     // ---- A. meta-actions of all agents (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315;
@@ -493,22 +603,9 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     }
 
     // ---- B. rank along x, lane membership masks, frame-start snapshot ----------------------------------------
-    int rank;
-    bool has_tie;
-    net_rank(me.x, present, pm, rank, has_tie);
-    int bits = 0;
-    for (int L = 0; L < np.n_lanes; ++L) {  // AbstractLane.on_lane(margin=1), lane.py:80-102
-      const double s = me.x - sh.lx0[L];
-      double lat = me.y - sh.ly0[L];
-      const double amp = sh.lamp[L];
-      if (amp != 0.0) {  // wave-uniform
-        double sn, cs;
-        sincos_bounded(sh.lpuls[L] * s + sh.lphase[L], &sn, &cs);
-        lat = lat - amp * sn;
-      }
-      const bool on = present && fabs(lat) <= sh.lwid[L] / 2 + 1.0 && -5.0 <= s && s < sh.llen[L] + 5.0;
-      bits |= on ? (1 << L) : 0;
-    }
+    // (counted in the first frame of a step, then carried from frame to frame and merely re-validated)
+    if (fr == 0) net_rank(me.x, present, pm, rank, has_tie);
+    else net_update_rank(me.x, present, pm, n_present, rank, has_tie);
     const int sorted_bits = wave_send_i(bits, rank);
     u64 m_pub = 0;
     for (int L = 0; L < np.n_lanes; ++L) {
@@ -640,7 +737,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     accel = controlled ? HWY_KP_A * (me.ts - me.v) : accel;
 
     // ---- E. Road.step: integrate (kinematics.py:130-177) ------------------------------------------------------
-    const double x_old = me.x;
+    const double x_old = me.x, v_old = me.v;
+    const int flags_old = me.flags;
     if (veh) {
       if (!(drives || controlled)) {  // a crashed IDM vehicle keeps its previous action, then clip_actions overrides it
         tb = 0.0;
@@ -664,46 +762,74 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       sincos_bounded(me.h, &me.sh, &me.ch);
     }
     {
-      const int cl_new = net_closest_lane(sh, np.n_lanes, me.x, me.y, me.h);  // on_state_update
+      int cl_new, bits_new;  // on_state_update (kinematics.py:170-177) + the next frame's membership bits
+      net_lane_pass<true>(np, sh, sine_mask, me.x, me.y, me.h, &bits_new, &cl_new);
       if (veh) me.lane = cl_new;
+      bits = present ? bits_new : 0;
     }
 
     // ---- F. Road.step: collisions (road.py:477-481, objects.py:92-138) ----------------------------------------
     // Outward scan in rank order bounded by the frame-start distance, like hwy_wave.h; "last pair in loop
     // order wins" == the partner with the highest slot (the obstacle, being last, beats every vehicle).
-    sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
+    // bodies after the integration, in the frame-start RANK order (same permutation as the snapshot above)
+    if (present) { sh.nx[rank] = me.x; sh.ny[rank] = me.y; sh.nv[rank] = me.v; sh.nc[rank] = me.ch; sh.ns[rank] = me.sh; }
     __syncthreads();
-    if (present) {
-      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, my_hl, my_hw};
-      const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
-      int best = -1;
-      for (int dir = -1; dir <= 1; dir += 2) {
-        for (int r2 = rank + dir; r2 >= 0 && r2 < n_present; r2 += dir) {
-          if (fabs(sh.x[r2] - x_old) > reach) break;
-          const int q = sh.idx[r2];
-          const bool q_obs = sh.kind[r2] == 0;
-          if (obstacle && q_obs) continue;  // road.py:477-481: vehicle-vehicle and vehicle-object pairs only
-          const NetBody other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
-                              q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
-          const double dx = other.x - me.x, dy = other.y - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
-          if (dx * dx + dy * dy > lim * lim) continue;
-          if (!(i_check || ((chk >> q) & 1))) continue;  // objects.py:98
-          const bool i_first = i < q;
-          const NetBody A = select_nbody(i_first, mine, other), Bb = select_nbody(i_first, other, mine);
-          if (net_surely_apart(A, Bb, p.dt)) continue;
-          double tx, ty;
-          const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
-          if ((r & 2) && q > best && veh) {
-            best = q;
-            // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
-            const double share = q_obs ? 1.0 : 0.5;
-            me.impx = i_first ? tx * share : -tx * share;
-            me.impy = i_first ? ty * share : -ty * share;
-            me.flags |= HWY_F_HAS_IMPACT;
-          }
-          if (r & 1) me.flags |= HWY_F_CRASHED;
+    {
+      // Phase 1, wave-uniform walk outwards in rank order (partners at rank - k and rank + k), bounded by the
+      // frame-start distance: lim of the sphere pre-check below + what two bodies can move towards each other in
+      // one frame (speed * dt each, + a pending impact each).  Speeds stay below 36 m/s in practice; the bound falls
+      // back to 50 m/s if any body is faster.  Close pairs are only COLLECTED here (bit r2 of `cand`, rank space).
+      const bool calm = __ballot(present && !(fabs(me.v) <= 36.0 && fabs(v_old) <= 36.0)) == 0;
+      const bool pending = __ballot(present && (flags_old & HWY_F_HAS_IMPACT)) != 0;
+      const double vb = (calm ? 36.0 : 50.0) * p.dt;
+      const double reach = (5.5 + vb) + 2.0 * (vb + (pending ? 3.0 : 0.0));
+      u64 cand = 0;
+      bool go_a = present, go_b = present;
+      for (int k = 1; k < n_present; ++k) {
+        const int ra = rank - k, rb = rank + k;
+        go_a = go_a && ra >= 0;
+        go_b = go_b && rb < n_present;
+        const int ia_ = go_a ? ra : 0, ib_ = go_b ? rb : 0;
+        go_a = go_a && !(fabs(sh.x[ia_] - x_old) > reach);
+        go_b = go_b && !(fabs(sh.x[ib_] - x_old) > reach);
+        if (__ballot(go_a || go_b) == 0) break;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const bool go = side ? go_b : go_a;
+          const int r2 = side ? ib_ : ia_;
+          const double dx = sh.nx[r2] - me.x, dy = sh.ny[r2] - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.nv[r2])) * p.dt;
+          const bool near = go && !(dx * dx + dy * dy > lim * lim);
+          cand |= near ? ((u64)1 << r2) : 0;
         }
+      }
+      // Phase 2: every thread's collected partners, one per trip (a handful of trips for the whole wave)
+      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, my_hl, my_hw};
+      int best = -1;
+      while (__ballot(cand != 0) != 0) {  // wave-uniform
+        if (cand == 0) continue;
+        const int r2 = ctz64(cand);
+        cand &= cand - 1;
+        const int q = sh.idx[r2];
+        const bool q_obs = sh.kind[r2] == 0;
+        if (obstacle && q_obs) continue;  // road.py:477-481: vehicle-vehicle and vehicle-object pairs only
+        if (!(i_check || ((chk >> q) & 1))) continue;  // objects.py:98
+        const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
+                            q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
+        const bool i_first = i < q;
+        const NetBody A = select_nbody(i_first, mine, other), Bb = select_nbody(i_first, other, mine);
+        if (net_surely_apart(A, Bb, p.dt)) continue;
+        double tx, ty;
+        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
+        if ((r & 2) && q > best && veh) {  // "last pair in loop order wins" == the partner in the highest slot
+          best = q;
+          // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
+          const double share = q_obs ? 1.0 : 0.5;
+          me.impx = i_first ? tx * share : -tx * share;
+          me.impy = i_first ? ty * share : -ty * share;
+          me.flags |= HWY_F_HAS_IMPACT;
+        }
+        if (r & 1) me.flags |= HWY_F_CRASHED;
       }
     }
   }  // frames

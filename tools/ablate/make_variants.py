@@ -20,8 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "highwayenv_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_device.h", "hwy_math.h")
-W, D = "hwy_wave.h", "hwy_device.h"
+FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_device.h", "hwy_math.h",
+         "hwy_net.h")
+W, D, NET = "hwy_wave.h", "hwy_device.h", "hwy_net.h"
 
 
 class Stale(Exception):
@@ -80,6 +81,31 @@ def ticks(text):
     return t
 
 
+def net_ticks(text):
+    """s_memtime stamps around the sections of the road-network kernel (hwy_net.h); totals through the obs buffer."""
+    t = sub("  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool present",
+            "  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};\n"
+            "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
+            "  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool present")(text)
+    marks = ["    // ---- A. meta-actions of all agents",
+             "    // ---- B. rank along x, lane membership masks",
+             "    const int sorted_bits = wave_send_i(bits, rank);",
+             "    // ---- C. Road.act ---",
+             "    const double delta = me.delta;\n    const double free_self",
+             "    // abort rule for ongoing lane changes on the same road",
+             "    // ---- D. low-level control",
+             "    // ---- E. Road.step: integrate",
+             "    {\n      int cl_new, bits_new;",
+             "    // ---- F. Road.step: collisions",
+             "  }  // frames\n\n  // ---- G. observe / reward / done"]
+    for k, m in enumerate(marks):
+        t = sub(m, f"    TICK({k})\n" + m)(t)
+    t = sub("    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
+            "    TICK(11)\n    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
+            "  if (i == 0 && p.obs) for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}")(t)
+    return t
+
+
 NO_LOGEXP = [(D, sub("return r > 0.0 ? log_pos(r) : -__builtin_inf();", "return r;")),
              (D, sub("(1 - exp_bounded(delta * log_ratio))", "(1 - delta * log_ratio)"))]
 
@@ -95,6 +121,8 @@ VARIANTS = {
     "wnosteer": [(W, sub("    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "    double tb = inv_v * 1e-9;"))],
     "wnoobs": [(W, sub("    observe_wave<true>(q, e, me, true, rank);\n", ""))],
     "wticks": [(W, ticks)],
+    # road-network kernel (hwy_net.h)
+    "nticks": [(NET, net_ticks)],
     # generic workgroup kernel (hwy_device.h)
     "base": [],
     "nocollide": [(D, cutter("    if (all_check) {\n      // Full pairwise (highway-v0): outward scan", "  }  // frames", "    if (false) {}\n"))],

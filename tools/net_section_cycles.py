@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU): per-section s_memtime cycle breakdown of hwy_net_step_kernel on the merge workloads, using
+the `nticks` build from tools/ablate/make_variants.py (HWY_ENGINE_LIB must point to it)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from highwayenv_amd import _abi, merge  # noqa: E402
+from highwayenv_amd.engine import Engine  # noqa: E402
+
+E = 4096
+which = sys.argv[1] if len(sys.argv) > 1 else "merge_ma4"
+if which == "merge":
+    scenario, cfg_d = "merge", merge.merge_default_config()
+else:
+    scenario, cfg_d = "merge-generic", merge.merge_generic_default_config()
+    cfg_d.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+                  "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+                  "observation": {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}})
+cfg = _abi.make_config(cfg_d, E, scenario=scenario)
+eng = Engine(cfg)
+eng.reset(base_seed=5)
+eng.set_autoreset(True, base_seed=99)
+rng = np.random.default_rng(0)
+tot = np.zeros(12)
+n = 0
+for t in range(40):
+    obs = eng.step(rng.integers(0, 5, size=(E, cfg.num_agents)))[0]
+    if t >= 20:
+        tot += obs.reshape(E, -1)[:, :12].astype(np.float64).mean(0)
+        n += 1
+names = ["load", "A meta-action", "B rank", "B membership+snapshot", "C follow_road+neighbours", "C gaps + MOBIL",
+         "C abort chain", "D control", "E integrate", "E closest lane", "F collisions", "G observe"]
+tot /= n
+print(which)
+for k, nm in enumerate(names):
+    print(f"{nm:26s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot.sum():5.1f}%")
+print(f"{'total':26s} {tot.sum():10.0f}")
