@@ -100,9 +100,19 @@ def net_ticks(text):
              "  }  // frames\n\n  // ---- G. observe / reward / done"]
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
+    # collisions split: phase 1 (walk) -> acc[10], phase 2 (SAT trips) -> acc[12]; trip / walk-step counters
+    t = sub("      // Phase 2: every thread's collected partners", "      TICK(10)\n      // Phase 2: every thread's collected partners")(t)
+    t = sub("  }  // frames\n\n  // ---- G. observe", "  TICK(12)\n  }  // frames\n\n  // ---- G. observe")(t)
+    t = sub("    TICK(10)\n  TICK(12)\n  }  // frames", "  TICK(12)\n  }  // frames")(t)
+    t = sub("        if (__ballot(go_a || go_b) == 0) break;", "        if (__ballot(go_a || go_b) == 0) break;\n        n_walk += 1.0f;")(t)
+    t = sub("        if (cand == 0) continue;\n        const int r2 = ctz64(cand);", "        n_trip += 1.0f; if (cand == 0) continue;\n        const int r2 = ctz64(cand);")(t)
+    t = sub("        double tx, ty;\n        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "        n_sat += 1.0f;\n        double tx, ty;\n        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
+    t = sub("  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};", "  float n_walk = 0, n_trip = 0, n_sat = 0; long long t_prev = clock64(); long long acc[13] = {0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
     t = sub("    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
             "    TICK(11)\n    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
-            "  if (i == 0 && p.obs) for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n}")(t)
+            "  { float sat_any = __ballot(n_sat > 0) ? 1.0f : 0.0f; n_sat = 0; for (int j = 0; j < 64; ++j) n_sat += __shfl(sat_any, j) * 0 ; n_sat = sat_any;\n"
+            "  if (i == 0 && p.obs) { for (int k = 0; k < 13; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
+            "    p.obs[(size_t)e * p.A * p.V * p.F + 13] = n_walk; p.obs[(size_t)e * p.A * p.V * p.F + 14] = n_trip; p.obs[(size_t)e * p.A * p.V * p.F + 15] = n_sat; } }\n}")(t)
     return t
 
 

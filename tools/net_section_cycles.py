@@ -24,17 +24,19 @@ eng = Engine(cfg)
 eng.reset(base_seed=5)
 eng.set_autoreset(True, base_seed=99)
 rng = np.random.default_rng(0)
-tot = np.zeros(12)
+tot = np.zeros(16)
 n = 0
 for t in range(40):
     obs = eng.step(rng.integers(0, 5, size=(E, cfg.num_agents)))[0]
     if t >= 20:
-        tot += obs.reshape(E, -1)[:, :12].astype(np.float64).mean(0)
+        tot += obs.reshape(E, -1)[:, :16].astype(np.float64).mean(0)
         n += 1
 names = ["load", "A meta-action", "B rank", "B membership+snapshot", "C follow_road+neighbours", "C gaps + MOBIL",
-         "C abort chain", "D control", "E integrate", "E closest lane", "F collisions", "G observe"]
+         "C abort chain", "D control", "E integrate", "E closest lane", "F collisions: walk", "G observe",
+         "F collisions: SAT trips"]
 tot /= n
 print(which)
 for k, nm in enumerate(names):
-    print(f"{nm:26s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot.sum():5.1f}%")
-print(f"{'total':26s} {tot.sum():10.0f}")
+    print(f"{nm:26s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot[:13].sum():5.1f}%")
+print(f"{'total':26s} {tot[:13].sum():10.0f}")
+print(f"walk steps per step {tot[13]:.1f}, SAT-phase trips per step {tot[14]:.1f}, waves that ran a SAT {tot[15]:.3f}")
