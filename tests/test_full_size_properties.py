@@ -95,3 +95,93 @@ def test_full_size_autoreset_keeps_every_env_alive():
     st = eng.get_state()
     assert (st["time"] <= 30).all()
     eng.close()
+
+
+# ---- BASELINE config 5 at full size: merge-generic, 4096 envs x 43 slots, 4 controlled agents per env ------------
+def make_merge(E_):
+    from highwayenv_amd import merge
+    from highwayenv_amd.engine import Engine
+    cfg_d = merge.merge_generic_default_config()
+    cfg_d.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+                  "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+                  "observation": {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}})
+    cfg = _abi.make_config(cfg_d, E_, scenario="merge-generic")
+    return cfg_d, cfg, Engine(cfg)
+
+
+def test_full_size_merge_multi_agent_determinism_independence_oracle_and_invariants():
+    cfg_d, cfg, eng = make_merge(E)
+    _, _, eng2 = make_merge(E)
+    A, N = cfg.num_agents, cfg.num_vehicles
+    seeds = np.arange(E, dtype=np.uint64) + 4242
+    for e_ in (eng, eng2):
+        e_.reset(seeds=seeds)
+    pick = np.sort(np.random.default_rng(3).choice(E, 16, replace=False))
+    sub_cfg = _abi.make_config(cfg_d, len(pick), scenario="merge-generic")
+    from highwayenv_amd.engine import Engine
+    sub = Engine(sub_cfg)
+    st0 = eng.get_state()
+    present0 = (st0["flags"] & _abi.F_ABSENT) == 0
+    assert 30 * E < present0.sum() <= N * E and present0[:, 0].all() and present0[:, N - 2:].all()
+    sub.set_state({k: np.ascontiguousarray(v[pick]) for k, v in st0.items()})
+    ref = {k: np.ascontiguousarray(v[pick]).copy() for k, v in st0.items()}
+    live = np.ones(len(pick), bool)
+    rng = np.random.default_rng(4)
+    n_term = 0
+    ever_done = np.zeros(E, bool)
+    for t in range(14):
+        acts = rng.integers(0, 5, size=(E, A)).astype(np.int32)
+        out1 = eng.step(acts)
+        out2 = eng2.step(acts)
+        for a, b in zip(out1[:4], out2[:4]):
+            np.testing.assert_array_equal(a, b, err_msg=f"determinism, step {t}")
+        obs, reward, term, trunc, info = out1
+        s_obs, s_rew, s_term, s_trunc, _ = sub.step(acts[pick])
+        np.testing.assert_array_equal(s_obs, obs[pick], err_msg=f"batch independence, step {t}")
+        np.testing.assert_array_equal(s_rew, reward[pick])
+        np.testing.assert_array_equal(s_term, term[pick])
+        o2, r2, te2, tr2, _ = oracle.step(sub_cfg, ref, acts[pick])
+        pres = (ref["flags"] & _abi.F_ABSENT) == 0
+        wreck = (pres & ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
+        ok = live & ~wreck
+        np.testing.assert_array_equal(s_term[live], te2[live])
+        np.testing.assert_allclose(s_obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=f"oracle, step {t}")
+        np.testing.assert_allclose(s_rew[ok], r2[ok], rtol=0, atol=1e-9)
+        live &= ~wreck & ~te2
+        # invariants over the whole batch
+        st = eng.get_state()
+        pres_all = (st["flags"] & _abi.F_ABSENT) == 0
+        np.testing.assert_array_equal(pres_all, present0)  # nothing appears or disappears while stepping
+        assert obs.shape == (E, A, 5, 5) and np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()
+        assert np.isfinite(reward).all() and not trunc.any()
+        assert ((st["lane"][pres_all] >= 0) & (st["lane"][pres_all] < cfg.net_lanes)).all()
+        # the obstacle never moves; terminated == ego crashed or past the end of the merge section
+        np.testing.assert_array_equal(st["x"][:, N - 1], st0["x"][:, N - 1])
+        want_term = ((st["flags"][:, 0] & _abi.F_CRASHED) != 0) | (st["x"][:, 0] > cfg.merge_end_x)
+        np.testing.assert_array_equal(term, want_term)
+        np.testing.assert_array_equal(st["time"], t + 1.0)
+        n_term += int((term & ~ever_done).sum())
+        ever_done |= term
+    assert ever_done.mean() > 0.9  # 14 s at ~30 m/s: nearly every ego crashed or left the 400 m section
+    for e_ in (eng, eng2, sub):
+        e_.close()
+
+
+def test_full_size_merge_autoreset_keeps_every_env_alive():
+    cfg_d, cfg, eng = make_merge(E)
+    A = cfg.num_agents
+    eng.reset(base_seed=99)
+    eng.set_autoreset(True, base_seed=7)
+    rng = np.random.default_rng(5)
+    done_prev = np.zeros(E, bool)
+    resets = np.zeros(E, int)
+    for t in range(45):
+        obs, reward, term, trunc, info = eng.step(rng.integers(0, 5, size=(E, A)))
+        assert (reward[done_prev] == 0).all() and not term[done_prev].any()
+        assert not info["crashed"][done_prev].any()
+        resets += done_prev
+        done_prev = term | trunc
+    assert (resets >= 2).all()  # an episode lasts at most ~13 steps
+    st = eng.get_state()
+    assert (st["x"][:, 0] <= cfg.merge_end_x + 45.0).all()
+    eng.close()
