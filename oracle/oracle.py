@@ -23,8 +23,9 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "hwy_oracle.c")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "hwy_engine.h")
     src_net = os.path.join(_HERE, "hwy_oracle_net.c")
+    src_ix = os.path.join(_HERE, "hwy_oracle_ix.c")
     stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(src_net), os.path.getmtime(hdr)))
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in (src, src_net, src_ix, hdr)))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _LIB_PATH

@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE: ctypes wrapper around the intersection oracle (oracle/hwy_oracle_ix.c, in libhwy_oracle.so).
+
+The checker for the next hot-path row (intersection dynamics); nothing in the product
+package imports it.  The structs mirror the oracle's private ``ix_config`` / ``ix_state``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import oracle as _base
+
+IX_MAX_LANES, IX_MAX_ROUTE, IX_MAX_FEATURES = 32, 4, 8
+FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7}
+LANE_F64 = ["sx", "sy", "ex", "ey", "heading", "dirx", "diry", "cx", "cy", "radius", "start_phase", "end_phase",
+            "length", "width", "speed_limit"]
+LANE_I32 = ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "id"]
+STATE_F64 = ["x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y"]
+STATE_I32 = ["present", "lane", "target_lane", "speed_index", "crashed", "has_impact", "controlled", "is_yielding",
+             "yield_timer", "route_len"]
+STATE_ROUTE = ["route_from", "route_to", "route_id"]
+
+
+class IxLane(C.Structure):
+    _fields_ = ([(k, C.c_int32) for k in ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "id",
+                                          "exit_lane"]]
+                + [(k, C.c_double) for k in ["sx", "sy", "ex", "ey", "heading", "dirx", "diry", "cx", "cy", "radius",
+                                             "start_phase", "end_phase", "length", "width", "speed_limit"]])
+
+
+class IxConfig(C.Structure):
+    _fields_ = ([(k, C.c_int32) for k in ["num_envs", "n_slots", "n_lanes", "n_route", "frames_per_step",
+                                          "num_target_speeds", "obs_vehicles", "obs_features"]]
+                + [("obs_feature_ids", C.c_int32 * IX_MAX_FEATURES)]
+                + [(k, C.c_int32) for k in ["obs_absolute", "obs_normalize", "obs_clip", "obs_see_behind",
+                                            "normalize_reward", "offroad_terminal", "pad0", "pad1"]]
+                + [(k, C.c_double) for k in ["dt", "policy_dt", "duration", "perception_distance", "distance_wanted",
+                                             "time_wanted", "comfort_acc_max", "comfort_acc_min"]]
+                + [("target_speeds", C.c_double * 8)]
+                + [(k, C.c_double) for k in ["collision_reward", "high_speed_reward", "arrived_reward"]]
+                + [("reward_speed_range", C.c_double * 2)]
+                + [(k, C.c_double * 2) for k in ["obs_range_x", "obs_range_y", "obs_range_vx", "obs_range_vy"]]
+                + [("spawn_probability", C.c_double), ("access_lane", C.c_int32 * 4), ("outer_node", C.c_int32 * 4),
+                   ("lanes", IxLane * IX_MAX_LANES)])
+
+
+_DP, _IP = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+
+class IxState(C.Structure):
+    _fields_ = ([(k, _DP) for k in STATE_F64] + [(k, _IP) for k in STATE_I32] + [(k, _IP) for k in STATE_ROUTE]
+                + [("road_steps", _IP), ("time", _DP)])
+
+
+def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots: int, n_route: int = 4) -> IxConfig:
+    """Flatten IntersectionEnv's config dict (intersection_env.py:17-58) + the recorded lane table."""
+    c = IxConfig()
+    c.num_envs, c.n_slots, c.n_route = int(num_envs), int(n_slots), int(n_route)
+    n = len(lane_tab["kind"])
+    c.n_lanes = n
+    names = [str(s) for s in node_names]
+    for k in range(n):
+        for f in LANE_F64:
+            setattr(c.lanes[k], f, float(lane_tab[f][k]))
+        for f in LANE_I32:
+            setattr(c.lanes[k], f, int(lane_tab[f][k]))
+        c.lanes[k].exit_lane = int("il" in names[lane_tab["from_node"][k]] and "o" in names[lane_tab["to_node"][k]])
+    for q in range(4):
+        c.outer_node[q] = names.index(f"o{q}")
+        c.access_lane[q] = next(k for k in range(n) if names[lane_tab["from_node"][k]] == f"o{q}"
+                                and names[lane_tab["to_node"][k]] == f"ir{q}" and lane_tab["id"][k] == 0)
+    c.frames_per_step = int(config["simulation_frequency"] // config["policy_frequency"])
+    c.dt, c.policy_dt = 1 / config["simulation_frequency"], 1 / config["policy_frequency"]
+    c.duration = float(config["duration"])
+    c.perception_distance = 5.0 * 40.0  # AbstractEnv.PERCEPTION_DISTANCE (abstract.py:58)
+    # IntersectionEnv._make_vehicles sets these on the vehicle class (intersection_env.py:243-247)
+    c.distance_wanted, c.time_wanted, c.comfort_acc_max, c.comfort_acc_min = 7.0, 1.5, 6.0, -3.0
+    ts = np.asarray(config["action"]["target_speeds"], np.float64)
+    c.num_target_speeds = ts.size
+    for k, v in enumerate(ts):
+        c.target_speeds[k] = float(v)
+    obs = config["observation"]
+    feats = obs["features"]
+    c.obs_vehicles, c.obs_features = int(obs["vehicles_count"]), len(feats)
+    for k, name in enumerate(feats):
+        c.obs_feature_ids[k] = FEATURE_IDS[name]
+    c.obs_absolute, c.obs_normalize = int(obs.get("absolute", False)), int(obs.get("normalize", True))
+    c.obs_clip, c.obs_see_behind = int(obs.get("clip", True)), int(obs.get("see_behind", False))
+    fr = obs["features_range"]
+    inf = float("inf")
+    for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
+        field[0], field[1] = (float(fr[name][0]), float(fr[name][1])) if name in fr else (-inf, inf)
+    c.collision_reward, c.high_speed_reward = float(config["collision_reward"]), float(config["high_speed_reward"])
+    c.arrived_reward = float(config["arrived_reward"])
+    c.reward_speed_range[0], c.reward_speed_range[1] = map(float, config["reward_speed_range"])
+    c.normalize_reward, c.offroad_terminal = int(config["normalize_reward"]), int(config["offroad_terminal"])
+    c.spawn_probability = float(config["spawn_probability"])
+    return c
+
+
+def alloc_state(E: int, C_: int, R: int = 4) -> dict:
+    st = {k: np.zeros((E, C_), np.float64) for k in STATE_F64}
+    st.update({k: np.zeros((E, C_), np.int32) for k in STATE_I32})
+    st.update({k: np.full((E, C_, R), -1, np.int32) for k in STATE_ROUTE})
+    st["road_steps"] = np.zeros(E, np.int32)
+    st["time"] = np.zeros(E, np.float64)
+    return st
+
+
+def _struct(st: dict) -> IxState:
+    s = IxState()
+    for k in STATE_F64 + ["time"]:
+        assert st[k].dtype == np.float64 and st[k].flags.c_contiguous, k
+        setattr(s, k, st[k].ctypes.data_as(_DP))
+    for k in STATE_I32 + STATE_ROUTE + ["road_steps"]:
+        assert st[k].dtype == np.int32 and st[k].flags.c_contiguous, k
+        setattr(s, k, st[k].ctypes.data_as(_IP))
+    return s
+
+
+def _lib():
+    lib = _base.lib()
+    lib.orc_ix_config_size.restype = C.c_size_t
+    assert lib.orc_ix_config_size() == C.sizeof(IxConfig), "ix_config layout mismatch"
+    return lib
+
+
+def frames(cfg: IxConfig, st: dict, actions, n_frames: int) -> None:
+    acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(cfg.num_envs))
+    s = _struct(st)
+    rc = _lib().orc_ix_frames(C.byref(cfg), C.byref(s), None if acts is None else acts.ctypes.data_as(_IP),
+                              C.c_int32(n_frames))
+    assert rc == 0, rc
+
+
+def observe(cfg: IxConfig, st: dict) -> np.ndarray:
+    obs = np.zeros((cfg.num_envs, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    s = _struct(st)
+    rc = _lib().orc_ix_observe(C.byref(cfg), C.byref(s), obs.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == 0, rc
+    return obs
+
+
+def step(cfg: IxConfig, st: dict, actions) -> tuple:
+    """AbstractEnv.step up to (not including) IntersectionEnv.step's clear / spawn."""
+    E = cfg.num_envs
+    acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E))
+    obs = np.zeros((E, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    reward, speed = np.zeros(E), np.zeros(E)
+    term, trunc, crashed = np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
+    s = _struct(st)
+    u8 = C.POINTER(C.c_uint8)
+    rc = _lib().orc_ix_step(C.byref(cfg), C.byref(s), acts.ctypes.data_as(_IP), obs.ctypes.data_as(C.POINTER(C.c_float)),
+                            reward.ctypes.data_as(_DP), term.ctypes.data_as(u8), trunc.ctypes.data_as(u8),
+                            speed.ctypes.data_as(_DP), crashed.ctypes.data_as(u8))
+    assert rc == 0, rc
+    return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+
+
+def clear_spawn(cfg: IxConfig, st: dict, draws, n_draws) -> np.ndarray:
+    """IntersectionEnv._clear_vehicles + _spawn_vehicle on recorded draws; returns the draws consumed per env."""
+    d = np.ascontiguousarray(draws, np.float64)
+    nd = np.ascontiguousarray(n_draws, np.int32)
+    used = np.zeros(cfg.num_envs, np.int32)
+    s = _struct(st)
+    rc = _lib().orc_ix_clear_spawn(C.byref(cfg), C.byref(s), d.ctypes.data_as(_DP), nd.ctypes.data_as(_IP),
+                                   C.c_int32(d.shape[-1]), used.ctypes.data_as(_IP))
+    assert rc == 0, rc
+    return used

@@ -154,3 +154,65 @@ def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
     for k in ["impact_x", "impact_y"]:  # up to a global sign (see assert_state_close)
         np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
+
+
+INTERSECTION = ["intersection_default", "intersection_dense"]
+
+
+class GoldenIntersection:
+    """Fixtures of tests/golden/make_golden_intersection.py (IntersectionEnv); state dicts for oracle/oracle_ix.py."""
+
+    def __init__(self, name: str):
+        import json
+
+        from oracle import oracle_ix
+        self.ix = oracle_ix
+        self.name = name
+        self.z = z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.E, self.N, self.T, self.steps, self.frames_for, self.A, self.R = (int(v) for v in z["meta"])
+        self.config = json.loads(str(z["cfg_json"]))
+        self.actions = z["actions"]  # [steps, E, 1]
+        self.lane_tab = {k: z["lane_" + k] for k in oracle_ix.LANE_F64 + oracle_ix.LANE_I32}
+
+    def ix_config(self, num_envs=None):
+        return self.ix.make_config(self.config, self.lane_tab, self.z["node_names"],
+                                   self.E if num_envs is None else num_envs, self.N, self.R)
+
+    def state(self, prefix: str, index=None, envs=None, road_steps=None, time=0.0) -> dict:
+        z = self.z
+
+        def get(k):
+            a = z[f"{prefix}_{k}"]
+            if index is not None:
+                a = a[index]
+            if envs is not None:
+                a = a[envs]
+            return a
+
+        E = get("x").shape[0]
+        st = self.ix.alloc_state(E, self.N, self.R)
+        for k in self.ix.STATE_F64 + self.ix.STATE_I32 + self.ix.STATE_ROUTE:
+            st[k][...] = get(k)
+        st["vid"] = np.array(get("vid"))
+        if road_steps is not None:
+            st["road_steps"][...] = road_steps
+        st["time"][...] = time
+        return st
+
+
+def assert_ix_state_close(got: dict, want: dict, atol=1e-9, what=""):
+    pres = want["present"] != 0
+    np.testing.assert_array_equal(got["present"] != 0, pres, err_msg=f"{what}: present")
+    for k in ["lane", "target_lane", "crashed", "has_impact", "controlled", "is_yielding", "route_len"]:
+        np.testing.assert_array_equal(got[k][pres], want[k][pres], err_msg=f"{what}: {k}")
+    for k in ["route_from", "route_to", "route_id"]:
+        m = pres[..., None] & (np.arange(want[k].shape[-1]) < want["route_len"][..., None])
+        np.testing.assert_array_equal(got[k][m], want[k][m], err_msg=f"{what}: {k}")
+    ctrl = pres & (want["controlled"] != 0)
+    np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
+    for k in ["x", "y", "heading", "speed", "target_speed"]:
+        np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+    for k in ["impact_x", "impact_y"]:
+        np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+    idm = pres & (want["controlled"] == 0)
+    np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
