@@ -13,12 +13,14 @@ import ctypes as C
 
 import numpy as np
 
-HWY_ABI_VERSION = 3
+HWY_ABI_VERSION = 4
 HWY_MAX_AGENTS = 16
 HWY_MAX_FEATURES = 16
 HWY_MAX_TARGET_SPEEDS = 8
 HWY_MAX_LANES = 16
 HWY_MAX_VEHICLES = 256
+HWY_MAX_GLANES = 24
+HWY_MAX_ROUTE = 3
 
 # hwy_status
 HWY_OK, HWY_ERR_INVALID_ARG, HWY_ERR_HIP, HWY_ERR_UNSUPPORTED, HWY_ERR_NO_DEVICE, HWY_ERR_ACTION = 0, -1, -2, -3, -4, -5
@@ -26,11 +28,13 @@ HWY_OK, HWY_ERR_INVALID_ARG, HWY_ERR_HIP, HWY_ERR_UNSUPPORTED, HWY_ERR_NO_DEVICE
 # per-vehicle flags
 F_CRASHED, F_HAS_IMPACT, F_CHECK_COLLISIONS, F_CONTROLLED = 1, 2, 4, 8
 F_OBSTACLE, F_ABSENT = 16, 32  # road-network scenarios only
-SCENARIO_HIGHWAY, SCENARIO_MERGE, SCENARIO_MERGE_GENERIC = 0, 1, 2
+F_YIELDING = 64                # intersection scenario only
+SCENARIO_HIGHWAY, SCENARIO_MERGE, SCENARIO_MERGE_GENERIC, SCENARIO_INTERSECTION = 0, 1, 2, 3
 # config flags
 C_NORMALIZE_REWARD, C_OFFROAD_TERMINAL, C_OBS_ABSOLUTE, C_OBS_NORMALIZE, C_OBS_CLIP, C_OBS_SEE_BEHIND = 1, 2, 4, 8, 16, 32
 C_EGO_ONLY_COLLISIONS = 64
 C_GRID_ALIGN = 128
+C_HOST_TRAFFIC = 256
 OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
 HWY_MAX_GRID_CELLS = 65536
 
@@ -54,6 +58,18 @@ class HwyLane(C.Structure):
 
 LANE_F64 = ["x0", "y0", "length", "width", "amplitude", "pulsation", "phase", "speed_limit"]
 LANE_I32 = ["road", "id", "road_first", "road_lanes", "next_first", "next_lanes", "forbidden"]
+
+
+class HwyGLane(C.Structure):
+    """hwy_glane: one lane of a general RoadNetwork -- StraightLane of any direction or CircularLane."""
+    _fields_ = ([(k, C.c_int32) for k in ["kind", "direction", "priority", "forbidden", "from_node", "to_node",
+                                          "exit_lane", "reserved"]]
+                + [(k, C.c_double) for k in ["sx", "sy", "heading", "dirx", "diry", "cx", "cy", "radius",
+                                             "start_phase", "length", "width", "speed_limit"]])
+
+
+GLANE_F64 = ["sx", "sy", "heading", "dirx", "diry", "cx", "cy", "radius", "start_phase", "length", "width", "speed_limit"]
+GLANE_I32 = ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "exit_lane"]
 
 
 class HwyConfig(C.Structure):
@@ -100,6 +116,20 @@ class HwyConfig(C.Structure):
         ("merging_speed_reward", C.c_double),
         ("lane_change_reward", C.c_double),
         ("net", HwyLane * HWY_MAX_LANES),
+        # HWY_SCENARIO_INTERSECTION (ABI v4)
+        ("gnet_lanes", C.c_int32),
+        ("initial_vehicle_count", C.c_int32),
+        ("destination", C.c_int32),
+        ("reserved3", C.c_int32),
+        ("access_lane", C.c_int32 * 4),
+        ("exit_of", C.c_int32 * 4),
+        ("spawn_probability", C.c_double),
+        ("arrived_reward", C.c_double),
+        ("idm_distance_wanted", C.c_double),
+        ("idm_time_wanted", C.c_double),
+        ("idm_comfort_acc_max", C.c_double),
+        ("idm_comfort_acc_min", C.c_double),
+        ("gnet", HwyGLane * HWY_MAX_GLANES),
     ]
 
 
@@ -118,7 +148,8 @@ STATE_I32 = ["lane", "target_lane", "speed_index", "flags"]
 
 
 class HwyState(C.Structure):
-    _fields_ = ([(n, _DP) for n in STATE_F64] + [(n, _IP) for n in STATE_I32] + [("time", _DP)])
+    _fields_ = ([(n, _DP) for n in STATE_F64] + [(n, _IP) for n in STATE_I32] + [("time", _DP)]
+                + [("route", _IP), ("road_steps", _IP)])  # intersection scenario only (NULL otherwise)
 
 
 def alloc_state(num_envs: int, num_vehicles: int) -> dict:
@@ -126,6 +157,15 @@ def alloc_state(num_envs: int, num_vehicles: int) -> dict:
     st = {k: np.zeros((num_envs, num_vehicles), np.float64) for k in STATE_F64}
     st.update({k: np.zeros((num_envs, num_vehicles), np.int32) for k in STATE_I32})
     st["time"] = np.zeros(num_envs, np.float64)
+    return st
+
+
+def alloc_state_ix(num_envs: int, num_vehicles: int) -> dict:
+    """Host SoA of the intersection scenario: + packed planned routes and RegulatedRoad.steps; every slot absent."""
+    st = alloc_state(num_envs, num_vehicles)
+    st["flags"][...] = F_ABSENT
+    st["route"] = np.zeros((num_envs, num_vehicles), np.int32)
+    st["road_steps"] = np.zeros(num_envs, np.int32)
     return st
 
 
@@ -140,6 +180,11 @@ def state_struct(st: dict) -> HwyState:
         a = st[k]
         assert a.dtype == np.int32 and a.flags.c_contiguous, k
         setattr(s, k, a.ctypes.data_as(_IP))
+    for k in ("route", "road_steps"):  # intersection scenario
+        if k in st:
+            a = st[k]
+            assert a.dtype == np.int32 and a.flags.c_contiguous, k
+            setattr(s, k, a.ctypes.data_as(_IP))
     return s
 
 
@@ -237,7 +282,11 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         raise ValueError("Unknown action type")
     if act["type"] != "DiscreteMetaAction":
         raise NotImplementedError(f"action type {act['type']} is outside the MI355X hot-path scope")
-    if not (act.get("longitudinal", True) and act.get("lateral", True)):
+    ix = scenario == "intersection"
+    if ix:
+        if not act.get("longitudinal", True) or act.get("lateral", True):
+            raise NotImplementedError("the intersection scenario takes longitudinal-only meta-actions")
+    elif not (act.get("longitudinal", True) and act.get("lateral", True)):
         raise NotImplementedError("DiscreteMetaAction with longitudinal/lateral disabled is out of scope")
     obs = cfg["observation"]
     if obs["type"] == "MultiAgentObservation":
@@ -253,14 +302,16 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     if cfg.get("other_vehicles_type", "highway_env.vehicle.behavior.IDMVehicle") != "highway_env.vehicle.behavior.IDMVehicle":
         raise NotImplementedError("only IDMVehicle traffic is in the hot-path scope")
     merge = scenario in ("merge", "merge-generic")
-    if scenario != "highway" and not merge:
+    if scenario != "highway" and not merge and not ix:
         raise ValueError(f"unknown scenario {scenario!r}")
     if cfg.get("neighbour_vehicles_connected_lanes", False):
         raise NotImplementedError("neighbour_vehicles_connected_lanes (merge-v1 / merge-generic-v1) is out of scope"
                                   if merge else
                                   "neighbour_vehicles_connected_lanes is meaningless on a single-segment highway")
-    if merge and grid:
+    if (merge or ix) and grid:
         raise NotImplementedError("OccupancyGrid is implemented for the straight-road scenarios only")
+    if ix and cfg.get("neighbour_vehicles_connected_lanes", False):
+        raise NotImplementedError("neighbour_vehicles_connected_lanes (intersection-v2) is out of scope")
     if not grid and obs.get("order", "sorted") != "sorted":
         raise NotImplementedError("KinematicObservation order='shuffled' is out of scope")
 
@@ -275,7 +326,11 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     c.dt = 1 / cfg["simulation_frequency"]
     c.policy_dt = 1 / cfg["policy_frequency"]
     c.lane_width = 4.0        # AbstractLane.DEFAULT_WIDTH (road/lane.py:16)
-    if merge:
+    if ix:
+        from . import intersection as _ix
+        _ix.fill_config(c, cfg)
+        y_lanes = 1
+    elif merge:
         from . import merge as _merge
         _merge.fill_config(c, cfg, generic=(scenario == "merge-generic"))
         y_lanes = _merge.ego_road_lanes(cfg, generic=(scenario == "merge-generic"))
@@ -300,7 +355,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     for k, v in enumerate(ts):
         c.target_speeds[k] = float(v)
     c.collision_reward = float(cfg["collision_reward"])
-    c.right_lane_reward = float(cfg["right_lane_reward"])
+    c.right_lane_reward = float(cfg.get("right_lane_reward", 0.0))
     c.high_speed_reward = float(cfg["high_speed_reward"])
     c.reward_speed_range[0], c.reward_speed_range[1] = map(float, cfg["reward_speed_range"])
     c.perception_distance = 5.0 * 40.0  # AbstractEnv.PERCEPTION_DISTANCE (abstract.py:58)
@@ -349,7 +404,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         if name not in ("x", "y", "vx", "vy"):
             raise NotImplementedError(f"features_range for {name!r} is out of scope")
     flags = 0
-    if cfg.get("normalize_reward", False) and not merge:
+    if cfg.get("normalize_reward", False) and not merge:  # (IntersectionEnv: lmap to [collision, arrived] rewards)
         flags |= C_NORMALIZE_REWARD
     if cfg.get("offroad_terminal", False) and not merge:
         flags |= C_OFFROAD_TERMINAL
@@ -363,6 +418,14 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         flags |= C_OBS_SEE_BEHIND
     if merge and not obs.get("include_obstacles", True):
         raise NotImplementedError("KinematicObservation include_obstacles=False is out of scope")
+    if ix:
+        for name in feats:
+            if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h"):
+                raise NotImplementedError(f"feature {name!r} is out of scope for the intersection scenario")
+        if obs.get("observe_intentions", False):
+            raise NotImplementedError("observe_intentions is out of scope")
+        if cfg.get("host_traffic", False):
+            flags |= C_HOST_TRAFFIC
     if merge:
         # the Obstacle's to_dict (vehicle/objects.py:141-160) has no heading / lane-offset keys: the reference
         # would put NaN in those columns whenever the obstacle is observed

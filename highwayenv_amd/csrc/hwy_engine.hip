@@ -31,6 +31,9 @@ struct hwy_engine {
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
+  int32_t *d_route = nullptr;       // intersection scenario: planned routes [E x pitch]
+  int32_t *d_road_steps = nullptr;  // intersection scenario: RegulatedRoad.steps [E]
+  hwy_glane *d_gnet = nullptr;      // intersection scenario: lane table
   double *d_time = nullptr;
   uint8_t *d_done = nullptr;
   uint32_t *d_episode = nullptr;
@@ -126,7 +129,24 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->num_target_speeds < 2 || c->num_target_speeds > HWY_MAX_TARGET_SPEEDS) BAD("num_target_speeds must be in [2,%d]", HWY_MAX_TARGET_SPEEDS);
   if (!(c->dt > 0) || !(c->policy_dt > 0)) BAD("dt and policy_dt must be positive");
   if (!(c->lane_width > 0) || !(c->road_length > 0)) BAD("lane_width and road_length must be positive");
-  if (c->scenario != HWY_SCENARIO_HIGHWAY) {
+  if (c->scenario == HWY_SCENARIO_INTERSECTION) {
+    if (c->obs_type != HWY_OBS_KINEMATICS) BAD("the intersection scenario supports the Kinematics observation only");
+    if (c->num_agents != 1) BAD("the intersection scenario has one controlled vehicle");
+    if (c->num_vehicles < 4 || c->num_vehicles > 64) BAD("the intersection scenario needs 4..64 slots (one wavefront per environment)");
+    if (c->gnet_lanes < 1 || c->gnet_lanes > HWY_MAX_GLANES) BAD("gnet_lanes must be in [1,%d]", HWY_MAX_GLANES);
+    if (c->destination < 0 || c->destination > 3) BAD("destination must be the k of \"o\" + k, 0..3");
+    if (c->initial_vehicle_count < 1) BAD("initial_vehicle_count must be positive");
+    for (int k = 0; k < 4; ++k)
+      if (c->access_lane[k] < 0 || c->access_lane[k] >= c->gnet_lanes || c->exit_of[k] < 0 || c->exit_of[k] >= c->gnet_lanes)
+        BAD("access_lane / exit_of out of range");
+    for (int k = 0; k < c->gnet_lanes; ++k) {
+      const hwy_glane &l = c->gnet[k];
+      if (!(l.length > 0) || !(l.width > 0)) BAD("gnet[%d]: length and width must be positive", k);
+      if (l.kind == 1 && !(l.radius > 0)) BAD("gnet[%d]: radius must be positive", k);
+      for (int q = 0; q < k; ++q)
+        if (c->gnet[q].from_node == l.from_node && c->gnet[q].to_node == l.to_node) BAD("gnet[%d]: every road holds one lane", k);
+    }
+  } else if (c->scenario != HWY_SCENARIO_HIGHWAY) {
     if (c->scenario != HWY_SCENARIO_MERGE && c->scenario != HWY_SCENARIO_MERGE_GENERIC) BAD("unknown scenario %d", c->scenario);
     if (c->obs_type != HWY_OBS_KINEMATICS) BAD("road-network scenarios support the Kinematics observation only");
     if (c->num_vehicles < 4 || c->num_vehicles > 64) BAD("road-network scenarios need 4..64 slots (one wavefront per environment)");
@@ -156,8 +176,20 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.grid_ws = eng->d_grid_ws;
 }
 
-static bool is_net(const hwy_engine *eng) { return eng->cfg.scenario != HWY_SCENARIO_HIGHWAY; }
+static bool is_ix(const hwy_engine *eng) { return eng->cfg.scenario == HWY_SCENARIO_INTERSECTION; }
+static bool is_net(const hwy_engine *eng) { return eng->cfg.scenario != HWY_SCENARIO_HIGHWAY && !is_ix(eng); }
+static void fill_ix(const hwy_engine *eng, const StepParams &p, hwy::IxParams &ip) {
+  hwy::ix_params_from_config(eng->cfg, p, ip);
+  ip.lanes = eng->d_gnet;
+  ip.route = eng->d_route;
+  ip.road_steps = eng->d_road_steps;
+}
 static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_ix(eng)) {
+    hwy::IxParams ip;
+    fill_ix(eng, p, ip);
+    return hwy::launch_ix_step(ip, eng->cfg.num_envs, eng->stream);
+  }
   if (is_net(eng)) {
     hwy::NetParams np;
     hwy::net_params_from_config(eng->cfg, p, np);
@@ -166,6 +198,11 @@ static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
   return hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel);
 }
 static hipError_t launch_reset_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_ix(eng)) {
+    hwy::IxParams ip;
+    fill_ix(eng, p, ip);
+    return hwy::launch_ix_reset(ip, eng->cfg.num_envs, eng->stream);
+  }
   if (is_net(eng)) {
     hwy::NetParams np;
     hwy::net_params_from_config(eng->cfg, p, np);
@@ -174,6 +211,11 @@ static hipError_t launch_reset_any(const hwy_engine *eng, const StepParams &p) {
   return hwy::launch_reset(p, eng->cfg.num_envs, eng->stream);
 }
 static hipError_t launch_observe_any(const hwy_engine *eng, const StepParams &p) {
+  if (is_ix(eng)) {
+    hwy::IxParams ip;
+    fill_ix(eng, p, ip);
+    return hwy::launch_ix_observe(ip, eng->cfg.num_envs, eng->stream);
+  }
   if (is_net(eng)) {
     hwy::NetParams np;
     hwy::net_params_from_config(eng->cfg, p, np);
@@ -205,7 +247,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
   if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
   // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
-  if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
+  if (cfg->scenario != HWY_SCENARIO_HIGHWAY && cfg->scenario != HWY_SCENARIO_INTERSECTION) eng->waves_per_eu = 4;
   if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
     const int v = std::atoi(w);
     if (v >= 1 && v <= 4) eng->waves_per_eu = v;
@@ -229,6 +271,14 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) return bail(e, "hipMalloc " #ptr)
   ALLOC(eng->d_f64, plane * 9 * sizeof(double));
   ALLOC(eng->d_packed, plane * sizeof(int32_t));
+  if (cfg->scenario == HWY_SCENARIO_INTERSECTION) {
+    ALLOC(eng->d_route, plane * sizeof(int32_t));
+    ALLOC(eng->d_road_steps, E * sizeof(int32_t));
+    ALLOC(eng->d_gnet, sizeof(hwy_glane) * HWY_MAX_GLANES);
+    if ((e = hipMemsetAsync(eng->d_route, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemsetAsync(eng->d_road_steps, 0, E * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemcpy(eng->d_gnet, cfg->gnet, sizeof(hwy_glane) * HWY_MAX_GLANES, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+  }
   ALLOC(eng->d_time, E * sizeof(double));
   ALLOC(eng->d_done, E);
   ALLOC(eng->d_episode, E * sizeof(uint32_t));
@@ -262,7 +312,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   if ((e = hipMemsetAsync(eng->d_done, 0, E, eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMemsetAsync(eng->d_episode, 0, E * sizeof(uint32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   // pinned staging: the largest of {state SoA, step I/O}
-  const size_t state_bytes = plane * (9 * sizeof(double) + sizeof(int32_t)) + E * sizeof(double);
+  const size_t state_bytes = plane * (9 * sizeof(double) + 2 * sizeof(int32_t)) + E * (sizeof(double) + sizeof(int32_t));
   const size_t io_bytes = eng->out_bytes + n_act * 4 + E * 9 + 64;
   eng->h_pinned_bytes = state_bytes > io_bytes ? state_bytes : io_bytes;
   if ((e = hipHostMalloc(&eng->h_pinned, eng->h_pinned_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
@@ -284,7 +334,7 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out,
-                  eng->d_mask, eng->d_seeds, eng->d_grid_ws};
+                  eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -314,7 +364,8 @@ extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
   HWY_HIP(eng, hipSetDevice(eng->device));
   const int E = eng->cfg.num_envs, N = eng->cfg.num_vehicles, P = eng->pitch;
   const size_t plane = (size_t)E * P;
-  const int n_lane_ids = is_net(eng) ? eng->cfg.net_lanes : eng->cfg.lanes_count;
+  const int n_lane_ids = is_ix(eng) ? eng->cfg.gnet_lanes : is_net(eng) ? eng->cfg.net_lanes : eng->cfg.lanes_count;
+  if (is_ix(eng) && (!h->route || !h->road_steps)) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: route / road_steps are required by the intersection scenario");
   for (size_t k = 0; k < (size_t)E * N; ++k) {
     if (h->lane[k] < 0 || h->lane[k] >= n_lane_ids || h->target_lane[k] < 0 || h->target_lane[k] >= n_lane_ids)
       return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_state: lane index out of range");
@@ -327,10 +378,21 @@ extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
   for (int e = 0; e < E; ++e)
     for (int i = 0; i < P; ++i) {
       const size_t k = (size_t)e * N + i;
-      pk[(size_t)e * P + i] = i < N ? hwy::pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k], i) : 0;
+      if (is_ix(eng)) pk[(size_t)e * P + i] = i < N ? hwy::ix_pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k])
+                                                    : hwy::ix_pack_word(0, 0, 0, HWY_F_ABSENT);
+      else pk[(size_t)e * P + i] = i < N ? hwy::pack_word(h->lane[k], h->target_lane[k], h->speed_index[k], h->flags[k], i) : 0;
     }
   double *tm = (double *)(pk + plane);
   std::memcpy(tm, h->time, sizeof(double) * E);
+  if (is_ix(eng)) {
+    int32_t *rt = (int32_t *)(tm + E);
+    int32_t *rs = rt + plane;
+    for (int e = 0; e < E; ++e)
+      for (int i = 0; i < P; ++i) rt[(size_t)e * P + i] = i < N ? h->route[(size_t)e * N + i] : 0;
+    std::memcpy(rs, h->road_steps, sizeof(int32_t) * E);
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_route, rt, plane * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_road_steps, rs, E * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
+  }
   HWY_HIP(eng, hipMemcpyAsync(eng->d_f64, stage, plane * 9 * sizeof(double), hipMemcpyHostToDevice, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(eng->d_packed, pk, plane * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(eng->d_time, tm, E * sizeof(double), hipMemcpyHostToDevice, eng->stream));
@@ -350,7 +412,30 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
   HWY_HIP(eng, hipMemcpyAsync(stage, eng->d_f64, plane * 9 * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(pk, eng->d_packed, plane * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(tm, eng->d_time, E * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
+  int32_t *rt = (int32_t *)(tm + E);
+  int32_t *rs = rt + plane;
+  if (is_ix(eng)) {
+    HWY_HIP(eng, hipMemcpyAsync(rt, eng->d_route, plane * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
+    HWY_HIP(eng, hipMemcpyAsync(rs, eng->d_road_steps, E * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
+  }
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  if (is_ix(eng)) {
+    for (int e = 0; e < E; ++e)
+      for (int i = 0; i < N; ++i) {
+        const int32_t w = pk[(size_t)e * P + i];
+        const size_t k = (size_t)e * N + i;
+        if (h->lane) h->lane[k] = hwy::ix_word_lane(w);
+        if (h->target_lane) h->target_lane[k] = hwy::ix_word_target(w);
+        if (h->speed_index) h->speed_index[k] = hwy::ix_word_speed_index(w);
+        if (h->flags) h->flags[k] = hwy::ix_word_flags(w);
+        if (h->route) h->route[k] = rt[(size_t)e * P + i];
+      }
+    if (h->road_steps) std::memcpy(h->road_steps, rs, sizeof(int32_t) * E);
+    double *flds[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};
+    for (int f = 0; f < 9; ++f) if (flds[f]) unpack_rows(eng, stage + f * plane, flds[f]);
+    if (h->time) std::memcpy(h->time, tm, sizeof(double) * E);
+    return HWY_OK;
+  }
   double *fields[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};
   for (int f = 0; f < 9; ++f) if (fields[f]) unpack_rows(eng, stage + f * plane, fields[f]);
   for (int e = 0; e < E; ++e)
@@ -446,8 +531,9 @@ extern "C" int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, dou
   io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
   const size_t E = eng->cfg.num_envs;
   // the reference raises KeyError for an unknown meta-action before touching the simulation (action.py:260)
+  const int max_action = is_ix(eng) ? 2 : 4;  // IntersectionEnv.ACTIONS has 3 entries (intersection_env.py:14)
   for (size_t k = 0; k < n_act; ++k)
-    if (actions[k] < 0 || actions[k] > 4) return fail(eng, HWY_ERR_ACTION, "meta-action outside [0,5)");
+    if (actions[k] < 0 || actions[k] > max_action) return fail(eng, HWY_ERR_ACTION, is_ix(eng) ? "meta-action outside [0,3)" : "meta-action outside [0,5)");
   HWY_HIP(eng, hipSetDevice(eng->device));
   // pinned layout: [mirror of the device output block][actions]
   char *h_out = (char *)eng->h_pinned;
@@ -480,7 +566,7 @@ extern "C" int hwy_step_frames(hwy_engine *eng, const int32_t *actions, int32_t 
   p.autoreset = 0;
   if (actions) {
     for (size_t k = 0; k < n_act; ++k)
-      if (actions[k] < 0 || actions[k] > 4) return fail(eng, HWY_ERR_ACTION, "meta-action outside [0,5)");
+      if (actions[k] < 0 || actions[k] > (is_ix(eng) ? 2 : 4)) return fail(eng, HWY_ERR_ACTION, "meta-action out of range");
     std::memcpy(eng->h_pinned, actions, n_act * 4);
     HWY_HIP(eng, hipMemcpyAsync(eng->d_actions, eng->h_pinned, n_act * 4, hipMemcpyHostToDevice, eng->stream));
     p.actions = eng->d_actions;

@@ -1,0 +1,786 @@
+// hwy_ix.h -- the fused policy-step kernel for the INTERSECTION scenario (IntersectionEnv,
+// highway_env/envs/intersection_env.py): ONE 64-wide wavefront per environment,
+// thread i == slot i of the vehicle arrays (Road.vehicles order; HWY_F_ABSENT slots after the last vehicle, the list
+// is re-compacted whenever vehicles are cleared).
+//
+// What differs from the x-aligned formulations (hwy_wave.h, hwy_net.h): the lanes of this network point in every
+// direction and a third of them are circular arcs, so there is no single sort key along "the road".  Instead every
+// vehicle projects itself on EVERY lane once per frame (one walk over the lane table after the integration: the
+// same projections give the new lane index -- get_closest_lane_index -- the membership bits of the next frame and
+// the longitudinal coordinate s on each lane, parked in LDS), one ballot per lane turns the bits into slot-space
+// masks, and a front / rear query on lane L is a walk over the few set bits of mask[L] reading s[L][j] from LDS.
+//   * planned routes (controller.py:71-87; next_lane, road.py:73-133): every road has one lane, a route is a list of
+//     lane-table indices in one packed word;
+//   * RegulatedRoad (road/regulation.py): every int(1 / dt / 2) frames every vehicle predicts 11 constant-speed poses
+//     along its route ONCE (LDS), then each thread tests itself against every other slot (sphere check, rotated
+//     rectangles with the reference's 9 sample points) and decides from lane priorities whether IT yields -- the
+//     reference's pair loop is order-independent (a vehicle yields iff some pair names it);
+//   * Road.act is order-independent here too (one-lane roads: no lane-change abort chain), collisions keep the
+//     "last pair in loop order wins" rule through "highest partner slot wins";
+//   * IntersectionEnv.step clears leaving vehicles and spawns at most one per policy step (intersection_env.py:
+//     136-140, 292-338): stable compaction by ballot + ds_permute, Philox draws (not numpy's stream).
+#pragma once
+
+#include "hwy_device.h"
+#include "hwy_wave.h"
+
+namespace hwy {
+
+struct IxParams {
+  StepParams s;  // must stay first
+  int32_t n_lanes, initial_count, host_spawn, destination;  // host_spawn: the host clears / spawns (reference stream)
+  int32_t access_lane[4], exit_of[4];
+  double spawn_probability, arrived_reward, d0, tau, a_max, b_min;
+  const hwy_glane *lanes;  // device memory [n_lanes]
+  int32_t *route;          // [E][pitch]
+  int32_t *road_steps;     // [E]
+};
+
+// packed per-vehicle word of this scenario: lane[0:4] | target_lane[5:9] | speed_index[10:12] | flags[13:19]
+__host__ __device__ inline int32_t ix_pack_word(int lane, int tgt, int sidx, int flags) {
+  return (lane & 0x1f) | ((tgt & 0x1f) << 5) | ((sidx & 0x7) << 10) | ((flags & 0x7f) << 13);
+}
+__host__ __device__ inline int ix_word_lane(int32_t w) { return w & 0x1f; }
+__host__ __device__ inline int ix_word_target(int32_t w) { return (w >> 5) & 0x1f; }
+__host__ __device__ inline int ix_word_speed_index(int32_t w) { return (w >> 10) & 0x7; }
+__host__ __device__ inline int ix_word_flags(int32_t w) { return (w >> 13) & 0x7f; }
+// route word: r0 | r1 << 5 | r2 << 10 | len << 15
+__host__ __device__ inline int route_len(int32_t r) { return (r >> 15) & 0x3; }
+__host__ __device__ inline int route_at(int32_t r, int k) { return (r >> (5 * k)) & 0x1f; }
+__host__ __device__ inline int32_t route_pop(int32_t r) { return ((r >> 5) & 0x3ff) | ((route_len(r) - 1) << 15); }
+__host__ __device__ inline int32_t route_make(int r0, int r1, int r2, int len) {
+  return (r0 & 0x1f) | ((r1 & 0x1f) << 5) | ((r2 & 0x1f) << 10) | (len << 15);
+}
+
+struct IxVeh {
+  double x, y, h, v, timer, ts, delta, impx, impy;
+  int lane, tgt, sidx, flags, route;
+};
+
+#define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
+
+struct IxShared {
+  // lane table (struct of arrays: per-thread lane indices read it with one ds_read each)
+  int kind[HWY_MAX_GLANES], ldir[HWY_MAX_GLANES], prio[HWY_MAX_GLANES], from[HWY_MAX_GLANES], to[HWY_MAX_GLANES],
+      exitl[HWY_MAX_GLANES];
+  double sx[HWY_MAX_GLANES], sy[HWY_MAX_GLANES], lhead[HWY_MAX_GLANES], dirx[HWY_MAX_GLANES], diry[HWY_MAX_GLANES],
+      cx[HWY_MAX_GLANES], cy[HWY_MAX_GLANES], rad[HWY_MAX_GLANES], sph[HWY_MAX_GLANES], len[HWY_MAX_GLANES],
+      wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
+  u64 mask[HWY_MAX_GLANES];  // slot-space membership (on_lane, margin 1) of every lane
+  // frame snapshot by slot
+  double x[64], y[64], v[64], c[64], s[64];
+  union {
+    double sl[HWY_MAX_GLANES][64];           // longitudinal coordinate of slot i on lane L (act phase)
+    double traj[HWY_IX_SAMPLES][3][64];      // predicted (x, y, heading) of slot i at sample k (regulation)
+  };
+};
+
+// ---- lane geometry from the LDS table, per-thread lane index ---------------------------------------------------
+// StraightLane.local_coordinates (lane.py:209-213); CircularLane.local_coordinates (lane.py:355-362)
+__device__ inline void ix_local(const IxShared &sh, int L, double x, double y, double *s, double *lat) {
+  if (sh.kind[L] == 0) {
+    const double dx = x - sh.sx[L], dy = y - sh.sy[L];
+    *s = dx * sh.dirx[L] + dy * sh.diry[L];
+    *lat = dx * -sh.diry[L] + dy * sh.dirx[L];
+  } else {
+    const double dx = x - sh.cx[L], dy = y - sh.cy[L];
+    double phi = atan2(dy, dx);
+    phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
+    const double r = sqrt(dx * dx + dy * dy);
+    *s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
+    *lat = sh.ldir[L] * (sh.rad[L] - r);
+  }
+}
+// heading_at (lane.py:203-204, 347-350)
+__device__ inline double ix_heading_at(const IxShared &sh, int L, double s) {
+  if (sh.kind[L] == 0) return sh.lhead[L];
+  const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
+  return phi + HWY_PI / 2 * sh.ldir[L];
+}
+// position(s, 0) (lane.py:196-201, 341-345)
+__device__ inline void ix_position(const IxShared &sh, int L, double s, double *px, double *py) {
+  if (sh.kind[L] == 0) {
+    *px = sh.sx[L] + s * sh.dirx[L] + 0.0 * -sh.diry[L];
+    *py = sh.sy[L] + s * sh.diry[L] + 0.0 * sh.dirx[L];
+  } else {
+    const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
+    *px = sh.cx[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * cos(phi);
+    *py = sh.cy[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * sin(phi);
+  }
+}
+
+__device__ inline void ix_load_table(const IxParams &ip, IxShared &sh) {
+  const int i = threadIdx.x;
+  if (i < ip.n_lanes) {
+    const hwy_glane &l = ip.lanes[i];
+    sh.kind[i] = l.kind; sh.ldir[i] = l.direction; sh.prio[i] = l.priority; sh.from[i] = l.from_node;
+    sh.to[i] = l.to_node; sh.exitl[i] = l.exit_lane;
+    sh.sx[i] = l.sx; sh.sy[i] = l.sy; sh.lhead[i] = l.heading; sh.dirx[i] = l.dirx; sh.diry[i] = l.diry;
+    sh.cx[i] = l.cx; sh.cy[i] = l.cy; sh.rad[i] = l.radius; sh.sph[i] = l.start_phase; sh.len[i] = l.length;
+    sh.wid[i] = l.width; sh.lim[i] = l.speed_limit;
+  }
+  __syncthreads();
+}
+
+// One walk over the lane table for my body (lane index wave-uniform): membership bits (on_lane margin 1, lane.py:80-102),
+// closest lane (road.py:55-71, lane.py:132-147; first minimum in table order) and s on every lane -> sh.sl[L][i].
+__device__ inline void ix_lane_pass(const IxParams &ip, IxShared &sh, double x, double y, double h, int *bits_out,
+                                    int *closest_out) {
+  const int i = threadIdx.x;
+  int bits = 0, best = 0;
+  double bd = 0.0;
+  for (int L = 0; L < ip.n_lanes; ++L) {
+    double s, lat, lane_h;
+    if (sh.kind[L] == 0) {  // wave-uniform
+      const double dx = x - sh.sx[L], dy = y - sh.sy[L];
+      s = dx * sh.dirx[L] + dy * sh.diry[L];
+      lat = dx * -sh.diry[L] + dy * sh.dirx[L];
+      lane_h = sh.lhead[L];
+    } else {
+      const double dx = x - sh.cx[L], dy = y - sh.cy[L];
+      double phi = atan2(dy, dx);
+      phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
+      const double r = sqrt(dx * dx + dy * dy);
+      s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
+      lat = sh.ldir[L] * (sh.rad[L] - r);
+      lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
+    }
+    const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
+    bits |= on ? (1 << L) : 0;
+    sh.sl[L][i] = s;
+    const double angle = fabs(wrap_to_pi(h - lane_h));
+    const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+    if (L == 0 || d < bd) { bd = d; best = L; }
+  }
+  *bits_out = bits;
+  *closest_out = best;
+}
+
+// Road.neighbour_vehicles (road.py:483-547, connected lanes off): the leader on lane L among the members of mask[L]
+// (slot order == list order: `<=` lets a later vehicle at the same s win, like the reference's scan)
+__device__ inline int ix_front(const IxShared &sh, int L, int self) {
+  const double s = sh.sl[L][self];
+  int f = -1;
+  double s_front = 0.0;
+  for (u64 m = sh.mask[L] & ~((u64)1 << self); m; m &= m - 1) {
+    const int j = ctz64(m);
+    const double s_v = sh.sl[L][j];
+    if (s <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
+  }
+  return f;
+}
+
+// RoadNetwork.next_lane (road.py:73-133) for one-lane roads; consumes the head of the route like route.pop(0)
+__device__ inline int ix_next_lane(const IxParams &ip, const IxShared &sh, int cur, IxVeh &me) {
+  int next = -1;
+  if (route_len(me.route) > 0) {
+    if (route_at(me.route, 0) == cur) me.route = route_pop(me.route);
+    if (route_len(me.route) > 0 && sh.from[route_at(me.route, 0)] == sh.to[cur]) next = route_at(me.route, 0);
+  }
+  if (next >= 0) return next;
+  // no planned successor: the lane leaving `to` that is closest to the projected position (first minimum)
+  double s, lat, px, py;
+  ix_local(sh, cur, me.x, me.y, &s, &lat);
+  ix_position(sh, cur, s, &px, &py);
+  double bd = 0.0;
+  for (int K = 0; K < ip.n_lanes; ++K) {
+    if (sh.from[K] != sh.to[cur]) continue;
+    double s2, r2;
+    ix_local(sh, K, px, py, &s2, &r2);
+    const double d = fabs(r2) + fmax(s2 - sh.len[K], 0.0) + fmax(0 - s2, 0.0);
+    if (next < 0 || d < bd) { bd = d; next = K; }
+  }
+  return next < 0 ? cur : next;  // KeyError -> current index
+}
+
+// position_heading_along_route (road.py:323-362) with lateral 0: route = v.route or [v.lane_index]
+__device__ inline void ix_along_route(const IxShared &sh, const IxVeh &me, double lon, double *px, double *py, double *hd) {
+  const int n = route_len(me.route);
+  int pos = 0;
+  int li = n > 0 ? route_at(me.route, 0) : me.lane;
+  while (n - pos > 1 && lon > sh.len[li]) {
+    lon -= sh.len[li];
+    ++pos;
+    li = route_at(me.route, pos);
+  }
+  ix_position(sh, li, lon, px, py);
+  *hd = ix_heading_at(sh, li, lon);
+}
+
+// utils.has_corner_inside (utils.py:160-174): the 9 sample points of rect 1 (corners, centre, edge midpoints) against
+// rect 2 with the reference's +angle rotation (utils.py:79-95)
+__device__ inline bool ix_corner_inside(double c1x, double c1y, double a1, double c2x, double c2y, double a2) {
+  const double hl = 1.5 * HWY_VEH_LENGTH / 2, hw = 0.9 * HWY_VEH_WIDTH / 2;
+  const double c = cos(a1), s = sin(a1), c2 = cos(a2), s2 = sin(a2);
+  bool any = false;
+  for (int k = 0; k < 9; ++k) {
+    const double qx = (k == 0 || k == 1 || k == 5) ? -hl : ((k == 2 || k == 3 || k == 6) ? hl : (k == 7 ? -0.0 : 0.0));
+    const double qy = (k == 0 || k == 3 || k == 7) ? -hw : ((k == 1 || k == 2 || k == 8) ? hw : (k == 5 ? -0.0 : 0.0));
+    const double x = (c * qx + -s * qy) + c1x, y = (s * qx + c * qy) + c1y;
+    const double dx = x - c2x, dy = y - c2y;
+    const double rux = c2 * dx + -s2 * dy, ruy = s2 * dx + c2 * dy;
+    any = any || (-hl <= rux && rux <= hl && -hw <= ruy && ruy <= hw);
+  }
+  return any;
+}
+
+// Vehicle ctor pieces shared by the device spawn paths: lane index, IDM timer, planned route to "o" + dest
+__device__ inline int ix_plan_route(const IxParams &ip, const IxShared &sh, int lane, int dest) {
+  // plan_route_to (controller.py:71-87): [lane_index] + shortest path lane_index[1] -> "o" + dest; on this network
+  // the path from the end of an access lane is always [turn / crossing lane, exit lane]
+  const int ex = ip.exit_of[dest];
+  if (lane == ex) return route_make(lane, 0, 0, 1);
+  if (sh.to[lane] == sh.from[ex]) return route_make(lane, ex, 0, 2);
+  for (int K = 0; K < ip.n_lanes; ++K)
+    if (sh.from[K] == sh.to[lane] && sh.to[K] == sh.from[ex]) return route_make(lane, K, ex, 3);
+  return route_make(lane, 0, 0, 1);  // no path: route == [lane_index]
+}
+
+__device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  o = IxVeh{};
+  o.flags = HWY_F_ABSENT;
+  if (i < p.N) {
+    const size_t k = (size_t)e * p.pitch + i;
+    o.x = p.st.x[k]; o.y = p.st.y[k]; o.h = p.st.heading[k]; o.v = p.st.speed[k];
+    o.timer = p.st.timer[k]; o.ts = p.st.target_speed[k]; o.delta = p.st.delta[k];
+    const int w = p.st.packed[k];
+    o.lane = ix_word_lane(w); o.tgt = ix_word_target(w); o.sidx = ix_word_speed_index(w); o.flags = ix_word_flags(w);
+    o.route = ip.route[k];
+    if (o.flags & HWY_F_HAS_IMPACT) {
+      o.impx = p.st.impact_x[k];
+      o.impy = p.st.impact_y[k];
+    }
+  }
+}
+__device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  if (i < p.N) {
+    const size_t k = (size_t)e * p.pitch + i;
+    p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
+    p.st.timer[k] = o.timer; p.st.target_speed[k] = o.ts; p.st.delta[k] = o.delta;
+    p.st.packed[k] = ix_pack_word(o.lane, o.tgt, o.sidx, o.flags);
+    ip.route[k] = o.route;
+    p.st.impact_x[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impx : 0.0;
+    p.st.impact_y[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impy : 0.0;
+  }
+}
+
+// ---- n_frames x { [meta-action]; Road.act(); RegulatedRoad.step(dt) } on the wave's registers + LDS --------------
+__device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh &me, int n_frames, const int32_t *actions,
+                                 int &road_steps, int &bits) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  const int every = (int)(1 / p.dt / 2);  // int(1 / dt / REGULATION_FREQUENCY) (regulation.py:38)
+  for (int fr = 0; fr < n_frames; ++fr) {
+    const bool present = !(me.flags & HWY_F_ABSENT);
+    const bool controlled = present && (me.flags & HWY_F_CONTROLLED);
+    const u64 pm = __ballot(present);
+    // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315): SLOWER / IDLE / FASTER ------
+    if (fr == 0 && actions && controlled) {
+      const int act = actions[e];
+      if (act == 0 || act == 2) {
+        const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+        int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == 2 ? 1 : -1);
+        idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
+        me.sidx = idx;
+        me.ts = p.target_speeds[idx];
+      }
+    }
+    // ---- B. membership masks + snapshot ---------------------------------------------------------------------------
+    __syncthreads();
+    for (int L = 0; L < ip.n_lanes; ++L) {
+      const u64 b = __ballot(present && ((bits >> L) & 1));
+      if (i == 0) sh.mask[L] = b;
+    }
+    const double ch = cos(me.h), shh = sin(me.h);
+    sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = ch; sh.s[i] = shh;
+    __syncthreads();
+
+    // ---- C. Road.act (road.py:464-467) ---------------------------------------------------------------------------
+    double steering = 0.0, accel = 0.0;
+    const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
+    const bool acts = present && (controlled || !crashed0);  // IDMVehicle.act returns early when crashed
+    if (acts) {
+      // follow_road (controller.py:135-143): AbstractLane.after_end on the target lane (lane.py:120-125)
+      if (sh.sl[me.tgt][i] > sh.len[me.tgt] - 5.0 / 2) me.tgt = ix_next_lane(ip, sh, me.tgt, me);
+      if (!controlled && me.lane == me.tgt && HWY_LC_DELAY < me.timer) me.timer = 0.0;  // behavior.py:246-248
+      // steering_control (controller.py:145-187)
+      {
+        double s_t, lat_t;
+        ix_local(sh, me.tgt, me.x, me.y, &s_t, &lat_t);
+        const double lane_future_heading = ix_heading_at(sh, me.tgt, s_t + me.v * (0.5 * 0.2));
+        const double lateral_speed_command = -HWY_KP_LATERAL * lat_t;
+        const double heading_command = asin(clipd(lateral_speed_command / not_zero(me.v), -1.0, 1.0));
+        const double heading_ref = lane_future_heading + clipd(heading_command, -HWY_PI / 4, HWY_PI / 4);
+        const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - me.h);
+        const double slip_angle = asin(clipd(HWY_VEH_LENGTH / 2 / not_zero(me.v) * heading_rate_command, -1.0, 1.0));
+        steering = clipd(atan(2 * tan(slip_angle)), -HWY_MAX_STEER, HWY_MAX_STEER);
+      }
+      if (controlled) {
+        accel = HWY_KP_A * (me.ts - me.v);  // speed_control (controller.py:189-198)
+      } else {
+        // IDM (behavior.py:150-217) on the current lane, and on the target lane while they differ
+        const double v0 = clipd(me.ts, 0.0, sh.lim[me.lane]);
+        const double free_acc = ip.a_max * (1 - pow(fmax(me.v, 0.0) / fabs(not_zero(v0)), me.delta));
+        const double ab2 = 2 * sqrt(-ip.a_max * ip.b_min);
+        accel = free_acc;
+        for (int q = 0; q < 2; ++q) {
+          const int Lq = q == 0 ? me.lane : me.tgt;
+          if (q == 1 && me.lane == me.tgt) break;
+          double a = free_acc;
+          const int f = ix_front(sh, Lq, i);
+          if (f >= 0) {
+            // lane_distance_to is measured on MY current lane (objects.py:183-198)
+            const double d = sh.sl[me.lane][f] - sh.sl[me.lane][i];
+            const double dv = (me.v * ch - sh.v[f] * sh.c[f]) * ch + (me.v * shh - sh.v[f] * sh.s[f]) * shh;
+            const double d_star = ip.d0 + me.v * ip.tau + me.v * dv / ab2;
+            const double r = d_star / not_zero(d);
+            a -= ip.a_max * (r * r);
+          }
+          accel = q == 0 ? a : fmin(accel, a);
+        }
+        accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
+      }
+    }
+
+    // ---- D. RegulatedRoad.step (regulation.py:36-68) --------------------------------------------------------------
+    road_steps += 1;
+    if (road_steps % every == 0) {  // wave-uniform
+      const bool veh = present;
+      if (veh && (me.flags & HWY_F_YIELDING)) {  // YIELD_DURATION == 0: released at the next regulation
+        me.ts = sh.lim[me.lane];
+        me.flags &= ~HWY_F_YIELDING;
+      }
+      const double s_me = sh.sl[me.lane][i];
+      __syncthreads();  // sl[][] is dead from here on: the trajectories share its storage
+      if (veh) {
+        for (int k = 0; k < HWY_IX_SAMPLES; ++k) {
+          double px, py, hd;
+          ix_along_route(sh, me, s_me + me.v * (0.25 + k * 0.25), &px, &py, &hd);
+          sh.traj[k][0][i] = px; sh.traj[k][1][i] = py; sh.traj[k][2][i] = hd;
+        }
+      }
+      __syncthreads();
+      bool yield = false;
+      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j
+        const int j = ctz64(m);
+        const int lane_j = wave_bcast_i(me.lane, j);
+        bool conflict = false;
+        if (veh && i != j) {
+          for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
+            const double ax = sh.traj[k][0][i], ay = sh.traj[k][1][i], bx = sh.traj[k][0][j], by = sh.traj[k][1][j];
+            const double dx = bx - ax, dy = by - ay;
+            if (sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH) continue;
+            const double ah = sh.traj[k][2][i], bh = sh.traj[k][2][j];
+            // rotated_rectangles_intersect(rect(lower slot), rect(higher slot)) is symmetric in its arguments
+            conflict = ix_corner_inside(ax, ay, ah, bx, by, bh) || ix_corner_inside(bx, by, bh, ax, ay, ah);
+          }
+        }
+        if (conflict) {
+          // respect_priorities(v1 = lower slot, v2 = higher slot) (regulation.py:70-86)
+          const int pj = sh.prio[lane_j], pi_ = sh.prio[me.lane];
+          const bool i_low = i < j;
+          const int p1 = i_low ? pi_ : pj, p2 = i_low ? pj : pi_;
+          bool low_yields;
+          if (p1 > p2) low_yields = false;
+          else if (p1 < p2) low_yields = true;
+          else {
+            const double fd_i = ch * (sh.x[j] - me.x) + shh * (sh.y[j] - me.y);          // i.front_distance_to(j)
+            const double fd_j = sh.c[j] * (me.x - sh.x[j]) + sh.s[j] * (me.y - sh.y[j]);  // j.front_distance_to(i)
+            const double f1 = i_low ? fd_i : fd_j, f2 = i_low ? fd_j : fd_i;
+            low_yields = f1 > f2;
+          }
+          yield = yield || (low_yields == i_low);
+        }
+      }
+      if (yield && !controlled) {  // only a ControlledVehicle that is not the MDPVehicle is stopped
+        me.ts = 0.0;
+        me.flags |= HWY_F_YIELDING;
+      }
+    }
+
+    // ---- E. Vehicle.step (kinematics.py:130-177, behavior.py:139-148) -------------------------------------------------
+    if (present) {
+      if (!controlled) me.timer += p.dt;
+      if (crashed0) {  // clip_actions
+        steering = 0.0;
+        accel = -1.0 * me.v;
+      }
+      accel = (me.v > HWY_MAX_SPEED) ? fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v))
+                                     : ((me.v < HWY_MIN_SPEED) ? fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v)) : accel);
+      const double beta = atan(1.0 / 2 * tan(steering));
+      const double vx = me.v * cos(me.h + beta), vy = me.v * sin(me.h + beta);
+      me.x += vx * p.dt;
+      me.y += vy * p.dt;
+      if (me.flags & HWY_F_HAS_IMPACT) {
+        me.x += me.impx;
+        me.y += me.impy;
+        me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
+        me.impx = me.impy = 0.0;
+      }
+      me.h += me.v * sin(beta) / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.v += accel * p.dt;
+    }
+    __syncthreads();  // the trajectories (if any) are dead: sl[][] is written again
+    {
+      int cl_new, bits_new;  // on_state_update + the next frame's membership bits and s table
+      ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits_new, &cl_new);
+      if (present) me.lane = cl_new;
+      bits = present ? bits_new : 0;
+    }
+
+    // ---- F. collisions (road.py:477-481, objects.py:92-138): every pair; the highest partner slot's impact stays ----
+    {
+      const double c2 = cos(me.h), s2 = sin(me.h);
+      __syncthreads();
+      sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
+      __syncthreads();
+      const Body mine{me.x, me.y, me.v, c2, s2};
+      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j, ascending
+        const int j = ctz64(m);
+        bool near = false;
+        if (present && i != j) {
+          const double dx = sh.x[j] - me.x, dy = sh.y[j] - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[j])) * p.dt;
+          near = dx * dx + dy * dy <= lim * lim;
+        }
+        if (near) {
+          const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
+          const bool i_first = i < j;
+          const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
+          double tx, ty;
+          const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
+          if (r & 2) {
+            me.impx = i_first ? tx / 2 : -tx / 2;
+            me.impy = i_first ? ty / 2 : -ty / 2;
+            me.flags |= HWY_F_HAS_IMPACT;
+          }
+          if (r & 1) me.flags |= HWY_F_CRASHED;
+        }
+      }
+    }
+  }
+}
+
+// ---- KinematicObservation (observation.py:234-276, road.py:421-450) + IntersectionEnv reward / termination -----------
+__device__ inline void ix_observe(const IxParams &ip, const IxShared &sh, int e, const IxVeh &me, bool write_reward) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  const bool present = !(me.flags & HWY_F_ABSENT);
+  const u64 egos = __ballot(present && (me.flags & HWY_F_CONTROLLED));
+  if (egos == 0) return;
+  const int ia = ctz64(egos);
+  const int V = p.V, F = p.F;
+  const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia), eh = wave_bcast(me.h, ia);
+  const int elane = wave_bcast_i(me.lane, ia);
+  const double dxe = me.x - ex, dye = me.y - ey;
+  // observer.lane_distance_to(me) on the observer's lane: s table of the last lane pass (positions unchanged since)
+  const double d_lane = sh.sl[elane][i] - sh.sl[elane][ia];
+  const bool elig = present && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
+                    ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
+  const double key = elig ? fabs(d_lane) : __builtin_inf();
+  const int n_elig = __popcll(__ballot(elig));
+  const int mrows = n_elig < V - 1 ? n_elig : V - 1;
+  int pos = 0;  // stable sort position (ties keep list order)
+  for (u64 em = __ballot(elig); em; em &= em - 1) {
+    const int k = ctz64(em);
+    const double kk = wave_bcast(key, k);
+    pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+  }
+  if (p.obs) {
+    float *out = p.obs + (size_t)e * (size_t)(V * F);
+    const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
+    if (present && row >= 0) {
+      const double ch = cos(me.h), shh = sin(me.h);
+      for (int f = 0; f < F; ++f) {
+        const int fid = p.feat[f];
+        double val = fid == HWY_FEAT_PRESENCE ? 1.0 : fid == HWY_FEAT_X ? me.x : fid == HWY_FEAT_Y ? me.y
+                   : fid == HWY_FEAT_VX ? me.v * ch : fid == HWY_FEAT_VY ? me.v * shh : fid == HWY_FEAT_HEADING ? me.h
+                   : fid == HWY_FEAT_COS_H ? ch : fid == HWY_FEAT_SIN_H ? shh : 0.0;
+        const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+        if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
+          const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * cos(eh) : ev * sin(eh);
+          val -= origin;
+        }
+        if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
+          const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+          const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+          if (r0 > -__builtin_inf()) {
+            val = lmap(val, r0, r1, -1.0, 1.0);
+            if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
+          }
+        }
+        out[row * F + f] = (float)val;
+      }
+    }
+    for (int t = i; t < V * F; t += 64)
+      if (t / F > mrows) out[t] = 0.0f;
+  }
+  if (write_reward && i == ia) {
+    const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
+    double s, lat;
+    ix_local(sh, me.lane, me.x, me.y, &s, &lat);
+    const bool arrived = sh.exitl[me.lane] && s >= 25.0;  // has_arrived (intersection_env.py:340-345)
+    const bool on_road = fabs(lat) <= sh.wid[me.lane] / 2 + 0.0 && -5.0 <= s && s < sh.len[me.lane] + 5.0;
+    const double scaled_speed = lmap(me.v, p.rs0, p.rs1, 0.0, 1.0);
+    double reward = 0.0;  // _agent_reward (intersection_env.py:79-105)
+    reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
+    reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
+    reward = reward + ip.arrived_reward * (arrived ? 1.0 : 0.0);
+    reward = reward + 0 * (on_road ? 1.0 : 0.0);
+    reward = arrived ? ip.arrived_reward : reward;
+    reward *= (on_road ? 1.0 : 0.0);
+    if (p.flags & HWY_C_NORMALIZE_REWARD) reward = lmap(reward, p.collision_reward, ip.arrived_reward, 0.0, 1.0);
+    p.reward[e] = reward;
+    if (p.info_speed) p.info_speed[e] = me.v;
+    if (p.info_crashed) p.info_crashed[e] = crashed ? 1 : 0;
+    const bool term = crashed || arrived || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
+    const double t = p.st.time[e] + p.policy_dt;
+    const bool trunc = t >= p.duration;
+    p.st.time[e] = t;
+    p.terminated[e] = term ? 1 : 0;
+    p.truncated[e] = trunc ? 1 : 0;
+    if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+  }
+}
+
+// ---- device-side traffic management (Philox draws, NOT numpy's stream) ---------------------------------------------------
+// standard normal from two uniforms (Box-Muller); u0 in [0,1) -> 1 - u0 in (0,1]
+__device__ inline double ix_normal(double u0, double u1) { return sqrt(-2.0 * log(1.0 - u0)) * cos(2 * HWY_PI * u1); }
+
+// stable compaction of the slots that stay (the reference rebuilds the list, intersection_env.py:333-338)
+__device__ inline void ix_compact(IxVeh &me, bool keep) {
+  const int i = threadIdx.x;
+  const u64 km = __ballot(keep);
+  const int n_keep = __popcll(km);
+  const int dst = keep ? __popcll(km & (((u64)1 << i) - 1)) : n_keep + __popcll(~km & (((u64)1 << i) - 1));
+#define MOVE_I(f) f = wave_send_i(f, dst)
+#define MOVE_D(f) f = __hiloint2double(wave_send_i(__double2hiint(f), dst), wave_send_i(__double2loint(f), dst))
+  int flags = keep ? me.flags : HWY_F_ABSENT;
+  MOVE_D(me.x); MOVE_D(me.y); MOVE_D(me.h); MOVE_D(me.v); MOVE_D(me.timer); MOVE_D(me.ts); MOVE_D(me.delta);
+  MOVE_D(me.impx); MOVE_D(me.impy);
+  MOVE_I(me.lane); MOVE_I(me.tgt); MOVE_I(me.sidx); MOVE_I(flags); MOVE_I(me.route);
+  me.flags = flags;
+#undef MOVE_I
+#undef MOVE_D
+}
+
+// IntersectionEnv._spawn_vehicle (intersection_env.py:292-324) on given draws; thread `slot` becomes the new vehicle
+__device__ inline void ix_spawn(const IxParams &ip, IxShared &sh, IxVeh &me, double longitudinal, double position_deviation,
+                                double speed_deviation, double spawn_probability, bool go_straight, double u_spawn,
+                                double u_r0, double u_r1, double z_pos, double z_speed, double u_delta) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  if (u_spawn > spawn_probability) return;  // wave-uniform
+  // route = choice(range(4), size=2, replace=False): r0 uniform over 4, r1 uniform over the other 3
+  int r0 = (int)(u_r0 * 4);
+  r0 = r0 > 3 ? 3 : r0;
+  int r1 = (int)(u_r1 * 3);
+  r1 = r1 > 2 ? 2 : r1;
+  r1 = r1 >= r0 ? r1 + 1 : r1;
+  if (go_straight) r1 = (r0 + 2) % 4;
+  const int access = ip.access_lane[r0];
+  double nx, ny;
+  const double lon = longitudinal + 5.0 + z_pos * position_deviation;
+  ix_position(sh, access, lon, &nx, &ny);
+  const double nh = ix_heading_at(sh, access, lon);
+  const double speed = 8.0 + z_speed * speed_deviation;
+  const bool present = !(me.flags & HWY_F_ABSENT);
+  const double dx = me.x - nx, dy = me.y - ny;
+  if (__ballot(present && sqrt(dx * dx + dy * dy) < 15) != 0) return;  // too close to somebody
+  const u64 pm = __ballot(present);
+  const int slot = __popcll(pm);  // the list is compact
+  if (slot >= p.N) return;        // capacity reached: no spawn (documented deviation; size num_vehicles accordingly)
+  if (i == slot) {
+    // lane index: get_closest_lane_index(position, heading)
+    int best = 0;
+    double bd = 0.0;
+    for (int L = 0; L < ip.n_lanes; ++L) {
+      double s, lat;
+      ix_local(sh, L, nx, ny, &s, &lat);
+      const double angle = fabs(wrap_to_pi(nh - ix_heading_at(sh, L, s)));
+      const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+      if (L == 0 || d < bd) { bd = d; best = L; }
+    }
+    me = IxVeh{};
+    me.x = nx; me.y = ny; me.h = nh; me.v = speed; me.ts = speed;
+    me.lane = me.tgt = best;
+    me.timer = py_mod_pos((nx + ny) * HWY_PI, HWY_LC_DELAY);
+    me.route = ix_plan_route(ip, sh, best, r1);
+    me.delta = 3.5 + (4.5 - 3.5) * u_delta;  // randomize_behavior (behavior.py:66-69)
+    me.flags = HWY_F_CHECK_COLLISIONS;
+  }
+}
+
+// IntersectionEnv.step's tail (intersection_env.py:136-140): _clear_vehicles + one _spawn_vehicle
+__device__ inline void ix_clear_spawn(const IxParams &ip, IxShared &sh, IxVeh &me, uint64_t seed, uint32_t episode,
+                                      uint32_t step_no) {
+  const int i = threadIdx.x;
+  const bool present = !(me.flags & HWY_F_ABSENT);
+  double s = 0.0, lat;
+  if (present) ix_local(sh, me.lane, me.x, me.y, &s, &lat);
+  const bool leaving = present && sh.exitl[me.lane] && s >= sh.len[me.lane] - 4 * HWY_VEH_LENGTH;
+  const bool keep = present && ((me.flags & HWY_F_CONTROLLED) || !leaving);
+  if (__ballot(present && !keep) != 0) ix_compact(me, keep);
+  double u0, u1, u2, u3, u4, u5, u6, u7;
+  philox_uniform2(seed, 1000u + step_no, episode, 0u, &u0, &u1);
+  philox_uniform2(seed, 1000u + step_no, episode, 1u, &u2, &u3);
+  philox_uniform2(seed, 1000u + step_no, episode, 2u, &u4, &u5);
+  philox_uniform2(seed, 1000u + step_no, episode, 3u, &u6, &u7);
+  (void)i;
+  ix_spawn(ip, sh, me, 0.0, 1.0, 1.0, ip.spawn_probability, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+}
+
+// IntersectionEnv._make_vehicles (intersection_env.py:232-290) on Philox draws
+__device__ inline void ix_spawn_env(const IxParams &ip, IxShared &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
+                                    int &road_steps, int &bits) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  me = IxVeh{};
+  me.flags = HWY_F_ABSENT;
+  road_steps = 0;
+  const int n = ip.initial_count;
+  for (int t = 0; t < n - 1; ++t) {  // np.linspace(0, 80, n_vehicles)[t]
+    double u0, u1, u2, u3, u4, u5, u6, u7;
+    philox_uniform2(seed, (uint32_t)t, episode, 0u, &u0, &u1);
+    philox_uniform2(seed, (uint32_t)t, episode, 1u, &u2, &u3);
+    philox_uniform2(seed, (uint32_t)t, episode, 2u, &u4, &u5);
+    philox_uniform2(seed, (uint32_t)t, episode, 3u, &u6, &u7);
+    const double lon = n > 1 ? 0.0 + t * ((80.0 - 0.0) / (n - 1)) : 0.0;
+    ix_spawn(ip, sh, me, lon, 1.0, 1.0, 0.6, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+  }
+  // three simulated seconds without the ego
+  {
+    int unused;
+    ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+    const int sim_freq = (int)rint(1 / p.dt);
+    ix_frames(ip, sh, e, me, 3 * sim_freq, nullptr, road_steps, bits);
+  }
+  {  // challenger: longitudinal 60, always, straight on, position deviation 0.1, speed deviation 0
+    double u0, u1, u2, u3, u4, u5, u6, u7;
+    philox_uniform2(seed, 500u, episode, 0u, &u0, &u1);
+    philox_uniform2(seed, 500u, episode, 1u, &u2, &u3);
+    philox_uniform2(seed, 500u, episode, 2u, &u4, &u5);
+    philox_uniform2(seed, 500u, episode, 3u, &u6, &u7);
+    ix_spawn(ip, sh, me, 60.0, 0.1, 0.0, 1.0, true, 0.0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+  }
+  // the ego on ("o0", "ir0", 0) at 60 + 5 * normal(1.0), speed = speed_limit, route to config["destination"]
+  double u0, u1;
+  philox_uniform2(seed, 501u, episode, 0u, &u0, &u1);
+  const int access = ip.access_lane[0];
+  double ex, ey;
+  ix_position(sh, access, 60.0 + 5.0 * (1.0 + ix_normal(u0, u1)), &ex, &ey);
+  const bool present = !(me.flags & HWY_F_ABSENT);
+  const double dx = me.x - ex, dy = me.y - ey;
+  const bool keep = present && !(sqrt(dx * dx + dy * dy) < 20);  // "prevent early collisions" (:283-290)
+  ix_compact(me, keep);
+  const int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
+  if (i == slot && slot < p.N) {
+    me = IxVeh{};
+    me.x = ex; me.y = ey; me.h = ix_heading_at(sh, access, 60.0); me.v = sh.lim[access];
+    int best = 0;
+    double bd = 0.0;
+    for (int L = 0; L < ip.n_lanes; ++L) {
+      double s, lat;
+      ix_local(sh, L, ex, ey, &s, &lat);
+      const double angle = fabs(wrap_to_pi(me.h - ix_heading_at(sh, L, s)));
+      const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+      if (L == 0 || d < bd) { bd = d; best = L; }
+    }
+    me.lane = me.tgt = best;
+    me.route = ix_plan_route(ip, sh, best, ip.destination);
+    const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+    me.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
+    me.ts = p.target_speeds[me.sidx];
+    me.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
+  }
+  int unused;
+  ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+  bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+}
+
+// =============================================================================================================
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_ix_step_kernel(const IxParams ip) {
+  const StepParams &p = ip.s;
+  __shared__ IxShared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  ix_load_table(ip, sh);
+  IxVeh me;
+  int road_steps, bits;
+  if (p.autoreset && p.st.done[e]) {  // the step after terminated | truncated re-spawns the environment
+    const uint32_t episode = p.st.episode[e] + 1u;
+    ix_spawn_env(ip, sh, e, p.rp.base_seed + (uint64_t)e, episode, me, road_steps, bits);
+    ix_observe(ip, sh, e, me, false);
+    ix_store_vehicle(ip, e, me);
+    if (i == 0) {
+      p.reward[e] = 0.0;
+      if (p.info_speed) p.info_speed[e] = sh.lim[ip.access_lane[0]];
+      if (p.info_crashed) p.info_crashed[e] = 0;
+      p.st.time[e] = 0.0;
+      p.st.done[e] = 0;
+      p.st.episode[e] = episode;
+      p.terminated[e] = 0;
+      p.truncated[e] = 0;
+      ip.road_steps[e] = road_steps;
+    }
+    return;
+  }
+  ix_load_vehicle(ip, e, me);
+  road_steps = ip.road_steps[e];
+  const uint32_t step_no = (uint32_t)rint(p.st.time[e] / p.policy_dt);  // read before anybody advances the clock
+  {
+    int unused;
+    ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+  }
+  ix_frames(ip, sh, e, me, p.n_frames, p.actions, road_steps, bits);
+  if (p.full_step) {
+    __syncthreads();
+    ix_observe(ip, sh, e, me, true);
+    if (!ip.host_spawn) ix_clear_spawn(ip, sh, me, p.rp.base_seed + (uint64_t)e, p.st.episode[e], step_no);
+  }
+  ix_store_vehicle(ip, e, me);
+  if (i == 0) ip.road_steps[e] = road_steps;
+}
+
+// Reset kernel: AbstractEnv.reset for the masked environments + first observation.
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_ix_reset_kernel(const IxParams ip) {
+  const StepParams &p = ip.s;
+  __shared__ IxShared sh;
+  const int e = blockIdx.x, i = threadIdx.x;
+  ix_load_table(ip, sh);
+  if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
+  IxVeh me;
+  int road_steps, bits;
+  const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
+  ix_spawn_env(ip, sh, e, seed, 0u, me, road_steps, bits);
+  ix_observe(ip, sh, e, me, false);
+  ix_store_vehicle(ip, e, me);
+  if (i == 0) {
+    p.st.time[e] = 0.0;
+    p.st.done[e] = 0;
+    p.st.episode[e] = 0;
+    ip.road_steps[e] = road_steps;
+  }
+}
+
+// Observation-only kernel (hwy_observe).
+template <int WPE>
+__global__ void __launch_bounds__(64, WPE) hwy_ix_observe_kernel(const IxParams ip) {
+  __shared__ IxShared sh;
+  ix_load_table(ip, sh);
+  IxVeh me;
+  ix_load_vehicle(ip, blockIdx.x, me);
+  int bits, unused;
+  ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+  __syncthreads();
+  ix_observe(ip, sh, blockIdx.x, me, false);
+}
+
+}  // namespace hwy

@@ -6,6 +6,7 @@
 #include "hwy_device.h"
 #include "hwy_wave.h"
 #include "hwy_net.h"
+#include "hwy_ix.h"
 #include "hwy_launch.h"
 
 namespace hwy {
@@ -73,6 +74,18 @@ hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t strea
 }
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream) {
   hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  return hipGetLastError();
+}
+hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_ix_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, ip);
+  return hipGetLastError();
+}
+hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_ix_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, ip);
+  return hipGetLastError();
+}
+hipError_t launch_ix_observe(const IxParams &ip, int num_envs, hipStream_t stream) {
+  hipLaunchKernelGGL((hwy_ix_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 __global__ void hwy_math_probe_kernel(int op, const double *in, double *out, long long n) {

@@ -46,6 +46,22 @@ inline void net_params_from_config(const hwy_config &c, const StepParams &p, NP 
   for (int k = 0; k < HWY_MAX_LANES; ++k) np.lane[k] = c.net[k];
 }
 
+// intersection scenario: constants next to the StepParams; the lane table, route plane and step counters are device
+// pointers the caller binds (IP = IxParams)
+template <typename IP>
+inline void ix_params_from_config(const hwy_config &c, const StepParams &p, IP &ip) {
+  std::memset(&ip, 0, sizeof ip);
+  ip.s = p;
+  ip.n_lanes = c.gnet_lanes;
+  ip.initial_count = c.initial_vehicle_count;
+  ip.host_spawn = (c.flags & HWY_C_HOST_TRAFFIC) ? 1 : 0;
+  ip.destination = c.destination;
+  for (int k = 0; k < 4; ++k) { ip.access_lane[k] = c.access_lane[k]; ip.exit_of[k] = c.exit_of[k]; }
+  ip.spawn_probability = c.spawn_probability;
+  ip.arrived_reward = c.arrived_reward;
+  ip.d0 = c.idm_distance_wanted; ip.tau = c.idm_time_wanted; ip.a_max = c.idm_comfort_acc_max; ip.b_min = c.idm_comfort_acc_min;
+}
+
 // observation length per agent: V*F (Kinematics) or F*W*H (OccupancyGrid)
 inline size_t obs_len(const hwy_config &c) {
   return c.obs_type == HWY_OBS_OCCUPANCY_GRID ? (size_t)c.obs_features * c.grid_shape[0] * c.grid_shape[1]

@@ -59,7 +59,8 @@ class Engine:
         self._check(self._lib.hwy_set_state(self._h, C.byref(s)))
 
     def get_state(self) -> dict:
-        st = _abi.alloc_state(self.E, self.N)
+        ix = self.cfg.scenario == _abi.SCENARIO_INTERSECTION
+        st = _abi.alloc_state_ix(self.E, self.N) if ix else _abi.alloc_state(self.E, self.N)
         s = _abi.state_struct(st)
         self._check(self._lib.hwy_get_state(self._h, C.byref(s)))
         return st

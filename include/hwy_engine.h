@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HWY_ABI_VERSION 3
+#define HWY_ABI_VERSION 4
 
 #define HWY_MAX_AGENTS 16
 #define HWY_MAX_FEATURES 16
@@ -45,6 +45,8 @@ extern "C" {
 #define HWY_MAX_LANES 16
 #define HWY_MAX_VEHICLES 256
 #define HWY_MAX_GRID_CELLS 65536
+#define HWY_MAX_GLANES 24  /* lanes of a general (any direction / circular) road network: HWY_SCENARIO_INTERSECTION */
+#define HWY_MAX_ROUTE 3    /* remaining roads of a planned route kept per vehicle */
 
 typedef enum hwy_status {
   HWY_OK = 0,
@@ -65,8 +67,11 @@ enum {
   HWY_F_OBSTACLE = 16,        /* the slot is an Obstacle of Road.objects (vehicle/objects.py:215-222): 2 m x 2 m,
                                  never acts or moves; slots of obstacles come AFTER every vehicle slot, like
                                  `self.vehicles + self.objects` in road.py:531 */
-  HWY_F_ABSENT = 32           /* empty slot: MergeGenericEnv's rejection-sampled spawn (merge_env.py:336-352)
-                                 creates a different number of vehicles per episode */
+  HWY_F_ABSENT = 32,          /* empty slot: MergeGenericEnv's rejection-sampled spawn (merge_env.py:336-352)
+                                 creates a different number of vehicles per episode; IntersectionEnv clears and spawns
+                                 vehicles between policy steps (intersection_env.py:136-140) */
+  HWY_F_YIELDING = 64         /* HWY_SCENARIO_INTERSECTION: RegulatedRoad made the vehicle yield (is_yielding,
+                                 road/regulation.py:60-68); YIELD_DURATION is 0, so yield_timer is never read */
 };
 
 /* config flag bits (hwy_config.flags) */
@@ -78,7 +83,10 @@ enum {
   HWY_C_OBS_CLIP = 16,        /* KinematicObservation.clip          observation.py:170 */
   HWY_C_OBS_SEE_BEHIND = 32,  /* KinematicObservation.see_behind    observation.py:171 */
   HWY_C_EGO_ONLY_COLLISIONS = 64, /* HighwayEnvFast: spawned traffic has check_collisions=False (highway_env.py:177-182) */
-  HWY_C_GRID_ALIGN = 128      /* OccupancyGridObservation.align_to_vehicle_axes  observation.py:294,431-435 */
+  HWY_C_GRID_ALIGN = 128,     /* OccupancyGridObservation.align_to_vehicle_axes  observation.py:294,431-435 */
+  HWY_C_HOST_TRAFFIC = 256    /* HWY_SCENARIO_INTERSECTION: the HOST clears / spawns vehicles between policy steps (the
+                                 reference-stream mode of highwayenv_amd/intersection.py); otherwise the step kernel does
+                                 it on Philox draws */
 };
 
 /* observation feature ids (Vehicle.to_dict keys, vehicle/kinematics.py:237-261) */
@@ -97,8 +105,30 @@ enum { HWY_OBS_KINEMATICS = 0, HWY_OBS_OCCUPANCY_GRID = 1 };
 enum {
   HWY_SCENARIO_HIGHWAY = 0, /* HighwayEnv / HighwayEnvFast: one straight road, lanes_count lanes (highway_env.py:59-70) */
   HWY_SCENARIO_MERGE = 1,   /* MergeEnv: x-aligned road network in hwy_config.net (merge_env.py:90-160), 3 + 1 traffic vehicles */
-  HWY_SCENARIO_MERGE_GENERIC = 2 /* MergeGenericEnv (merge_env.py:233-363): same kernels, rejection-sampled spawn */
+  HWY_SCENARIO_MERGE_GENERIC = 2, /* MergeGenericEnv (merge_env.py:233-363): same kernels, rejection-sampled spawn */
+  HWY_SCENARIO_INTERSECTION = 3   /* IntersectionEnv (intersection_env.py): general lane table hwy_config.gnet, planned
+                                     routes, RegulatedRoad, vehicles cleared / spawned between policy steps; meta-actions
+                                     are {0: SLOWER, 1: IDLE, 2: FASTER} (intersection_env.py:14) */
 };
+
+/*
+ * One lane of a GENERAL RoadNetwork (HWY_SCENARIO_INTERSECTION): a StraightLane of any direction (road/lane.py:159-213)
+ * or a CircularLane (road/lane.py:311-369).  Table order == iteration order of get_closest_lane_index (road.py:55-71).
+ * Every road (from, to) of such a network holds ONE lane, so a planned route is a list of table indices.
+ */
+typedef struct hwy_glane {
+  int32_t kind;                       /* 0 StraightLane, 1 CircularLane */
+  int32_t direction;                  /* CircularLane.direction: +1 clockwise, -1 otherwise */
+  int32_t priority;                   /* lane.priority (RegulatedRoad.respect_priorities, regulation.py:70-86) */
+  int32_t forbidden;
+  int32_t from_node, to_node;         /* graph node ids; the lanes leaving a node are the candidates of next_lane */
+  int32_t exit_lane;                  /* "il" in lane_index[0] and "o" in lane_index[1] (intersection_env.py:328-331,341-344) */
+  int32_t reserved;
+  double sx, sy;                      /* StraightLane.start */
+  double heading, dirx, diry;         /* StraightLane.heading (arctan2), .direction */
+  double cx, cy, radius, start_phase; /* CircularLane.center / radius / start_phase */
+  double length, width, speed_limit;
+} hwy_glane;
 
 /*
  * One lane of an x-aligned RoadNetwork (road/road.py:16-38): StraightLane (road/lane.py:150-233) when
@@ -173,6 +203,18 @@ typedef struct hwy_config {
   double merging_speed_reward;         /* merge_env.py:35 */
   double lane_change_reward;           /* merge_env.py:36 */
   hwy_lane net[HWY_MAX_LANES];
+  /* HWY_SCENARIO_INTERSECTION (ABI v4) */
+  int32_t gnet_lanes;                  /* entries used in gnet[] */
+  int32_t initial_vehicle_count;       /* config["initial_vehicle_count"] (device reset, intersection_env.py:232-290) */
+  int32_t destination;                 /* k of config["destination"] == "o" + k (the ego's route, intersection_env.py:262-275) */
+  int32_t reserved3;
+  int32_t access_lane[4];              /* table index of ("o" + k, "ir" + k, 0): where _spawn_vehicle puts new traffic */
+  int32_t exit_of[4];                  /* table index of ("il" + k, "o" + k, 0): the last road of a route to "o" + k */
+  double spawn_probability;            /* config["spawn_probability"] */
+  double arrived_reward;               /* config["arrived_reward"] */
+  double idm_distance_wanted, idm_time_wanted, idm_comfort_acc_max, idm_comfort_acc_min; /* set on the vehicle class by
+                                          IntersectionEnv._make_vehicles (intersection_env.py:243-247): 7, 1.5, 6, -3 */
+  hwy_glane gnet[HWY_MAX_GLANES];
 } hwy_config;
 
 /*
@@ -194,6 +236,10 @@ typedef struct hwy_state {
   int32_t *speed_index;                 /* MDPVehicle.speed_index (controlled vehicles) */
   int32_t *flags;                       /* HWY_F_* */
   double *time;                         /* AbstractEnv.time [E]                  abstract.py:274 */
+  /* HWY_SCENARIO_INTERSECTION only (ABI v4; ignored / may be NULL otherwise): */
+  int32_t *route;                       /* ControlledVehicle.route [E*N]: r0 | r1 << 5 | r2 << 10 | len << 15, r_k = gnet
+                                           index of the k-th remaining road (controller.py:71-87, road.py:98-106) */
+  int32_t *road_steps;                  /* RegulatedRoad.steps [E] (regulation.py:36-40) */
 } hwy_state;
 
 typedef struct hwy_engine hwy_engine; /* opaque */

@@ -25,6 +25,7 @@ def build(force: bool = False) -> str:
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_net.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_ix.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_math.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_params.h"),
             os.path.join(_ROOT, "include", "hwy_engine.h")]
@@ -54,7 +55,8 @@ class EmuEngine:
     def __init__(self, cfg: _abi.HwyConfig):
         self.cfg = cfg
         self.E, self.N, self.A = cfg.num_envs, cfg.num_vehicles, cfg.num_agents
-        self.st = _abi.alloc_state(self.E, self.N)
+        self.ix = cfg.scenario == _abi.SCENARIO_INTERSECTION
+        self.st = _abi.alloc_state_ix(self.E, self.N) if self.ix else _abi.alloc_state(self.E, self.N)
         self.done = np.zeros(self.E, np.uint8)
         self.episode = np.zeros(self.E, np.uint32)
         self.autoreset = (0, 0, 2.0, 1.0, -1)
@@ -96,7 +98,7 @@ class EmuEngine:
 
     def step(self, actions):
         a = np.asarray(actions)
-        if ((a < 0) | (a > 4)).any():
+        if ((a < 0) | (a > (2 if self.ix else 4))).any():
             raise KeyError("invalid meta-action")
         return self._run(1, self.cfg.frames_per_step, actions)
 

@@ -26,6 +26,7 @@ inline double noisy(double v) {
 #include "../../highwayenv_amd/csrc/hwy_device.h"
 #include "../../highwayenv_amd/csrc/hwy_wave.h"
 #include "../../highwayenv_amd/csrc/hwy_net.h"
+#include "../../highwayenv_amd/csrc/hwy_ix.h"
 #include "../../highwayenv_amd/csrc/hwy_params.h"
 
 using hwy::StepParams;
@@ -33,15 +34,18 @@ using hwy::StepParams;
 namespace {
 struct HostImage {
   int E, N;
+  bool ix;
   std::vector<double> f64;
   std::vector<int32_t> packed;
-  HostImage(const hwy_config &c, const hwy_state &h) : E(c.num_envs), N(c.num_vehicles) {
+  HostImage(const hwy_config &c, const hwy_state &h) : E(c.num_envs), N(c.num_vehicles), ix(c.scenario == HWY_SCENARIO_INTERSECTION) {
     const size_t plane = (size_t)E * N;
     f64.resize(plane * 9);
     packed.resize(plane);
     const double *fields[9] = {h.x, h.y, h.heading, h.speed, h.timer, h.target_speed, h.delta, h.impact_x, h.impact_y};
     for (int f = 0; f < 9; ++f) std::memcpy(&f64[f * plane], fields[f], plane * sizeof(double));
-    for (size_t k = 0; k < plane; ++k) packed[k] = hwy::pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k], (int)(k % N));
+    for (size_t k = 0; k < plane; ++k)
+      packed[k] = ix ? hwy::ix_pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k])
+                     : hwy::pack_word(h.lane[k], h.target_lane[k], h.speed_index[k], h.flags[k], (int)(k % N));
   }
   void store(hwy_state &h) const {
     const size_t plane = (size_t)E * N;
@@ -49,6 +53,10 @@ struct HostImage {
     for (int f = 0; f < 9; ++f) std::memcpy(fields[f], &f64[f * plane], plane * sizeof(double));
     for (size_t k = 0; k < plane; ++k) {
       const int32_t w = packed[k];
+      if (ix) {
+        h.lane[k] = hwy::ix_word_lane(w); h.target_lane[k] = hwy::ix_word_target(w); h.speed_index[k] = hwy::ix_word_speed_index(w); h.flags[k] = hwy::ix_word_flags(w);
+        continue;
+      }
       h.lane[k] = hwy::word_lane(w); h.target_lane[k] = hwy::word_target(w); h.speed_index[k] = hwy::word_speed_index(w); h.flags[k] = hwy::word_flags(w);
       if (!(h.flags[k] & HWY_F_HAS_IMPACT)) h.impact_x[k] = h.impact_y[k] = 0.0;  // as hwy_get_state does
     }
@@ -59,8 +67,22 @@ struct HostImage {
 enum Which { STEP, RESET, OBSERVE };
 bool g_force_block = false;
 const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road-network scenarios need the lane table)
+hwy_state *g_st = nullptr;          // host state of the call (intersection scenario: route / road_steps planes)
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
+  if (g_cfg && g_cfg->scenario == HWY_SCENARIO_INTERSECTION) {
+    hwy::IxParams ip;
+    hwy::ix_params_from_config(*g_cfg, p, ip);
+    ip.lanes = g_cfg->gnet;
+    ip.route = g_st->route;  // pitch == N in the emulation
+    ip.road_steps = g_st->road_steps;
+    switch (which) {
+      case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1>(q); }, E, 64, ip); break;
+      case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1>(q); }, E, 64, ip); break;
+      case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1>(q); }, E, 64, ip); break;
+    }
+    return;
+  }
   if (g_cfg && g_cfg->scenario != HWY_SCENARIO_HIGHWAY) {  // same dispatch rule as hwy_engine.hip
     hwy::NetParams np;
     hwy::net_params_from_config(*g_cfg, p, np);
@@ -110,6 +132,7 @@ int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episo
             int initial_lane_id) {
   HostImage img(*cfg, *st);
   g_cfg = cfg;
+  g_st = st;
   StepParams p;
   hwy::params_from_config(*cfg, cfg->num_vehicles, p);
   hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);
@@ -144,6 +167,7 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
               int initial_lane_id, float *obs) {
   HostImage img(*cfg, *st);
   g_cfg = cfg;
+  g_st = st;
   StepParams p;
   hwy::params_from_config(*cfg, cfg->num_vehicles, p);
   hwy::bind_planes(img.f64.data(), (size_t)cfg->num_envs * cfg->num_vehicles, p.st);

@@ -216,3 +216,46 @@ def assert_ix_state_close(got: dict, want: dict, atol=1e-9, what=""):
         np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
     idm = pres & (want["controlled"] == 0)
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
+
+
+def ix_engine_state(g: "GoldenIntersection", gst: dict, cfg) -> dict:
+    """Golden / oracle intersection state (tests' own layout) -> the product's hwy_state dict for hwy_set_state."""
+    from highwayenv_amd import intersection as hix
+    tab = hix.table_from_config(cfg)
+    E = gst["x"].shape[0]
+    st = _abi.alloc_state_ix(E, cfg.num_vehicles)
+    n = g.N
+    assert n <= cfg.num_vehicles
+    for k in ["x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y"]:
+        st[k][:, :n] = gst[k]
+    for k in ["lane", "target_lane", "speed_index"]:
+        st[k][:, :n] = gst[k]
+    pres = gst["present"] != 0
+    flags = (gst["crashed"] * _abi.F_CRASHED + gst["has_impact"] * _abi.F_HAS_IMPACT + _abi.F_CHECK_COLLISIONS
+             + gst["controlled"] * _abi.F_CONTROLLED + gst["is_yielding"] * _abi.F_YIELDING)
+    st["flags"][:, :n] = np.where(pres, flags, _abi.F_ABSENT)
+    lane_of = {(int(tab["from_node"][k]), int(tab["to_node"][k])): k for k in range(len(tab["kind"]))}
+    for e in range(E):
+        for i in np.nonzero(pres[e])[0]:
+            r = [lane_of[(int(gst["route_from"][e, i, q]), int(gst["route_to"][e, i, q]))] for q in range(int(gst["route_len"][e, i]))]
+            st["route"][e, i] = hix.route_pack(r)
+    st["road_steps"][...] = gst["road_steps"]
+    st["time"][...] = gst["time"]
+    return st
+
+
+def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what=""):
+    """Two hwy_state dicts of the intersection scenario (absent slots ignored)."""
+    pres = (want["flags"] & _abi.F_ABSENT) == 0
+    np.testing.assert_array_equal((got["flags"] & _abi.F_ABSENT) == 0, pres, err_msg=f"{what}: present")
+    for k in ["lane", "target_lane", "flags", "route"]:
+        np.testing.assert_array_equal(got[k][pres], want[k][pres], err_msg=f"{what}: {k}")
+    ctrl = pres & ((want["flags"] & _abi.F_CONTROLLED) != 0)
+    np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
+    for k in ["x", "y", "heading", "speed", "target_speed"]:
+        np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+    for k in ["impact_x", "impact_y"]:
+        np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+    idm = pres & ~ctrl
+    np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
+    np.testing.assert_array_equal(got["road_steps"], want["road_steps"], err_msg=f"{what}: road_steps")

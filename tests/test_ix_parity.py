@@ -1,0 +1,108 @@
+"""Parity of the intersection step kernel (csrc/hwy_ix.h: IntersectionEnv) with the reference (golden traces,
+tests/golden/intersection_*.npz) and with the C oracle (oracle/hwy_oracle_ix.c).
+
+Backends: ``emu`` = the kernel source run on the CPU (tests/emu, test infrastructure), ``hip`` = the shipped
+libhwy_engine.so on the MI355X (``-m gpu``), called through the C-ABI.  Tolerances as in test_engine_parity.py:
+1e-9 per frame from identical state, obs (f32) 1e-6, reward 1e-9; lane indices, routes, yielding / crash / impact
+flags, terminated / truncated: bit-exact.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi
+from tests.backends import BACKENDS, make_engine
+from tests.golden_util import (INTERSECTION, GoldenIntersection, assert_ix_engine_state_close, ix_engine_state)
+
+
+def _hwy_config(g, E, host_traffic=True):
+    cfg = dict(g.config)
+    cfg["max_vehicles"] = g.N
+    cfg["host_traffic"] = host_traffic
+    return _abi.make_config(cfg, E, scenario="intersection")
+
+
+def _sub(st, sel):
+    return {k: np.ascontiguousarray(v[sel]) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", INTERSECTION)
+def test_teacher_forced_frames_vs_reference(backend, name):
+    """Each simulation frame (meta-action on the first frame of a step, Road.act, RegulatedRoad.step incl. the
+    regulation every 7th frame) from the reference's own state; all recorded frames batched into two engine calls."""
+    g = GoldenIntersection(name)
+    Ef, T = g.frames_for, g.T
+    K = g.steps * T
+    steps0 = g.z["road_steps0"][:Ef]
+    envs = slice(0, Ef)
+    starts, wants, acts, has_act = [], [], [], []
+    for k in range(K):
+        step, fr = divmod(k, T)
+        if fr == 0:
+            s0 = g.state("init", envs=envs) if step == 0 else g.state("next", step - 1, envs=envs)
+        else:
+            s0 = g.state("frame", k - 1)
+        s0["road_steps"][...] = steps0 + k
+        w = g.state("frame", k)
+        w["road_steps"][...] = steps0 + k + 1
+        starts.append(s0)
+        wants.append(w)
+        acts.append(g.actions[step, :Ef, 0] if fr == 0 else np.ones(Ef, np.int32))
+        has_act.append(np.full(Ef, fr == 0))
+    cat = lambda sts: {f: np.concatenate([s[f] for s in sts]) for f in sts[0]}  # noqa: E731
+    start, want = cat(starts), cat(wants)
+    acts, has_act = np.concatenate(acts), np.concatenate(has_act)
+    n_yield = 0
+    for sel, with_actions in ((has_act, True), (~has_act, False)):
+        idx = np.nonzero(sel)[0]
+        cfg = _hwy_config(g, len(idx))
+        eng = make_engine(backend, cfg)
+        eng.set_state(ix_engine_state(g, _sub(start, idx), cfg))
+        eng.step_frames(acts[idx].reshape(-1, 1) if with_actions else None, 1)
+        w = ix_engine_state(g, _sub(want, idx), cfg)
+        assert_ix_engine_state_close(eng.get_state(), w, atol=1e-9, what=f"{name} actions={with_actions}")
+        n_yield += int(((w["flags"] & _abi.F_YIELDING) != 0).sum())
+        eng.close()
+    assert n_yield > 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", INTERSECTION)
+def test_policy_steps_vs_reference(backend, name):
+    """Whole policy steps from the reference's state at the start of each step (host-traffic mode: the kernel does not
+    clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call."""
+    g = GoldenIntersection(name)
+    E, S = g.E, g.steps
+    steps0 = g.z["road_steps0"]
+    starts = []
+    for t in range(S):
+        s0 = g.state("init") if t == 0 else g.state("next", t - 1)
+        s0["road_steps"][...] = steps0 + t * g.T
+        s0["time"][...] = float(t)
+        starts.append(s0)
+    cat = lambda sts: {f: np.concatenate([s[f] for s in sts]) for f in sts[0]}  # noqa: E731
+    cfg = _hwy_config(g, E * S)
+    eng = make_engine(backend, cfg)
+    eng.set_state(ix_engine_state(g, cat(starts), cfg))
+    obs, reward, term, trunc, info = eng.step(g.actions[:, :, 0].reshape(E * S, 1))
+    got = eng.get_state()
+    live = np.ones(E, bool)
+    for t in range(S):
+        rows = slice(t * E, (t + 1) * E)
+        want = g.state("step", t)
+        want["road_steps"][...] = steps0 + (t + 1) * g.T
+        want["time"][...] = float(t + 1)
+        wreck = ((want["present"] != 0) & ((want["crashed"] != 0) | (want["has_impact"] != 0))).any(1)
+        clean = live & ~wreck
+        what = f"{name} step {t}"
+        sub_cfg = _hwy_config(g, int(clean.sum()))
+        assert_ix_engine_state_close(_sub(_sub(got, rows), clean), ix_engine_state(g, _sub(want, clean), sub_cfg), atol=1e-8,
+                                     what=what)
+        np.testing.assert_array_equal(term[rows][live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
+        np.testing.assert_array_equal(trunc[rows][live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
+        np.testing.assert_array_equal(info["crashed"][rows][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
+        np.testing.assert_allclose(obs[rows][clean, 0], g.z["obs"][t][clean], rtol=0, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(reward[rows][clean, 0], g.z["reward"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(info["speed"][rows][clean, 0], g.z["info_speed"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+        live &= ~g.z["terminated"][t].astype(bool)
+    eng.close()
