@@ -19,6 +19,7 @@ import numpy as np
 
 from . import _abi, spawn
 from . import merge as _merge
+from . import intersection as _ix
 from .engine import Engine
 
 try:  # optional: only to expose real spaces when gymnasium is installed
@@ -167,10 +168,14 @@ class BatchedHighwayEnv:
         self.time[:] = 0
         self.steps = 0
         st = eng.get_state()
-        ego = self._hcfg.agent_index[0]
-        info = {"speed": st["speed"][:, ego].copy(), "crashed": (st["flags"][:, ego] & _abi.F_CRASHED) != 0,
+        rows, ego = np.arange(E), self._ego_slots(st)
+        info = {"speed": st["speed"][rows, ego].copy(), "crashed": (st["flags"][rows, ego] & _abi.F_CRASHED) != 0,
                 "action": None}
         return self._shape_obs(obs), info
+
+    def _ego_slots(self, st) -> np.ndarray:
+        """Slot of the (first) controlled vehicle of every env."""
+        return np.full(self.num_envs, self._hcfg.agent_index[0])
 
     def _spawn_reference(self, generators) -> dict:
         """``_create_vehicles`` replayed on each env's numpy Generator (highway_env.py:72-98)."""
@@ -289,6 +294,80 @@ class BatchedMergeGenericEnv(BatchedMergeEnv):
     GENERIC = True
 
 
+class BatchedIntersectionEnv(BatchedHighwayEnv):
+    """E parallel ``intersection-v0`` environments (IntersectionEnv, highway_env/envs/intersection_env.py): a 4-way
+    junction of straight and circular lanes, planned routes, ``RegulatedRoad`` priorities, traffic that is cleared and
+    spawned while the episode runs, 3 longitudinal meta-actions, Kinematics ``15 x 7`` absolute observation.
+
+    ``spawn_mode="reference"``: traffic management replays the reference's numpy stream on the host
+    (``highwayenv_amd/intersection.py``; ``reset(seed=s)`` and every later spawn are the reference's);
+    ``spawn_mode="device"``: the step kernel clears / spawns / resets on Philox draws (no host round trip).
+    ``config["max_vehicles"]`` (default 32) is the number of vehicle slots per environment."""
+    SCENARIO = "intersection"
+
+    @classmethod
+    def default_config(cls) -> dict:
+        return _ix.intersection_default_config()
+
+    def _define_spaces(self):
+        self.config["host_traffic"] = self.spawn_mode == "reference"
+        super()._define_spaces()
+        if _gym is not None:
+            self.single_action_space = _gym.spaces.Discrete(3)
+        else:
+            self.single_action_space = _Discrete(3)
+        self.action_space = self.single_action_space
+
+    def _device_spawn_args(self) -> dict:
+        return {}
+
+    def _ego_slots(self, st) -> np.ndarray:  # the ego's slot moves when the vehicle list is re-compacted
+        return np.argmax((st["flags"] & _abi.F_CONTROLLED) != 0, axis=1)
+
+    def reset(self, *, seed=None, options: dict | None = None):
+        if self.spawn_mode != "reference":
+            return super().reset(seed=seed, options=options)
+        if options and "config" in options:
+            self.configure(options["config"])
+        self._define_spaces()
+        eng = self._ensure_engine()
+        E = self.num_envs
+        seeds = [None] * E if seed is None else ([int(seed) + e for e in range(E)] if np.ndim(seed) == 0 else list(seed))
+        for e, s in enumerate(seeds):
+            if s is not None or self.np_random[e] is None:
+                self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+        eng.set_autoreset(False)
+        st = _ix.reset_reference_stream(eng, self._hcfg, self.config, self.np_random)
+        obs = eng.observe()
+        self.time[:] = 0
+        self.steps = 0
+        ego = (st["flags"] & _abi.F_CONTROLLED) != 0
+        info = {"speed": st["speed"][ego], "crashed": (st["flags"][ego] & _abi.F_CRASHED) != 0, "action": None}
+        return self._shape_obs(obs), info
+
+    def step(self, action):
+        out = super().step(action)
+        if self.spawn_mode == "reference":  # IntersectionEnv.step: _clear_vehicles, _spawn_vehicle (:136-140)
+            _ix.clear_and_spawn_reference_stream(self._engine, self._hcfg, self.config, self.np_random)
+        return out
+
+    def rewards(self, env_index: int = 0) -> dict:
+        """IntersectionEnv._agent_rewards (intersection_env.py:96-105) of one env, from the device state."""
+        st = self._engine.get_state()
+        e = env_index
+        i = int(np.nonzero(st["flags"][e] & _abi.F_CONTROLLED)[0][0])
+        tab = _ix.table_from_config(self._hcfg)
+        lane = int(st["lane"][e, i])
+        s, lat = _ix.lane_local(tab, lane, (st["x"][e, i], st["y"][e, i]))
+        r0, r1 = self.config["reward_speed_range"]
+        scaled = 0 + (st["speed"][e, i] - r0) * (1 - 0) / (r1 - r0)
+        on_road = abs(lat) <= tab["width"][lane] / 2 and -5.0 <= s < tab["length"][lane] + 5.0
+        return {"collision_reward": float(bool(st["flags"][e, i] & _abi.F_CRASHED)),
+                "high_speed_reward": float(np.clip(scaled, 0, 1)),
+                "arrived_reward": float(bool(tab["exit_lane"][lane]) and s >= 25),
+                "on_road_reward": float(on_road)}
+
+
 class _SingleEnvMixin:
     """E == 1 with the reference's unbatched signature."""
 
@@ -331,6 +410,21 @@ class _SingleMergeMixin(_SingleEnvMixin):
         return (obs[0], float(reward[0]), bool(term[0]), bool(trunc[0]),
                 {"speed": float(info["speed"][0]), "crashed": bool(info["crashed"][0]), "action": action,
                  "rewards": self.rewards(0, action)})
+
+
+class _SingleIntersectionMixin(_SingleEnvMixin):
+    @property
+    def vehicle(self) -> VehicleView:
+        st = self._engine.get_state()
+        return VehicleView(st, 0, int(np.nonzero(st["flags"][0] & _abi.F_CONTROLLED)[0][0]))
+
+    @property
+    def controlled_vehicles(self):
+        return [self.vehicle]
+
+
+class IntersectionEnv(_SingleIntersectionMixin, BatchedIntersectionEnv):
+    """Drop-in for ``highway_env.envs.intersection_env.IntersectionEnv`` (``intersection-v0``)."""
 
 
 class MergeEnv(_SingleMergeMixin, BatchedMergeEnv):

@@ -181,3 +181,66 @@ def test_batched_merge_generic_multi_agent_shapes_and_errors():
         EmuBatchedMergeGeneric({"after_merge_length": 50}, num_envs=1)
     with pytest.raises(NotImplementedError):
         EmuBatchedMergeGeneric({"observation": {"type": "OccupancyGrid"}}, num_envs=1)
+
+
+# ---- intersection-v0 (highway_env/envs/intersection_env.py) -----------------------------------------------------
+class EmuIntersection(envs._SingleIntersectionMixin, envs.BatchedIntersectionEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+class EmuBatchedIntersection(envs.BatchedIntersectionEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+@pytest.mark.parametrize("e", [0, 2])
+def test_single_intersection_env_dropin_matches_reference_episode(real, e):
+    """IntersectionEnv(): reset(seed=s) -- host spawns on the reference's numpy stream, the three warm-up seconds of
+    _make_vehicles on the engine -- then golden actions, clearing and spawning on the same stream: the reference's
+    obs / reward / terminated / truncated while the episode is live (stop at the first wreck or near-standstill:
+    see tests/test_oracle_golden_intersection.py on the ill-conditioned steering of a stopped car)."""
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection("intersection_default")
+    env = envs.IntersectionEnv() if real else EmuIntersection()
+    obs, info = env.reset(seed=int(g.z["seeds"][e]))
+    assert obs.shape == (15, 7) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)
+    assert abs(info["speed"] - 10.0) < 1e-12
+    compared = 0
+    for t in range(g.steps):
+        want = g.state("step", t)
+        pres = want["present"][e] != 0
+        if ((want["crashed"][e] != 0) | (want["has_impact"][e] != 0))[pres].any() or (np.abs(want["speed"][e][pres]) < 0.5).any():
+            break
+        obs, r, te, tr, info = env.step(int(g.actions[t, e, 0]))
+        assert isinstance(r, float) and isinstance(te, bool) and isinstance(tr, bool)
+        np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=f"step {t}")
+        assert abs(r - g.z["reward"][t, e]) < 1e-9
+        assert te == bool(g.z["terminated"][t, e]) and tr == bool(g.z["truncated"][t, e])
+        assert abs(info["speed"] - g.z["info_speed"][t, e]) < 1e-9
+        assert set(info["rewards"]) == {"collision_reward", "high_speed_reward", "arrived_reward", "on_road_reward"}
+        # the vehicle list after clear / spawn is the reference's
+        st = env.get_state()
+        nxt = g.state("next", t)
+        n = int(nxt["present"][e].sum())
+        assert int(((st["flags"][0] & _abi.F_ABSENT) == 0).sum()) == n
+        np.testing.assert_allclose(st["x"][0, :n], nxt["x"][e, :n], atol=1e-7)
+        compared += 1
+        if te or tr:
+            break
+    assert compared >= 3
+    with pytest.raises(KeyError):
+        env.step(3)  # IntersectionEnv.ACTIONS has three entries
+    assert env.vehicle.controlled and len(env.controlled_vehicles) == 1
+    env.close()
+
+
+def test_intersection_config_errors():
+    with pytest.raises(NotImplementedError):
+        EmuBatchedIntersection({"controlled_vehicles": 2}, num_envs=1)
+    with pytest.raises(NotImplementedError):
+        EmuBatchedIntersection({"destination": None}, num_envs=1)
+    with pytest.raises(NotImplementedError):
+        EmuBatchedIntersection({"observation": {"type": "OccupancyGrid"}}, num_envs=1)
+    env = EmuBatchedIntersection(num_envs=2)
+    assert env.single_action_space.n == 3 and env.single_observation_shape == (15, 7)
