@@ -1,0 +1,184 @@
+"""Device-side traffic management of the intersection scenario (csrc/hwy_ix.h: ix_clear_spawn, ix_spawn_env): the
+step kernel clears leaving vehicles, spawns new ones and re-spawns finished episodes on Philox draws.
+
+The random stream is not numpy's; what has to match the reference is the RULE.  The product's host implementation of
+that rule (highwayenv_amd/intersection.py: spawn_vehicle / clear_vehicles / make_vehicles_*) is pinned to the
+reference's reset(seed=s) and episodes in tests/test_envs_host.py; here it is driven by a fake Generator that hands
+out the kernel's own Philox draws in the reference's draw order, and the kernel must produce the same traffic.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi
+from highwayenv_amd import intersection as hix
+from tests.backends import BACKENDS, make_engine
+from tests.test_device_reset import philox_uniform2
+
+
+class PhiloxAsGenerator:
+    """The draws one _spawn_vehicle call takes, from the kernel's counters (vehicle id `stream`, 4 x 2 uniforms)."""
+
+    def __init__(self, seed, stream, episode, force_spawn=False):
+        u = []
+        for d in range(4):
+            u.extend(philox_uniform2(int(seed), int(stream), int(episode), d))
+        self.u = u
+        self.force = force_spawn
+        self.k_normal = 0
+
+    def uniform(self, low=None, high=None):
+        if low is None:
+            return 0.0 if self.force else self.u[0]
+        return low + (high - low) * self.u[7]
+
+    def choice(self, rng, size, replace):
+        r0 = min(int(self.u[1] * 4), 3)
+        r1 = min(int(self.u[2] * 3), 2)
+        r1 = r1 + 1 if r1 >= r0 else r1
+        return np.array([r0, r1])
+
+    def normal(self, loc=0.0):
+        a, b = (self.u[3], self.u[4]) if self.k_normal == 0 else (self.u[5], self.u[6])
+        self.k_normal += 1
+        return loc + np.sqrt(-2.0 * np.log(1.0 - a)) * np.cos(2 * np.pi * b)
+
+
+def _config(E, **over):
+    cfg = hix.intersection_default_config()
+    cfg.update(over)
+    return cfg, _abi.make_config(cfg, E, scenario="intersection")
+
+
+def _assert_same_traffic(got, want, atol=1e-9, what=""):
+    pres = (want["flags"] & _abi.F_ABSENT) == 0
+    np.testing.assert_array_equal((got["flags"] & _abi.F_ABSENT) == 0, pres, err_msg=f"{what}: present")
+    for k in ("lane", "target_lane", "flags", "route"):
+        np.testing.assert_array_equal(got[k][pres], want[k][pres], err_msg=f"{what}: {k}")
+    for k in ("x", "y", "heading", "speed", "target_speed", "timer", "delta"):
+        np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+
+
+def _host_reset(backend, cfg, c, seeds, episode):
+    """ix_spawn_env restated with the host rule: initial spawns, 45 frames on a host-traffic engine, challenger, ego."""
+    E = len(seeds)
+    tab = hix.table_from_config(c)
+    st = _abi.alloc_state_ix(E, c.num_vehicles)
+    n = int(cfg["initial_vehicle_count"])
+    for e, sd in enumerate(seeds):
+        for t in range(n - 1):
+            hix.spawn_vehicle(c, tab, st, e, PhiloxAsGenerator(sd, t, episode), np.linspace(0, 80, n)[t])
+    cfg_h = dict(cfg, host_traffic=True)
+    eng = make_engine(backend, _abi.make_config(cfg_h, E, scenario="intersection"))
+    eng.set_state(st)
+    eng.step_frames(None, 3 * int(cfg["simulation_frequency"]))
+    st = eng.get_state()
+    eng.close()
+    for e, sd in enumerate(seeds):
+        hix.spawn_vehicle(c, tab, st, e, PhiloxAsGenerator(sd, 500, episode, force_spawn=True), 60, spawn_probability=1.0,
+                          go_straight=True, position_deviation=0.1, speed_deviation=0.0)
+
+        class EgoDraw:
+            def normal(self, loc=0.0, _sd=sd):
+                a, b = philox_uniform2(int(_sd), 501, int(episode), 0)
+                return loc + np.sqrt(-2.0 * np.log(1.0 - a)) * np.cos(2 * np.pi * b)
+
+            def uniform(self, *a, **k):  # the challenger already took its draws
+                raise AssertionError
+        # second half of make_vehicles_after_warmup without its own challenger spawn: replay it with a generator whose
+        # first call (the challenger's uniform) rejects the spawn
+        class AfterWarmup(EgoDraw):
+            def uniform(self, *a, **k):
+                return 2.0
+        hix.make_vehicles_after_warmup(c, cfg, tab, st, e, AfterWarmup())
+    st["time"][...] = 0.0
+    return st
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_reset_follows_the_reference_rule(backend):
+    E = 6
+    cfg, c = _config(E, max_vehicles=24)
+    seeds = np.array([3, 2**40 + 17, 99, 12345678901234567, 0, 7], np.uint64)
+    eng = make_engine(backend, c)
+    obs = eng.reset(seeds=seeds)
+    got = eng.get_state()
+    want = _host_reset(backend, cfg, c, seeds, 0)
+    _assert_same_traffic(got, want, atol=1e-9, what="reset")
+    np.testing.assert_array_equal(got["road_steps"], 45)
+    assert (got["time"] == 0).all()
+    # one controlled vehicle per env, last in the list; the first observation row is the ego's absolute pose
+    ctrl = (got["flags"] & _abi.F_CONTROLLED) != 0
+    assert (ctrl.sum(1) == 1).all()
+    cfg_h = dict(cfg, host_traffic=True)
+    ref = make_engine(backend, _abi.make_config(cfg_h, E, scenario="intersection"))
+    ref.set_state(want)
+    np.testing.assert_allclose(obs, ref.observe(), rtol=0, atol=1e-6)
+    ref.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_step_clears_and_spawns_like_the_host_rule(backend):
+    """Same start, same actions: the device-traffic engine after each step == the host-traffic engine + the host
+    rule fed with the kernel's Philox draws (stream 1000 + step number)."""
+    E = 8
+    cfg, c = _config(E, max_vehicles=24, spawn_probability=0.9, duration=40)
+    base = 777
+    dev = make_engine(backend, c)
+    dev.reset(seeds=np.uint64(base) + np.arange(E, dtype=np.uint64))
+    dev.set_autoreset(False, base_seed=base)
+    cfg_h = dict(cfg, host_traffic=True)
+    ch = _abi.make_config(cfg_h, E, scenario="intersection")
+    host = make_engine(backend, ch)
+    host.set_state(dev.get_state())
+    tab = hix.table_from_config(c)
+    rng = np.random.default_rng(0)
+    n_spawn = n_clear = 0
+    for t in range(22):
+        acts = rng.integers(0, 3, size=(E, 1)).astype(np.int32)
+        o1, r1, te1, tr1, _ = dev.step(acts)
+        o2, r2, te2, tr2, _ = host.step(acts)
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_array_equal(te1, te2)
+        st = host.get_state()
+        before = ((st["flags"] & _abi.F_ABSENT) == 0).sum(1)
+        for e in range(E):
+            hix.clear_vehicles(ch, tab, st, e)
+        mid = ((st["flags"] & _abi.F_ABSENT) == 0).sum(1)
+        for e in range(E):
+            hix.spawn_vehicle(ch, tab, st, e, PhiloxAsGenerator(base + e, 1000 + t, 0), spawn_probability=0.9)
+        after = ((st["flags"] & _abi.F_ABSENT) == 0).sum(1)
+        n_clear += int((before - mid).sum())
+        n_spawn += int((after - mid).sum())
+        _assert_same_traffic(dev.get_state(), st, atol=1e-12, what=f"step {t}")
+        host.set_state(st)
+    assert n_spawn > 10 and n_clear > 3
+    dev.close()
+    host.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_autoreset_next_step_semantics(backend):
+    E = 6
+    cfg, c = _config(E, max_vehicles=24, duration=4)
+    base = 4242
+    eng = make_engine(backend, c)
+    eng.reset(seeds=np.uint64(base) + np.arange(E, dtype=np.uint64))
+    eng.set_autoreset(True, base_seed=base)
+    done_prev = np.zeros(E, bool)
+    episode = np.zeros(E, int)
+    n_resets = 0
+    for t in range(11):
+        obs, reward, term, trunc, info = eng.step(np.ones((E, 1), np.int32))
+        st = eng.get_state()
+        for e in np.nonzero(done_prev)[0]:
+            episode[e] += 1
+            want = _host_reset(backend, cfg, c, [base + e], int(episode[e]))
+            _assert_same_traffic({k: v[e:e + 1] for k, v in st.items() if v.ndim == 2},
+                                 {k: v for k, v in want.items() if v.ndim == 2}, atol=1e-9, what=f"step {t} env {e}")
+            assert reward[e, 0] == 0 and not term[e] and not trunc[e] and st["time"][e] == 0
+            n_resets += 1
+        done_prev = term | trunc
+    assert n_resets >= E  # duration 4: every env was truncated (or terminated) and re-spawned
+    eng.close()
