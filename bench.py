@@ -35,9 +35,10 @@ EVENT_EVERY = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int) -> int:
-    """B_env = 72*N + 110*A bytes per env-step."""
-    return 72 * n_vehicles + 110 * agents
+def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int, obs_floats: int = 25) -> int:
+    """B_env = 72*N + 110*A bytes per env-step (110 = 4*V*F obs + reward, flags, action for
+    the 5 x 5 observation; other observation shapes replace the 100 obs bytes)."""
+    return 72 * n_vehicles + (4 * obs_floats + 10) * agents
 
 
 def measured_traffic(envs_per_gpu: int, fast: bool = True):
@@ -60,6 +61,8 @@ def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: 
     same workload: same config, same spawn rule, random actions."""
     from highwayenv_amd import _abi, merge, spawn
     from oracle import oracle
+    if scenario == "intersection":
+        return cpu_baseline_intersection(cfg_dict, budget_s)
     E = 64 if fast else 8
     cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario)
     if scenario == "highway":
@@ -86,6 +89,69 @@ def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: 
             "vehicle_steps_per_s": rate * cfg.num_vehicles}
 
 
+def cpu_baseline_intersection(cfg_dict, budget_s: float = 12.0):
+    """oracle/hwy_oracle_ix.c (1 thread) on the same workload: start states from the engine's device reset, random
+    actions, clearing and spawning with numpy draws in the reference's format."""
+    from highwayenv_amd import _abi
+    from highwayenv_amd import intersection as hix
+    from highwayenv_amd.engine import Engine
+    from oracle import oracle_ix
+    E = 16
+    cfg = _abi.make_config(cfg_dict, E, scenario="intersection")
+    eng = Engine(cfg)
+    eng.reset(base_seed=11)
+    st_h = eng.get_state()
+    eng.close()
+    tab = hix.table_from_config(cfg)
+    lane_tab = {k: tab[k] for k in tab}
+    lane_tab["ex"] = lane_tab["ey"] = lane_tab["end_phase"] = np.zeros_like(tab["sx"])
+    lane_tab["id"] = np.zeros_like(tab["kind"])
+    oc = oracle_ix.make_config(cfg_dict, lane_tab, hix.NODE_NAMES, E, cfg.num_vehicles, 4)
+
+    def to_oracle(h):
+        st = oracle_ix.alloc_state(E, cfg.num_vehicles, 4)
+        for k in oracle_ix.STATE_F64:
+            st[k][...] = h[k]
+        f = h["flags"]
+        st["present"][...] = (f & _abi.F_ABSENT) == 0
+        for k, bit in (("crashed", _abi.F_CRASHED), ("has_impact", _abi.F_HAS_IMPACT), ("controlled", _abi.F_CONTROLLED),
+                       ("is_yielding", _abi.F_YIELDING)):
+            st[k][...] = (f & bit) != 0
+        for k in ("lane", "target_lane", "speed_index"):
+            st[k][...] = h[k]
+        for e in range(E):
+            for i in range(cfg.num_vehicles):
+                r = hix.route_unpack(int(h["route"][e, i])) if st["present"][e, i] else []
+                st["route_len"][e, i] = len(r)
+                for q, l in enumerate(r):
+                    st["route_from"][e, i, q], st["route_to"][e, i, q] = tab["from_node"][l], tab["to_node"][l]
+                    st["route_id"][e, i, q] = -1 if q else 0
+        st["road_steps"][...] = h["road_steps"]
+        return st
+
+    st0 = to_oracle(st_h)
+    rng = np.random.default_rng(3)
+    steps_done, t_used = 0, 0.0
+    st = {k: v.copy() for k, v in st0.items()}
+    while t_used < budget_s:
+        if steps_done % int(cfg_dict["duration"]) == 0:
+            st = {k: v.copy() for k, v in st0.items()}  # bounded stand-in for per-env resets: restart the batch
+        acts = rng.integers(0, 3, size=E).astype(np.int32)
+        route = np.stack([rng.permutation(4)[:2] for _ in range(E)]).astype(np.float64)
+        draws = np.column_stack([rng.uniform(size=E), route, rng.normal(size=(E, 2)), rng.uniform(3.5, 4.5, size=E),
+                                 np.zeros((E, 2))])
+        t0 = time.perf_counter()
+        oracle_ix.step(oc, st, acts)
+        oracle_ix.clear_spawn(oc, st, draws, np.full(E, 6, np.int32))
+        t_used += time.perf_counter() - t0
+        steps_done += 1
+    rate = steps_done * E / t_used
+    return {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{E} envs x {steps_done} policy steps of the same workload on 1 host core "
+                      f"(oracle/hwy_oracle_ix.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
+            "vehicle_slots": cfg.num_vehicles}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,11 +159,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge"], default="fast",
+    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge", "intersection"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
                          "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024); "
                          "merge_ma4 = BASELINE config 5 (merge-generic, 4 lanes, 40 traffic vehicles, 4 controlled agents "
-                         "per env); merge = merge-v0 defaults")
+                         "per env); merge = merge-v0 defaults; intersection = BASELINE config 4's world model "
+                         "(intersection-v0, 30 vehicle slots, Kinematics 15 x 7 obs; use --envs-per-gpu 2048)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +206,10 @@ def main() -> None:
                              "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
                              "observation": {"type": "MultiAgentObservation",
                                              "observation_config": {"type": "Kinematics"}}})
+    elif args.workload == "intersection":
+        from highwayenv_amd import intersection as hix
+        scenario, cfg_dict = "intersection", hix.intersection_default_config()
+        cfg_dict.update({"max_vehicles": 30})
     else:
         cfg_dict = _abi.highway_default_config()
         if args.workload == "v0_n100":
@@ -157,7 +228,8 @@ def main() -> None:
     total = args.warmup + args.steps
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    actions = torch.randint(0, 5, (total, E, A), generator=g, device=dev, dtype=torch.int32)
+    n_actions = 3 if scenario == "intersection" else 5
+    actions = torch.randint(0, n_actions, (total, E, A), generator=g, device=dev, dtype=torch.int32)
     # two alternating output blocks: the RCCL gather of step t (async, on RCCL's stream) overlaps the step kernel of
     # step t+1, which writes into the other block
     outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist) for _ in range(2)]
@@ -203,7 +275,7 @@ def main() -> None:
     # reported for DESIGN.md, never as `value`
     host_rate = None
     if world == 1:
-        acts_h = np.random.default_rng(5).integers(0, 5, size=(E, A)).astype(np.int32)
+        acts_h = np.random.default_rng(5).integers(0, n_actions, size=(E, A)).astype(np.int32)
         for _ in range(5):
             eng.step(acts_h)
         th = time.perf_counter()
@@ -221,7 +293,7 @@ def main() -> None:
     if rank == 0:
         env_steps = args.steps * E * world
         value = env_steps / elapsed
-        b_env = algorithmic_bytes_per_env_step(N, A)
+        b_env = algorithmic_bytes_per_env_step(N, A, int(np.prod(_abi.obs_shape(cfg))))
         # without HIP events (HWY_BENCH_NO_EVENTS=1, a developer knob) fall back to the wall-clock step time
         avg_kernel_s = kernel_ms / 1e3 / launches if launches else elapsed / args.steps
         achieved = b_env * E / avg_kernel_s / 1e9
@@ -241,6 +313,10 @@ def main() -> None:
             "config": {"workload": (f"highway-fast-v0, {E} envs/GPU x {VEHICLES_COUNT} IDM vehicles (+1 ego, N={N}), "
                                     f"{LANES} lanes, 5 frames/step, DiscreteMetaAction random actions, Kinematics 5x5 obs, "
                                     "device spawn + auto-reset") if fast else
+                                   (f"intersection-v0, {E} envs/GPU x {N} vehicle slots (4-way junction of 20 straight / circular lanes, "
+                                    f"planned routes, RegulatedRoad priorities, vehicles cleared and spawned every policy step on the "
+                                    f"device), {cfg.frames_per_step} frames/step, full pairwise collisions, random actions (3), Kinematics "
+                                    f"{cfg.obs_vehicles} x {cfg.obs_features} absolute obs, device reset + auto-reset") if scenario == "intersection" else
                                    (f"{'merge-v0' if scenario == 'merge' else 'merge-generic-v0'}, {E} envs/GPU x {N} slots "
                                     f"({A} controlled MDP vehicles, {N - A - 2} IDM traffic slots of which the rejection-sampled "
                                     f"spawn fills most, 1 merging IDM vehicle, 1 obstacle), {cfg.lanes_count} highway lanes + ramp "
@@ -253,7 +329,8 @@ def main() -> None:
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E, fast),
-                         "kernel": ("hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
+                         "kernel": ("hwy_ix_step_kernel  (one 64-wide wavefront per env)" if scenario == "intersection" else
+                                    "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "algorithmic_bytes_per_launch": b_env * E},
