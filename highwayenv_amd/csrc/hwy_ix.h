@@ -23,6 +23,7 @@
 
 #include "hwy_device.h"
 #include "hwy_wave.h"
+#include "hwy_net.h"
 
 namespace hwy {
 
@@ -54,12 +55,16 @@ __host__ __device__ inline int32_t route_make(int r0, int r1, int r2, int len) {
 
 struct IxVeh {
   double x, y, h, v, timer, ts, delta, impx, impy;
+  double ch, sh;  // cos / sin of the heading, refreshed whenever the heading changes
   int lane, tgt, sidx, flags, route;
 };
 
 #define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
 
-struct IxShared {
+// CAP = slots per environment the LDS arrays are sized for == threads per workgroup (32 or 64: a 32-thread workgroup
+// still occupies one wavefront, with the upper half of the lanes masked off)
+template <int CAP>
+struct IxSharedT {
   // lane table (struct of arrays: per-thread lane indices read it with one ds_read each)
   int kind[HWY_MAX_GLANES], ldir[HWY_MAX_GLANES], prio[HWY_MAX_GLANES], from[HWY_MAX_GLANES], to[HWY_MAX_GLANES],
       exitl[HWY_MAX_GLANES];
@@ -68,16 +73,18 @@ struct IxShared {
       wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
   u64 mask[HWY_MAX_GLANES];  // slot-space membership (on_lane, margin 1) of every lane
   // frame snapshot by slot
-  double x[64], y[64], v[64], c[64], s[64];
+  double x[CAP], y[CAP], v[CAP], c[CAP], s[CAP];
+  double bcx[CAP], bcy[CAP], brho[CAP];  // regulation: a circle around the 11 predicted positions of slot i
   union {
-    double sl[HWY_MAX_GLANES][64];           // longitudinal coordinate of slot i on lane L (act phase)
-    double traj[HWY_IX_SAMPLES][3][64];      // predicted (x, y, heading) of slot i at sample k (regulation)
+    double sl[HWY_MAX_GLANES][CAP];          // longitudinal coordinate of slot i on lane L (act phase)
+    double traj[HWY_IX_SAMPLES][3][CAP];     // predicted (x, y, heading) of slot i at sample k (regulation)
   };
 };
 
 // ---- lane geometry from the LDS table, per-thread lane index ---------------------------------------------------
 // StraightLane.local_coordinates (lane.py:209-213); CircularLane.local_coordinates (lane.py:355-362)
-__device__ inline void ix_local(const IxShared &sh, int L, double x, double y, double *s, double *lat) {
+template <typename SH>
+__device__ inline void ix_local(const SH &sh, int L, double x, double y, double *s, double *lat) {
   if (sh.kind[L] == 0) {
     const double dx = x - sh.sx[L], dy = y - sh.sy[L];
     *s = dx * sh.dirx[L] + dy * sh.diry[L];
@@ -92,13 +99,15 @@ __device__ inline void ix_local(const IxShared &sh, int L, double x, double y, d
   }
 }
 // heading_at (lane.py:203-204, 347-350)
-__device__ inline double ix_heading_at(const IxShared &sh, int L, double s) {
+template <typename SH>
+__device__ inline double ix_heading_at(const SH &sh, int L, double s) {
   if (sh.kind[L] == 0) return sh.lhead[L];
   const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
   return phi + HWY_PI / 2 * sh.ldir[L];
 }
 // position(s, 0) (lane.py:196-201, 341-345)
-__device__ inline void ix_position(const IxShared &sh, int L, double s, double *px, double *py) {
+template <typename SH>
+__device__ inline void ix_position(const SH &sh, int L, double s, double *px, double *py) {
   if (sh.kind[L] == 0) {
     *px = sh.sx[L] + s * sh.dirx[L] + 0.0 * -sh.diry[L];
     *py = sh.sy[L] + s * sh.diry[L] + 0.0 * sh.dirx[L];
@@ -109,7 +118,8 @@ __device__ inline void ix_position(const IxShared &sh, int L, double s, double *
   }
 }
 
-__device__ inline void ix_load_table(const IxParams &ip, IxShared &sh) {
+template <typename SH>
+__device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
   const int i = threadIdx.x;
   if (i < ip.n_lanes) {
     const hwy_glane &l = ip.lanes[i];
@@ -123,34 +133,49 @@ __device__ inline void ix_load_table(const IxParams &ip, IxShared &sh) {
 }
 
 // One walk over the lane table for my body (lane index wave-uniform): membership bits (on_lane margin 1, lane.py:80-102),
-// closest lane (road.py:55-71, lane.py:132-147; first minimum in table order) and s on every lane -> sh.sl[L][i].
-__device__ inline void ix_lane_pass(const IxParams &ip, IxShared &sh, double x, double y, double h, int *bits_out,
-                                    int *closest_out) {
+// closest lane (road.py:55-71, lane.py:132-147; minimum distance_with_heading, ties to the lowest table index) and s on
+// the lanes that can matter -> sh.sl[L][i].  Straight lanes first; a CircularLane costs an atan2, and it can neither hold
+// me (|lateral| > width / 2 + 1) nor be my closest lane (its distance is at least |lateral| = |radius - r|, which already
+// exceeds the best distance found) nor be my target lane for most vehicles most of the time: when that is so for the
+// whole wave the arc is skipped.  sl[L][i] is only read for members of L, for my own lane and for my target lane.
+template <typename SH>
+__device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, double x, double y, double h, int tgt,
+                                    int *bits_out, int *closest_out) {
   const int i = threadIdx.x;
   int bits = 0, best = 0;
-  double bd = 0.0;
+  double bd = __builtin_inf();
   for (int L = 0; L < ip.n_lanes; ++L) {
-    double s, lat, lane_h;
-    if (sh.kind[L] == 0) {  // wave-uniform
-      const double dx = x - sh.sx[L], dy = y - sh.sy[L];
-      s = dx * sh.dirx[L] + dy * sh.diry[L];
-      lat = dx * -sh.diry[L] + dy * sh.dirx[L];
-      lane_h = sh.lhead[L];
-    } else {
-      const double dx = x - sh.cx[L], dy = y - sh.cy[L];
-      double phi = atan2(dy, dx);
-      phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
-      const double r = sqrt(dx * dx + dy * dy);
-      s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
-      lat = sh.ldir[L] * (sh.rad[L] - r);
-      lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
+    if (sh.kind[L] != 0) continue;  // wave-uniform
+    const double dx = x - sh.sx[L], dy = y - sh.sy[L];
+    const double s = dx * sh.dirx[L] + dy * sh.diry[L];
+    const double lat = dx * -sh.diry[L] + dy * sh.dirx[L];
+    const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
+    bits |= on ? (1 << L) : 0;
+    sh.sl[L][i] = s;
+    const double angle = fabs(wrap_to_pi(h - sh.lhead[L]));
+    const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+    if (d < bd) { bd = d; best = L; }
+  }
+  for (int L = 0; L < ip.n_lanes; ++L) {
+    if (sh.kind[L] == 0) continue;  // wave-uniform
+    const double dx = x - sh.cx[L], dy = y - sh.cy[L];
+    const double r = sqrt(dx * dx + dy * dy);
+    const double lat = sh.ldir[L] * (sh.rad[L] - r);
+    const bool need = present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);
+    if (__ballot(need) == 0) {
+      sh.sl[L][i] = 0.0;
+      continue;
     }
+    double phi = atan2(dy, dx);
+    phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
+    const double s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
+    const double lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
     const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
     bits |= on ? (1 << L) : 0;
     sh.sl[L][i] = s;
     const double angle = fabs(wrap_to_pi(h - lane_h));
     const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-    if (L == 0 || d < bd) { bd = d; best = L; }
+    if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
   }
   *bits_out = bits;
   *closest_out = best;
@@ -158,7 +183,8 @@ __device__ inline void ix_lane_pass(const IxParams &ip, IxShared &sh, double x, 
 
 // Road.neighbour_vehicles (road.py:483-547, connected lanes off): the leader on lane L among the members of mask[L]
 // (slot order == list order: `<=` lets a later vehicle at the same s win, like the reference's scan)
-__device__ inline int ix_front(const IxShared &sh, int L, int self) {
+template <typename SH>
+__device__ inline int ix_front(const SH &sh, int L, int self) {
   const double s = sh.sl[L][self];
   int f = -1;
   double s_front = 0.0;
@@ -171,7 +197,8 @@ __device__ inline int ix_front(const IxShared &sh, int L, int self) {
 }
 
 // RoadNetwork.next_lane (road.py:73-133) for one-lane roads; consumes the head of the route like route.pop(0)
-__device__ inline int ix_next_lane(const IxParams &ip, const IxShared &sh, int cur, IxVeh &me) {
+template <typename SH>
+__device__ inline int ix_next_lane(const IxParams &ip, const SH &sh, int cur, IxVeh &me) {
   int next = -1;
   if (route_len(me.route) > 0) {
     if (route_at(me.route, 0) == cur) me.route = route_pop(me.route);
@@ -194,7 +221,8 @@ __device__ inline int ix_next_lane(const IxParams &ip, const IxShared &sh, int c
 }
 
 // position_heading_along_route (road.py:323-362) with lateral 0: route = v.route or [v.lane_index]
-__device__ inline void ix_along_route(const IxShared &sh, const IxVeh &me, double lon, double *px, double *py, double *hd) {
+template <typename SH>
+__device__ inline void ix_along_route(const SH &sh, const IxVeh &me, double lon, double *px, double *py, double *hd) {
   const int n = route_len(me.route);
   int pos = 0;
   int li = n > 0 ? route_at(me.route, 0) : me.lane;
@@ -225,7 +253,8 @@ __device__ inline bool ix_corner_inside(double c1x, double c1y, double a1, doubl
 }
 
 // Vehicle ctor pieces shared by the device spawn paths: lane index, IDM timer, planned route to "o" + dest
-__device__ inline int ix_plan_route(const IxParams &ip, const IxShared &sh, int lane, int dest) {
+template <typename SH>
+__device__ inline int ix_plan_route(const IxParams &ip, const SH &sh, int lane, int dest) {
   // plan_route_to (controller.py:71-87): [lane_index] + shortest path lane_index[1] -> "o" + dest; on this network
   // the path from the end of an access lane is always [turn / crossing lane, exit lane]
   const int ex = ip.exit_of[dest];
@@ -253,6 +282,7 @@ __device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o) {
       o.impy = p.st.impact_y[k];
     }
   }
+  sincos_bounded(o.h, &o.sh, &o.ch);
 }
 __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o) {
   const StepParams &p = ip.s;
@@ -269,7 +299,8 @@ __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &
 }
 
 // ---- n_frames x { [meta-action]; Road.act(); RegulatedRoad.step(dt) } on the wave's registers + LDS --------------
-__device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh &me, int n_frames, const int32_t *actions,
+template <typename SH>
+__device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, int n_frames, const int32_t *actions,
                                  int &road_steps, int &bits) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
@@ -295,37 +326,43 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
       const u64 b = __ballot(present && ((bits >> L) & 1));
       if (i == 0) sh.mask[L] = b;
     }
-    const double ch = cos(me.h), shh = sin(me.h);
+    const double ch = me.ch, shh = me.sh;
     sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = ch; sh.s[i] = shh;
     __syncthreads();
 
     // ---- C. Road.act (road.py:464-467) ---------------------------------------------------------------------------
-    double steering = 0.0, accel = 0.0;
+    // steering -> slip angle -> bicycle model are folded like in hwy_net.h: tb = tan(beta) with beta = atan(tan(delta) / 2)
+    // (controller.py:145-187 + kinematics.py:141-152; exact trigonometric identities, <= 2 ulp from the literal chain)
+    double tb = 0.0, accel = 0.0;
     const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
     const bool acts = present && (controlled || !crashed0);  // IDMVehicle.act returns early when crashed
     if (acts) {
       // follow_road (controller.py:135-143): AbstractLane.after_end on the target lane (lane.py:120-125)
-      if (sh.sl[me.tgt][i] > sh.len[me.tgt] - 5.0 / 2) me.tgt = ix_next_lane(ip, sh, me.tgt, me);
+      if (sh.sl[me.tgt][i] > sh.len[me.tgt] - 5.0 / 2) {
+        me.tgt = ix_next_lane(ip, sh, me.tgt, me);
+        // my coordinate on the new target lane (the table walk skipped it if I was not near it; only I read this slot
+        // unless I am a member of that lane, in which case the walk wrote the same value)
+        double s_new, lat_new;
+        ix_local(sh, me.tgt, me.x, me.y, &s_new, &lat_new);
+        sh.sl[me.tgt][i] = s_new;
+      }
       if (!controlled && me.lane == me.tgt && HWY_LC_DELAY < me.timer) me.timer = 0.0;  // behavior.py:246-248
-      // steering_control (controller.py:145-187)
       {
         double s_t, lat_t;
         ix_local(sh, me.tgt, me.x, me.y, &s_t, &lat_t);
         const double lane_future_heading = ix_heading_at(sh, me.tgt, s_t + me.v * (0.5 * 0.2));
-        const double lateral_speed_command = -HWY_KP_LATERAL * lat_t;
-        const double heading_command = asin(clipd(lateral_speed_command / not_zero(me.v), -1.0, 1.0));
-        const double heading_ref = lane_future_heading + clipd(heading_command, -HWY_PI / 4, HWY_PI / 4);
-        const double heading_rate_command = HWY_KP_HEADING * wrap_to_pi(heading_ref - me.h);
-        const double slip_angle = asin(clipd(HWY_VEH_LENGTH / 2 / not_zero(me.v) * heading_rate_command, -1.0, 1.0));
-        steering = clipd(atan(2 * tan(slip_angle)), -HWY_MAX_STEER, HWY_MAX_STEER);
+        tb = net_steer_tan_beta(lat_t, lane_future_heading, me.h, fast_rcp(not_zero(me.v)));
       }
       if (controlled) {
         accel = HWY_KP_A * (me.ts - me.v);  // speed_control (controller.py:189-198)
       } else {
-        // IDM (behavior.py:150-217) on the current lane, and on the target lane while they differ
+        // IDM (behavior.py:150-217) on the current lane, and on the target lane while they differ;
+        // (v / v0) ** delta == exp(delta * log(v / v0)) with the bounded-domain routines of hwy_math.h
         const double v0 = clipd(me.ts, 0.0, sh.lim[me.lane]);
-        const double free_acc = ip.a_max * (1 - pow(fmax(me.v, 0.0) / fabs(not_zero(v0)), me.delta));
-        const double ab2 = 2 * sqrt(-ip.a_max * ip.b_min);
+        const double ratio = fmax(me.v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+        const double powr = ratio > 0.0 ? exp_bounded(fmin(me.delta * log_pos(ratio), 40.0)) : 0.0;
+        const double free_acc = ip.a_max * (1 - powr);
+        const double inv_ab2 = fast_rcp(2 * sqrt(-ip.a_max * ip.b_min));
         accel = free_acc;
         for (int q = 0; q < 2; ++q) {
           const int Lq = q == 0 ? me.lane : me.tgt;
@@ -336,8 +373,8 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
             // lane_distance_to is measured on MY current lane (objects.py:183-198)
             const double d = sh.sl[me.lane][f] - sh.sl[me.lane][i];
             const double dv = (me.v * ch - sh.v[f] * sh.c[f]) * ch + (me.v * shh - sh.v[f] * sh.s[f]) * shh;
-            const double d_star = ip.d0 + me.v * ip.tau + me.v * dv / ab2;
-            const double r = d_star / not_zero(d);
+            const double d_star = ip.d0 + me.v * ip.tau + (me.v * dv) * inv_ab2;
+            const double r = d_star * fast_rcp(not_zero(d));
             a -= ip.a_max * (r * r);
           }
           accel = q == 0 ? a : fmin(accel, a);
@@ -363,13 +400,29 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
           sh.traj[k][0][i] = px; sh.traj[k][1][i] = py; sh.traj[k][2][i] = hd;
         }
       }
+      // Two vehicles can only conflict if at some sample their predicted positions are within LENGTH of each other
+      // (regulation.py:103): bound every vehicle's 11 positions by a circle (centre = the middle sample) and skip a
+      // partner for the whole wave when no pair of circles comes within LENGTH (triangle inequality, 1e-6 of slack)
+      double my_cx = 0.0, my_cy = 0.0, my_rho = 0.0;
+      if (veh) {
+        my_cx = sh.traj[HWY_IX_SAMPLES / 2][0][i];
+        my_cy = sh.traj[HWY_IX_SAMPLES / 2][1][i];
+        for (int k = 0; k < HWY_IX_SAMPLES; ++k) {
+          const double dx = sh.traj[k][0][i] - my_cx, dy = sh.traj[k][1][i] - my_cy;
+          my_rho = fmax(my_rho, sqrt(dx * dx + dy * dy));
+        }
+      }
+      sh.bcx[i] = my_cx; sh.bcy[i] = my_cy; sh.brho[i] = my_rho;
       __syncthreads();
       bool yield = false;
       for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j
         const int j = ctz64(m);
+        const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
+        const bool possible = veh && i != j && sqrt(bdx * bdx + bdy * bdy) <= my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;
+        if (__ballot(possible) == 0) continue;
         const int lane_j = wave_bcast_i(me.lane, j);
         bool conflict = false;
-        if (veh && i != j) {
+        if (possible) {
           for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
             const double ax = sh.traj[k][0][i], ay = sh.traj[k][1][i], bx = sh.traj[k][0][j], by = sh.traj[k][1][j];
             const double dx = bx - ax, dy = by - ay;
@@ -405,14 +458,15 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
     // ---- E. Vehicle.step (kinematics.py:130-177, behavior.py:139-148) -------------------------------------------------
     if (present) {
       if (!controlled) me.timer += p.dt;
+      if (!acts) tb = 0.0;
       if (crashed0) {  // clip_actions
-        steering = 0.0;
+        tb = 0.0;
         accel = -1.0 * me.v;
       }
       accel = (me.v > HWY_MAX_SPEED) ? fmin(accel, 1.0 * (HWY_MAX_SPEED - me.v))
                                      : ((me.v < HWY_MIN_SPEED) ? fmax(accel, 1.0 * (HWY_MIN_SPEED - me.v)) : accel);
-      const double beta = atan(1.0 / 2 * tan(steering));
-      const double vx = me.v * cos(me.h + beta), vy = me.v * sin(me.h + beta);
+      const double cb = fast_rsqrt(1.0 + tb * tb), sb = tb * cb;
+      const double vx = me.v * (me.ch * cb - me.sh * sb), vy = me.v * (me.sh * cb + me.ch * sb);
       me.x += vx * p.dt;
       me.y += vy * p.dt;
       if (me.flags & HWY_F_HAS_IMPACT) {
@@ -421,20 +475,21 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
         me.flags = (me.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
         me.impx = me.impy = 0.0;
       }
-      me.h += me.v * sin(beta) / (HWY_VEH_LENGTH / 2) * p.dt;
+      me.h += me.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       me.v += accel * p.dt;
+      sincos_bounded(me.h, &me.sh, &me.ch);
     }
     __syncthreads();  // the trajectories (if any) are dead: sl[][] is written again
     {
       int cl_new, bits_new;  // on_state_update + the next frame's membership bits and s table
-      ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits_new, &cl_new);
+      ix_lane_pass(ip, sh, present, me.x, me.y, me.h, me.tgt, &bits_new, &cl_new);
       if (present) me.lane = cl_new;
       bits = present ? bits_new : 0;
     }
 
     // ---- F. collisions (road.py:477-481, objects.py:92-138): every pair; the highest partner slot's impact stays ----
     {
-      const double c2 = cos(me.h), s2 = sin(me.h);
+      const double c2 = me.ch, s2 = me.sh;
       __syncthreads();
       sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
       __syncthreads();
@@ -466,7 +521,8 @@ __device__ inline void ix_frames(const IxParams &ip, IxShared &sh, int e, IxVeh 
 }
 
 // ---- KinematicObservation (observation.py:234-276, road.py:421-450) + IntersectionEnv reward / termination -----------
-__device__ inline void ix_observe(const IxParams &ip, const IxShared &sh, int e, const IxVeh &me, bool write_reward) {
+template <typename SH>
+__device__ inline void ix_observe(const IxParams &ip, const SH &sh, int e, const IxVeh &me, bool write_reward) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
@@ -477,8 +533,10 @@ __device__ inline void ix_observe(const IxParams &ip, const IxShared &sh, int e,
   const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia), eh = wave_bcast(me.h, ia);
   const int elane = wave_bcast_i(me.lane, ia);
   const double dxe = me.x - ex, dye = me.y - ey;
-  // observer.lane_distance_to(me) on the observer's lane: s table of the last lane pass (positions unchanged since)
-  const double d_lane = sh.sl[elane][i] - sh.sl[elane][ia];
+  // observer.lane_distance_to(me): both projected on the observer's lane (wave-uniform lane: no divergence)
+  double s_mine, lat_unused;
+  ix_local(sh, elane, me.x, me.y, &s_mine, &lat_unused);
+  const double d_lane = s_mine - wave_bcast(s_mine, ia);
   const bool elig = present && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
                     ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
   const double key = elig ? fabs(d_lane) : __builtin_inf();
@@ -494,7 +552,7 @@ __device__ inline void ix_observe(const IxParams &ip, const IxShared &sh, int e,
     float *out = p.obs + (size_t)e * (size_t)(V * F);
     const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
     if (present && row >= 0) {
-      const double ch = cos(me.h), shh = sin(me.h);
+      const double ch = me.ch, shh = me.sh;
       for (int f = 0; f < F; ++f) {
         const int fid = p.feat[f];
         double val = fid == HWY_FEAT_PRESENCE ? 1.0 : fid == HWY_FEAT_X ? me.x : fid == HWY_FEAT_Y ? me.y
@@ -516,7 +574,7 @@ __device__ inline void ix_observe(const IxParams &ip, const IxShared &sh, int e,
         out[row * F + f] = (float)val;
       }
     }
-    for (int t = i; t < V * F; t += 64)
+    for (int t = i; t < V * F; t += (int)blockDim.x)
       if (t / F > mrows) out[t] = 0.0f;
   }
   if (write_reward && i == ia) {
@@ -561,7 +619,7 @@ __device__ inline void ix_compact(IxVeh &me, bool keep) {
 #define MOVE_D(f) f = __hiloint2double(wave_send_i(__double2hiint(f), dst), wave_send_i(__double2loint(f), dst))
   int flags = keep ? me.flags : HWY_F_ABSENT;
   MOVE_D(me.x); MOVE_D(me.y); MOVE_D(me.h); MOVE_D(me.v); MOVE_D(me.timer); MOVE_D(me.ts); MOVE_D(me.delta);
-  MOVE_D(me.impx); MOVE_D(me.impy);
+  MOVE_D(me.impx); MOVE_D(me.impy); MOVE_D(me.ch); MOVE_D(me.sh);
   MOVE_I(me.lane); MOVE_I(me.tgt); MOVE_I(me.sidx); MOVE_I(flags); MOVE_I(me.route);
   me.flags = flags;
 #undef MOVE_I
@@ -569,7 +627,8 @@ __device__ inline void ix_compact(IxVeh &me, bool keep) {
 }
 
 // IntersectionEnv._spawn_vehicle (intersection_env.py:292-324) on given draws; thread `slot` becomes the new vehicle
-__device__ inline void ix_spawn(const IxParams &ip, IxShared &sh, IxVeh &me, double longitudinal, double position_deviation,
+template <typename SH>
+__device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double longitudinal, double position_deviation,
                                 double speed_deviation, double spawn_probability, bool go_straight, double u_spawn,
                                 double u_r0, double u_r1, double z_pos, double z_speed, double u_delta) {
   const StepParams &p = ip.s;
@@ -612,11 +671,13 @@ __device__ inline void ix_spawn(const IxParams &ip, IxShared &sh, IxVeh &me, dou
     me.route = ix_plan_route(ip, sh, best, r1);
     me.delta = 3.5 + (4.5 - 3.5) * u_delta;  // randomize_behavior (behavior.py:66-69)
     me.flags = HWY_F_CHECK_COLLISIONS;
+    sincos_bounded(me.h, &me.sh, &me.ch);
   }
 }
 
 // IntersectionEnv.step's tail (intersection_env.py:136-140): _clear_vehicles + one _spawn_vehicle
-__device__ inline void ix_clear_spawn(const IxParams &ip, IxShared &sh, IxVeh &me, uint64_t seed, uint32_t episode,
+template <typename SH>
+__device__ inline void ix_clear_spawn(const IxParams &ip, SH &sh, IxVeh &me, uint64_t seed, uint32_t episode,
                                       uint32_t step_no) {
   const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
@@ -635,7 +696,8 @@ __device__ inline void ix_clear_spawn(const IxParams &ip, IxShared &sh, IxVeh &m
 }
 
 // IntersectionEnv._make_vehicles (intersection_env.py:232-290) on Philox draws
-__device__ inline void ix_spawn_env(const IxParams &ip, IxShared &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
+template <typename SH>
+__device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
                                     int &road_steps, int &bits) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
@@ -655,7 +717,7 @@ __device__ inline void ix_spawn_env(const IxParams &ip, IxShared &sh, int e, uin
   // three simulated seconds without the ego
   {
     int unused;
-    ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
     bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
     const int sim_freq = (int)rint(1 / p.dt);
     ix_frames(ip, sh, e, me, 3 * sim_freq, nullptr, road_steps, bits);
@@ -697,17 +759,18 @@ __device__ inline void ix_spawn_env(const IxParams &ip, IxShared &sh, int e, uin
     me.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
     me.ts = p.target_speeds[me.sidx];
     me.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
+    sincos_bounded(me.h, &me.sh, &me.ch);
   }
   int unused;
-  ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+  ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
   bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
 }
 
 // =============================================================================================================
-template <int WPE>
-__global__ void __launch_bounds__(64, WPE) hwy_ix_step_kernel(const IxParams ip) {
+template <int WPE, int CAP>
+__global__ void __launch_bounds__(CAP, WPE) hwy_ix_step_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
-  __shared__ IxShared sh;
+  __shared__ IxSharedT<CAP> sh;
   const int e = blockIdx.x, i = threadIdx.x;
   ix_load_table(ip, sh);
   IxVeh me;
@@ -735,7 +798,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_ix_step_kernel(const IxParams ip)
   const uint32_t step_no = (uint32_t)rint(p.st.time[e] / p.policy_dt);  // read before anybody advances the clock
   {
     int unused;
-    ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
+    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
     bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
   }
   ix_frames(ip, sh, e, me, p.n_frames, p.actions, road_steps, bits);
@@ -749,10 +812,10 @@ __global__ void __launch_bounds__(64, WPE) hwy_ix_step_kernel(const IxParams ip)
 }
 
 // Reset kernel: AbstractEnv.reset for the masked environments + first observation.
-template <int WPE>
-__global__ void __launch_bounds__(64, WPE) hwy_ix_reset_kernel(const IxParams ip) {
+template <int WPE, int CAP>
+__global__ void __launch_bounds__(CAP, WPE) hwy_ix_reset_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
-  __shared__ IxShared sh;
+  __shared__ IxSharedT<CAP> sh;
   const int e = blockIdx.x, i = threadIdx.x;
   ix_load_table(ip, sh);
   if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
@@ -771,15 +834,12 @@ __global__ void __launch_bounds__(64, WPE) hwy_ix_reset_kernel(const IxParams ip
 }
 
 // Observation-only kernel (hwy_observe).
-template <int WPE>
-__global__ void __launch_bounds__(64, WPE) hwy_ix_observe_kernel(const IxParams ip) {
-  __shared__ IxShared sh;
+template <int WPE, int CAP>
+__global__ void __launch_bounds__(CAP, WPE) hwy_ix_observe_kernel(const IxParams ip) {
+  __shared__ IxSharedT<CAP> sh;
   ix_load_table(ip, sh);
   IxVeh me;
   ix_load_vehicle(ip, blockIdx.x, me);
-  int bits, unused;
-  ix_lane_pass(ip, sh, me.x, me.y, me.h, &bits, &unused);
-  __syncthreads();
   ix_observe(ip, sh, blockIdx.x, me, false);
 }
 

@@ -77,15 +77,18 @@ hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t str
   return hipGetLastError();
 }
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_ix_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_ix_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 hipError_t launch_ix_observe(const IxParams &ip, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_ix_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_observe_kernel<1, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_observe_kernel<1, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 __global__ void hwy_math_probe_kernel(int op, const double *in, double *out, long long n) {

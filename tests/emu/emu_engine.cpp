@@ -76,10 +76,18 @@ void dispatch(Which which, const StepParams &p, int E) {
     ip.lanes = g_cfg->gnet;
     ip.route = g_st->route;  // pitch == N in the emulation
     ip.road_steps = g_st->road_steps;
-    switch (which) {
-      case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1>(q); }, E, 64, ip); break;
-      case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1>(q); }, E, 64, ip); break;
-      case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1>(q); }, E, 64, ip); break;
+    if (p.N <= 32) {  // same dispatch rule as hwy_kernels.hip
+      switch (which) {
+        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32>(q); }, E, 32, ip); break;
+        case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 32>(q); }, E, 32, ip); break;
+        case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1, 32>(q); }, E, 32, ip); break;
+      }
+    } else {
+      switch (which) {
+        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 64>(q); }, E, 64, ip); break;
+        case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 64>(q); }, E, 64, ip); break;
+        case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1, 64>(q); }, E, 64, ip); break;
+      }
     }
     return;
   }
