@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "highwayenv_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_device.h", "hwy_math.h",
-         "hwy_net.h")
-W, D, NET = "hwy_wave.h", "hwy_device.h", "hwy_net.h"
+         "hwy_net.h", "hwy_ix.h")
+W, D, NET, IX = "hwy_wave.h", "hwy_device.h", "hwy_net.h", "hwy_ix.h"
 
 
 class Stale(Exception):
@@ -133,6 +133,13 @@ VARIANTS = {
     "wticks": [(W, ticks)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
+    # intersection kernel (hwy_ix.h): sections removed (timing only)
+    "ixbase": [],
+    "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],
+    "ixnocoll": [(IX, sub("      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j, ascending", "      for (u64 m = 0; m; m &= m - 1) {"))],
+    "ixnoarc": [(IX, sub("    const bool need = present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);", "    const bool need = false;"))],
+    "ixnoreset": [(IX, sub("  if (p.autoreset && p.st.done[e]) {  // the step after", "  if (false) {  // the step after"))],
+    "ixnoact": [(IX, sub("    if (acts) {\n      // follow_road", "    if (false) {\n      // follow_road"))],
     # generic workgroup kernel (hwy_device.h)
     "base": [],
     "nocollide": [(D, cutter("    if (all_check) {\n      // Full pairwise (highway-v0): outward scan", "  }  // frames", "    if (false) {}\n"))],
