@@ -159,12 +159,13 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge", "intersection"], default="fast",
+    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge", "intersection", "intersection_kin"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
                          "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024); "
                          "merge_ma4 = BASELINE config 5 (merge-generic, 4 lanes, 40 traffic vehicles, 4 controlled agents "
                          "per env); merge = merge-v0 defaults; intersection = BASELINE config 4's world model "
-                         "(intersection-v0, 30 vehicle slots, Kinematics 15 x 7 obs; use --envs-per-gpu 2048)")
+                         "(intersection-v0, 30 vehicle slots, OccupancyGrid 4 x 11 x 11 obs; use --envs-per-gpu 2048); intersection_kin = "
+                         "the same with intersection-v0's default Kinematics 15 x 7 observation")
     args = ap.parse_args()
 
     import torch
@@ -206,10 +207,12 @@ def main() -> None:
                              "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
                              "observation": {"type": "MultiAgentObservation",
                                              "observation_config": {"type": "Kinematics"}}})
-    elif args.workload == "intersection":
+    elif args.workload in ("intersection", "intersection_kin"):
         from highwayenv_amd import intersection as hix
         scenario, cfg_dict = "intersection", hix.intersection_default_config()
         cfg_dict.update({"max_vehicles": 30})
+        if args.workload == "intersection":  # BASELINE config 4: IntersectionEnv({"observation": {"type": "OccupancyGrid"}})
+            cfg_dict["observation"] = {"type": "OccupancyGrid"}
     else:
         cfg_dict = _abi.highway_default_config()
         if args.workload == "v0_n100":
@@ -315,8 +318,10 @@ def main() -> None:
                                     "device spawn + auto-reset") if fast else
                                    (f"intersection-v0, {E} envs/GPU x {N} vehicle slots (4-way junction of 20 straight / circular lanes, "
                                     f"planned routes, RegulatedRoad priorities, vehicles cleared and spawned every policy step on the "
-                                    f"device), {cfg.frames_per_step} frames/step, full pairwise collisions, random actions (3), Kinematics "
-                                    f"{cfg.obs_vehicles} x {cfg.obs_features} absolute obs, device reset + auto-reset") if scenario == "intersection" else
+                                    f"device), {cfg.frames_per_step} frames/step, full pairwise collisions, random actions (3), "
+                                    + (f"OccupancyGrid {'x'.join(str(k) for k in _abi.obs_shape(cfg))} obs (presence, vx, vy, on_road)"
+                                       if cfg.obs_type == _abi.OBS_OCCUPANCY_GRID else
+                                       f"Kinematics {cfg.obs_vehicles} x {cfg.obs_features} absolute obs") + ", device reset + auto-reset") if scenario == "intersection" else
                                    (f"{'merge-v0' if scenario == 'merge' else 'merge-generic-v0'}, {E} envs/GPU x {N} slots "
                                     f"({A} controlled MDP vehicles, {N - A - 2} IDM traffic slots of which the rejection-sampled "
                                     f"spawn fills most, 1 merging IDM vehicle, 1 obstacle), {cfg.lanes_count} highway lanes + ramp "

@@ -308,8 +308,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         raise NotImplementedError("neighbour_vehicles_connected_lanes (merge-v1 / merge-generic-v1) is out of scope"
                                   if merge else
                                   "neighbour_vehicles_connected_lanes is meaningless on a single-segment highway")
-    if (merge or ix) and grid:
-        raise NotImplementedError("OccupancyGrid is implemented for the straight-road scenarios only")
+    if merge and grid:
+        raise NotImplementedError("OccupancyGrid is not implemented for the merge networks")
     if ix and cfg.get("neighbour_vehicles_connected_lanes", False):
         raise NotImplementedError("neighbour_vehicles_connected_lanes (intersection-v2) is out of scope")
     if not grid and obs.get("order", "sorted") != "sorted":
@@ -420,7 +420,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         raise NotImplementedError("KinematicObservation include_obstacles=False is out of scope")
     if ix:
         for name in feats:
-            if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h"):
+            if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h") + (("on_road",) if grid else ()):
                 raise NotImplementedError(f"feature {name!r} is out of scope for the intersection scenario")
         if obs.get("observe_intentions", False):
             raise NotImplementedError("observe_intentions is out of scope")

@@ -520,15 +520,96 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
   }
 }
 
+// ---- OccupancyGridObservation.observe (observation.py:354-413) for the controlled vehicle, same scheme as observe_grid in
+//      hwy_device.h (atomic-min cell ownership: the lowest slot wins like the reference's reverse iteration; owners write
+//      their features; a cell-strided pass writes the on-road layer and the zeros), with the on-road layer painted from
+//      the waypoints of EVERY lane of the network (fill_road_layer_by_lanes, :454-484: straight lanes of any direction
+//      and circular arcs).  sh.brho doubles as the per-lane origin table. ------------------------------------------------
+template <typename SH>
+__device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, const IxVeh &me, bool present, int ia) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x, NT = (int)blockDim.x;
+  const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
+  const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
+  const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
+  int32_t *own = p.grid_ws + (size_t)e * 2 * (size_t)WH, *road = own + WH;
+  float *out = p.obs + (size_t)e * (size_t)F * WH;
+  for (int t = i; t < WH; t += NT) {
+    grid_ws_store(own + t, 0x7fffffff);
+    grid_ws_store(road + t, 0);
+  }
+  __syncthreads();
+  int my_ci = -1, my_cj = -1;
+  if (present) {
+    double x = me.x - ex, y = me.y - ey;
+    if (p.rx0 > -__builtin_inf()) x = lmap(lmap(x, p.rx0, p.rx1, -1.0, 1.0), -1.0, 1.0, p.rx0, p.rx1);
+    if (p.ry0 > -__builtin_inf()) y = lmap(lmap(y, p.ry0, p.ry1, -1.0, 1.0), -1.0, 1.0, p.ry0, p.ry1);
+    int ci, cj;
+    grid_cell(p, x, y, ec, es, &ci, &cj);
+    if (0 <= ci && ci < W && 0 <= cj && cj < H) {
+      my_ci = ci;
+      my_cj = cj;
+      grid_ws_min(own + ci * H + cj, i);
+    }
+  }
+  bool has_road = false;
+  for (int f = 0; f < F; ++f) has_road |= (p.feat[f] == HWY_FEAT_ON_ROAD);
+  if (has_road) {  // wave-uniform
+    // origin of lane L = lane.local_coordinates(observer.position)[0], one lane per thread
+    if (i < ip.n_lanes) {
+      double s, lat;
+      ix_local(sh, i, ex, ey, &s, &lat);
+      sh.brho[i] = s;
+    }
+    __syncthreads();
+    for (int t = i; t < ip.n_lanes * p.g_nwp; t += NT) {
+      const int k = t / p.g_nwp, j = t - k * p.g_nwp;
+      const double wp = clipd((sh.brho[k] - 100.0) + j * p.g_spacing, 0.0, sh.len[k]);
+      double px, py;
+      ix_position(sh, k, wp, &px, &py);
+      int ci, cj;
+      grid_cell(p, px - ex, py - ey, ec, es, &ci, &cj);
+      if (0 <= ci && ci < W && 0 <= cj && cj < H) grid_ws_store(road + ci * H + cj, 1);
+    }
+  }
+  __syncthreads();
+  const bool clip = (p.flags & HWY_C_OBS_CLIP) != 0;
+  if (my_ci >= 0 && grid_ws_load(own + my_ci * H + my_cj) == i) {  // I own my cell: write the vehicle layers
+    for (int f = 0; f < F; ++f) {
+      const int fid = p.feat[f];
+      if (fid == HWY_FEAT_ON_ROAD) continue;
+      double val = fid == HWY_FEAT_PRESENCE ? 1.0 : fid == HWY_FEAT_X ? me.x : fid == HWY_FEAT_Y ? me.y
+                 : fid == HWY_FEAT_VX ? me.v * me.ch : fid == HWY_FEAT_VY ? me.v * me.sh : fid == HWY_FEAT_HEADING ? me.h
+                 : fid == HWY_FEAT_COS_H ? me.ch : fid == HWY_FEAT_SIN_H ? me.sh : 0.0;
+      const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+      if (rel) {
+        val -= fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+        const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+        const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+        if (r0 > -__builtin_inf()) val = lmap(val, r0, r1, -1.0, 1.0);
+      }
+      if (clip) val = clipd(val, -1.0, 1.0);
+      out[(f * W + my_ci) * H + my_cj] = (float)val;
+    }
+  }
+  for (int t = i; t < F * WH; t += NT) {  // everything the owners do not write
+    const int f = t / WH, c = t - f * WH;
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
+    else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;  // NaN (empty) -> 0
+  }
+  __syncthreads();
+}
+
 // ---- KinematicObservation (observation.py:234-276, road.py:421-450) + IntersectionEnv reward / termination -----------
 template <typename SH>
-__device__ inline void ix_observe(const IxParams &ip, const SH &sh, int e, const IxVeh &me, bool write_reward) {
+__device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh &me, bool write_reward) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
   const u64 egos = __ballot(present && (me.flags & HWY_F_CONTROLLED));
   if (egos == 0) return;
   const int ia = ctz64(egos);
+  if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, me, present, ia);
   const int V = p.V, F = p.F;
   const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia), eh = wave_bcast(me.h, ia);
   const int elane = wave_bcast_i(me.lane, ia);
@@ -548,7 +629,7 @@ __device__ inline void ix_observe(const IxParams &ip, const SH &sh, int e, const
     const double kk = wave_bcast(key, k);
     pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
   }
-  if (p.obs) {
+  if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
     float *out = p.obs + (size_t)e * (size_t)(V * F);
     const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
     if (present && row >= 0) {

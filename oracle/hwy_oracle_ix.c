@@ -45,7 +45,7 @@
 #define IX_MAX_ROUTE 4
 #define IX_MAX_FEATURES 8
 
-enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H };
+enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_ON_ROAD = 13 };
 enum { ACT_SLOWER = 0, ACT_IDLE = 1, ACT_FASTER = 2 }; /* IntersectionEnv.ACTIONS, intersection_env.py:14 */
 
 typedef struct {
@@ -69,6 +69,8 @@ typedef struct {
   double spawn_probability;
   int32_t access_lane[4]; /* table index of ("o" + k, "ir" + k, 0) */
   int32_t outer_node[4];  /* node id of "o" + k */
+  int32_t obs_type, grid_align, grid_shape[2]; /* obs_type 1: OccupancyGridObservation (observation.py:279-499) */
+  double grid_min[2], grid_step[2];
   ix_lane lanes[IX_MAX_LANES];
 } ix_config;
 
@@ -646,9 +648,11 @@ static double feature_of(const veh_t *v, int fid) {
   }
   return 0;
 }
+static void observe_grid_agent(const road_t *r, int ego_idx, float *obs);
 typedef struct { double key; int idx; } close_t;
 static void observe_agent(const road_t *r, int ego_idx, float *obs) {
   const ix_config *c = r->cfg;
+  if (c->obs_type == 1) { observe_grid_agent(r, ego_idx, obs); return; }
   const veh_t *ego = &r->v[ego_idx];
   int V = c->obs_vehicles, F = c->obs_features;
   close_t *close = (close_t *)malloc(sizeof(close_t) * (size_t)(r->n + 1));
@@ -691,6 +695,77 @@ static void observe_agent(const road_t *r, int ego_idx, float *obs) {
       obs[row * F + f] = (float)val;
     }
   free(close);
+}
+
+/* ---- OccupancyGridObservation.observe (observation.py:354-413) for the controlled vehicle ------------------------ */
+static void grid_pos_to_index(const ix_config *c, const veh_t *ego, double px, double py, int relative, int *ci, int *cj) {
+  if (!relative) { px -= ego->x; py -= ego->y; }
+  if (c->grid_align) { /* [[c, s], [-s, c]] @ position (observation.py:431-435) */
+    double cs = cos(ego->heading), sn = sin(ego->heading);
+    double qx = cs * px + sn * py, qy = -sn * px + cs * py;
+    px = qx; py = qy;
+  }
+  *ci = (int)floor((px - c->grid_min[0]) / c->grid_step[0]);
+  *cj = (int)floor((py - c->grid_min[1]) / c->grid_step[1]);
+}
+static const double *grid_range(const ix_config *c, int fid) {
+  const double *rg = fid == FEAT_X ? c->obs_range_x : fid == FEAT_Y ? c->obs_range_y
+                   : fid == FEAT_VX ? c->obs_range_vx : fid == FEAT_VY ? c->obs_range_vy : NULL;
+  return (rg && isfinite(rg[0])) ? rg : NULL;
+}
+static void observe_grid_agent(const road_t *r, int ego_idx, float *obs) {
+  const ix_config *c = r->cfg;
+  const veh_t *ego = &r->v[ego_idx];
+  int F = c->obs_features, W = c->grid_shape[0], H = c->grid_shape[1];
+  double *grid = (double *)malloc(sizeof(double) * (size_t)F * W * H);
+  for (int k = 0; k < F * W * H; k++) grid[k] = NAN; /* self.grid.fill(np.nan) */
+  for (int layer = 0; layer < F; layer++) {
+    int fid = c->obs_feature_ids[layer];
+    if (fid != FEAT_ON_ROAD) {
+      for (int i = r->n - 1; i >= 0; i--) { /* df[::-1].iterrows(): the lower index wins a contested cell */
+        const veh_t *v = &r->v[i];
+        double x = v->x - ego->x, y = v->y - ego->y; /* to_dict(observer): relative x, y, vx, vy */
+        const double *rx = grid_range(c, FEAT_X), *ry = grid_range(c, FEAT_Y);
+        if (rx) { x = lmap(x, rx[0], rx[1], -1, 1); x = lmap(x, -1, 1, rx[0], rx[1]); }
+        if (ry) { y = lmap(y, ry[0], ry[1], -1, 1); y = lmap(y, -1, 1, ry[0], ry[1]); }
+        int ci, cj;
+        grid_pos_to_index(c, ego, x, y, 1, &ci, &cj);
+        if (0 <= ci && ci < W && 0 <= cj && cj < H) {
+          double val = feature_of(v, fid);
+          if (fid == FEAT_X || fid == FEAT_Y || fid == FEAT_VX || fid == FEAT_VY) val -= feature_of(ego, fid);
+          const double *rg = grid_range(c, fid);
+          if (rg) val = lmap(val, rg[0], rg[1], -1, 1);
+          grid[((size_t)layer * W + ci) * H + cj] = val;
+        }
+      }
+    } else { /* fill_road_layer_by_lanes (observation.py:454-484), every lane of the network in graph order */
+      double spacing = fmin(c->grid_step[0], c->grid_step[1]);
+      for (int k = 0; k < c->n_lanes; k++) {
+        const ix_lane *l = &c->lanes[k];
+        double origin, lat;
+        lane_local(l, ego->x, ego->y, &origin, &lat);
+        double start = origin - 100.0, stop = origin + 100.0;
+        int n = (int)ceil((stop - start) / spacing); /* len(np.arange(start, stop, step)) */
+        for (int j = 0; j < n; j++) {
+          double wp = clipd(start + j * spacing, 0, l->length);
+          double px, py;
+          lane_position(l, wp, 0, &px, &py);
+          int ci, cj;
+          grid_pos_to_index(c, ego, px, py, 0, &ci, &cj);
+          if (0 <= ci && ci < W && 0 <= cj && cj < H) grid[((size_t)layer * W + ci) * H + cj] = 1;
+        }
+      }
+    }
+  }
+  for (int k = 0; k < F * W * H; k++) {
+    double v = grid[k];
+    if (c->obs_clip) v = isnan(v) ? v : clipd(v, -1, 1);
+    obs[k] = isnan(v) ? 0.0f : (float)v; /* np.nan_to_num */
+  }
+  free(grid);
+}
+static size_t ix_obs_len(const ix_config *c) {
+  return c->obs_type == 1 ? (size_t)c->obs_features * c->grid_shape[0] * c->grid_shape[1] : (size_t)c->obs_vehicles * c->obs_features;
 }
 
 /* ---- IntersectionEnv reward / termination (intersection_env.py:60-126, 340-345) ----------------------------- */
@@ -791,7 +866,7 @@ int orc_ix_frames(const ix_config *c, ix_state *st, const int32_t *actions, int3
 
 int orc_ix_observe(const ix_config *c, const ix_state *st, float *obs) {
   veh_t *buf = (veh_t *)malloc(sizeof(veh_t) * (size_t)c->n_slots);
-  size_t per = (size_t)c->obs_vehicles * c->obs_features;
+  size_t per = ix_obs_len(c);
   for (int e = 0; e < c->num_envs; e++) {
     road_t r = {c, buf, 0, st->road_steps[e]};
     r.n = load_env(c, st, e, buf);
@@ -808,7 +883,7 @@ int orc_ix_step(const ix_config *c, ix_state *st, const int32_t *actions, float 
   int rc = orc_ix_frames(c, st, actions, c->frames_per_step);
   if (rc) return rc;
   veh_t *buf = (veh_t *)malloc(sizeof(veh_t) * (size_t)c->n_slots);
-  size_t per = (size_t)c->obs_vehicles * c->obs_features;
+  size_t per = ix_obs_len(c);
   for (int e = 0; e < c->num_envs; e++) {
     road_t r = {c, buf, 0, st->road_steps[e]};
     r.n = load_env(c, st, e, buf);

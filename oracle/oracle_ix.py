@@ -12,7 +12,7 @@ import numpy as np
 from . import oracle as _base
 
 IX_MAX_LANES, IX_MAX_ROUTE, IX_MAX_FEATURES = 32, 4, 8
-FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7}
+FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7, "on_road": 13}
 LANE_F64 = ["sx", "sy", "ex", "ey", "heading", "dirx", "diry", "cx", "cy", "radius", "start_phase", "end_phase",
             "length", "width", "speed_limit"]
 LANE_I32 = ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "id"]
@@ -42,6 +42,8 @@ class IxConfig(C.Structure):
                 + [("reward_speed_range", C.c_double * 2)]
                 + [(k, C.c_double * 2) for k in ["obs_range_x", "obs_range_y", "obs_range_vx", "obs_range_vy"]]
                 + [("spawn_probability", C.c_double), ("access_lane", C.c_int32 * 4), ("outer_node", C.c_int32 * 4),
+                   ("obs_type", C.c_int32), ("grid_align", C.c_int32), ("grid_shape", C.c_int32 * 2),
+                   ("grid_min", C.c_double * 2), ("grid_step", C.c_double * 2),
                    ("lanes", IxLane * IX_MAX_LANES)])
 
 
@@ -81,13 +83,27 @@ def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots
     for k, v in enumerate(ts):
         c.target_speeds[k] = float(v)
     obs = config["observation"]
-    feats = obs["features"]
-    c.obs_vehicles, c.obs_features = int(obs["vehicles_count"]), len(feats)
+    grid = obs["type"] == "OccupancyGrid"
+    if grid:  # OccupancyGridObservation.__init__ defaults (observation.py:286-327, 347-351)
+        feats = obs.get("features") or ["presence", "vx", "vy", "on_road"]
+        gs = np.array(obs.get("grid_size") or [[-27.5, 27.5], [-27.5, 27.5]], np.float64)
+        step = np.array(obs.get("grid_step") or [5, 5], np.float64)
+        shape = np.asarray(np.floor((gs[:, 1] - gs[:, 0]) / step), dtype=np.intp)
+        c.obs_type, c.grid_align = 1, int(obs.get("align_to_vehicle_axes", False))
+        c.grid_shape[0], c.grid_shape[1] = int(shape[0]), int(shape[1])
+        c.grid_min[0], c.grid_min[1] = float(gs[0, 0]), float(gs[1, 0])
+        c.grid_step[0], c.grid_step[1] = float(step[0]), float(step[1])
+        c.obs_vehicles = 1
+        fr = obs.get("features_range") or {"vx": [-80.0, 80.0], "vy": [-80.0, 80.0]}
+    else:
+        feats = obs["features"]
+        c.obs_vehicles = int(obs["vehicles_count"])
+        fr = obs["features_range"]
+    c.obs_features = len(feats)
     for k, name in enumerate(feats):
         c.obs_feature_ids[k] = FEATURE_IDS[name]
     c.obs_absolute, c.obs_normalize = int(obs.get("absolute", False)), int(obs.get("normalize", True))
     c.obs_clip, c.obs_see_behind = int(obs.get("clip", True)), int(obs.get("see_behind", False))
-    fr = obs["features_range"]
     inf = float("inf")
     for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
         field[0], field[1] = (float(fr[name][0]), float(fr[name][1])) if name in fr else (-inf, inf)
@@ -134,8 +150,12 @@ def frames(cfg: IxConfig, st: dict, actions, n_frames: int) -> None:
     assert rc == 0, rc
 
 
+def obs_shape(cfg: IxConfig) -> tuple:
+    return (cfg.obs_features, cfg.grid_shape[0], cfg.grid_shape[1]) if cfg.obs_type == 1 else (cfg.obs_vehicles, cfg.obs_features)
+
+
 def observe(cfg: IxConfig, st: dict) -> np.ndarray:
-    obs = np.zeros((cfg.num_envs, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    obs = np.zeros((cfg.num_envs, *obs_shape(cfg)), np.float32)
     s = _struct(st)
     rc = _lib().orc_ix_observe(C.byref(cfg), C.byref(s), obs.ctypes.data_as(C.POINTER(C.c_float)))
     assert rc == 0, rc
@@ -146,7 +166,7 @@ def step(cfg: IxConfig, st: dict, actions) -> tuple:
     """AbstractEnv.step up to (not including) IntersectionEnv.step's clear / spawn."""
     E = cfg.num_envs
     acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E))
-    obs = np.zeros((E, cfg.obs_vehicles, cfg.obs_features), np.float32)
+    obs = np.zeros((E, *obs_shape(cfg)), np.float32)
     reward, speed = np.zeros(E), np.zeros(E)
     term, trunc, crashed = np.zeros(E, np.uint8), np.zeros(E, np.uint8), np.zeros(E, np.uint8)
     s = _struct(st)

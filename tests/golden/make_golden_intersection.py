@@ -151,6 +151,15 @@ SCENARIOS = [
     # denser traffic, longer episodes (more yielding and more crashes to follow)
     dict(name="intersection_dense", config={"initial_vehicle_count": 14, "spawn_probability": 0.9, "duration": 20},
          seeds=[11, 12, 13, 14], steps=18, action_seed=42, frames_for=2, n_slots=32),
+    # BASELINE config 4's observation: OccupancyGrid with its defaults (presence, vx, vy, on_road; 11 x 11 cells of 5 m)
+    dict(name="intersection_grid", config={"observation": {"type": "OccupancyGrid"}}, seeds=[21, 22, 23], steps=12,
+         action_seed=43, frames_for=0, n_slots=24),
+    # vehicle-aligned grid with position / heading layers and an x / y range (the normalise -> denormalise round trip)
+    dict(name="intersection_grid_aligned",
+         config={"observation": {"type": "OccupancyGrid", "align_to_vehicle_axes": True, "grid_size": [[-32, 32], [-16, 16]],
+                                 "grid_step": [4, 4], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
+                                 "features_range": {"x": [-40, 40], "y": [-40, 40], "vx": [-20, 20], "vy": [-20, 20]}}},
+         seeds=[31, 32], steps=12, action_seed=44, frames_for=0, n_slots=24),
 ]
 
 
@@ -243,7 +252,7 @@ def main() -> None:
         print(f"{sc['name']}: E,N,T,steps,frames_for,A,R={data['meta'].tolist()} "
               f"vehicles/env at reset={data['init_present'].sum(axis=1).tolist()} "
               f"max vehicles={int(data['next_present'].sum(axis=2).max())} "
-              f"yielding frames={int(data['frame_is_yielding'].sum())} "
+              f"yielding frames={int(data['frame_is_yielding'].sum()) if 'frame_is_yielding' in data else -1} "
               f"terminated={data['terminated'].any(axis=0).astype(int).tolist()} "
               f"crashed_total={int(data['step_crashed'][-1].sum())} -> {os.path.getsize(path) / 1024:.0f} KiB")
 

@@ -241,6 +241,27 @@ def test_intersection_config_errors():
     with pytest.raises(NotImplementedError):
         EmuBatchedIntersection({"destination": None}, num_envs=1)
     with pytest.raises(NotImplementedError):
-        EmuBatchedIntersection({"observation": {"type": "OccupancyGrid"}}, num_envs=1)
+        EmuBatchedIntersection({"observation": {"type": "OccupancyGrid", "features": ["presence", "lat_off"]}}, num_envs=1)
+    assert EmuBatchedIntersection({"observation": {"type": "OccupancyGrid"}}, num_envs=1).single_observation_shape == (4, 11, 11)
     env = EmuBatchedIntersection(num_envs=2)
     assert env.single_action_space.n == 3 and env.single_observation_shape == (15, 7)
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+def test_intersection_env_with_occupancy_grid_matches_reference(real):
+    """BASELINE config 4: IntersectionEnv({"observation": {"type": "OccupancyGrid"}}) -- reset(seed=s) and the first
+    steps give the reference's 4 x 11 x 11 grids (presence, vx, vy, on_road over straight and circular lanes)."""
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection("intersection_grid")
+    cls = envs.IntersectionEnv if real else EmuIntersection
+    env = cls({"observation": {"type": "OccupancyGrid"}})
+    e = 1
+    obs, info = env.reset(seed=int(g.z["seeds"][e]))
+    assert obs.shape == (4, 11, 11) and obs.dtype == np.float32
+    np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)
+    assert obs[3].sum() > 10  # the on-road layer is painted
+    for t in range(4):
+        obs, r, te, tr, info = env.step(int(g.actions[t, e, 0]))
+        np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=f"step {t}")
+        assert abs(r - g.z["reward"][t, e]) < 1e-9
+    env.close()

@@ -11,7 +11,8 @@ import pytest
 
 from highwayenv_amd import _abi
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import (INTERSECTION, GoldenIntersection, assert_ix_engine_state_close, ix_engine_state)
+from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, GoldenIntersection, assert_ix_engine_state_close,
+                               ix_engine_state)
 
 
 def _hwy_config(g, E, host_traffic=True):
@@ -67,10 +68,12 @@ def test_teacher_forced_frames_vs_reference(backend, name):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID)
 def test_policy_steps_vs_reference(backend, name):
     """Whole policy steps from the reference's state at the start of each step (host-traffic mode: the kernel does not
-    clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call."""
+    clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call.
+    The *_grid fixtures carry BASELINE config 4's OccupancyGrid observation (on-road layer over straight lanes of any
+    direction and circular arcs, world- and vehicle-aligned cells)."""
     g = GoldenIntersection(name)
     E, S = g.E, g.steps
     steps0 = g.z["road_steps0"]
