@@ -185,3 +185,76 @@ def test_full_size_merge_autoreset_keeps_every_env_alive():
     st = eng.get_state()
     assert (st["x"][:, 0] <= cfg.merge_end_x + 45.0).all()
     eng.close()
+
+
+# ---- BASELINE config 4 at full size: intersection-v0, 2048 envs x 30 slots, OccupancyGrid, device traffic -------------
+def make_ix(E_, host_traffic=False):
+    from highwayenv_amd import intersection as hix
+    from highwayenv_amd.engine import Engine
+    cfg_d = hix.intersection_default_config()
+    cfg_d.update({"max_vehicles": 30, "observation": {"type": "OccupancyGrid"}, "host_traffic": host_traffic})
+    cfg = _abi.make_config(cfg_d, E_, scenario="intersection")
+    return cfg_d, cfg, Engine(cfg)
+
+
+def test_full_size_intersection_determinism_independence_oracle_and_invariants():
+    from oracle import oracle_ix
+    from tests.golden_util import ix_oracle_config, ix_oracle_state
+    E_ix = 2048
+    cfg_d, cfg, eng = make_ix(E_ix)
+    _, _, eng2 = make_ix(E_ix)
+    base = 31337
+    for e_ in (eng, eng2):
+        e_.reset(seeds=np.uint64(base) + np.arange(E_ix, dtype=np.uint64))
+        e_.set_autoreset(True, base_seed=base)
+    pick = np.sort(np.random.default_rng(6).choice(E_ix, 24, replace=False))
+    cfg_h, sub_cfg, sub = make_ix(len(pick), host_traffic=True)   # dynamics only: compared with the oracle every step
+    oc = ix_oracle_config(cfg_h, sub_cfg, len(pick))
+    rng = np.random.default_rng(7)
+    n_checked = n_reset = 0
+    done_prev = np.zeros(E_ix, bool)
+    for t in range(30):
+        st = eng.get_state()
+        # invariants of the traffic management: compact list, exactly one controlled vehicle, valid lanes / routes
+        pres = (st["flags"] & _abi.F_ABSENT) == 0
+        n = pres.sum(1)
+        assert (pres == (np.arange(30)[None, :] < n[:, None])).all()
+        assert (((st["flags"] & _abi.F_CONTROLLED) != 0) & pres).sum(1).tolist() == [1] * E_ix
+        assert ((st["lane"][pres] >= 0) & (st["lane"][pres] < cfg.gnet_lanes)).all()
+        assert (((st["route"][pres] >> 15) & 3) <= 3).all() and (n >= 1).all() and (n <= 30).all()
+        acts = rng.integers(0, 3, size=(E_ix, 1)).astype(np.int32)
+        # the picked envs, one step from the big batch's own state on a host-traffic engine and on the oracle
+        sub_st = {k: np.ascontiguousarray(v[pick]) for k, v in st.items()}
+        ost = ix_oracle_state(sub_st, sub_cfg)
+        sub.set_state(sub_st)
+        s_obs, s_rew, s_term, s_trunc, s_info = sub.step(acts[pick])
+        o_obs, o_rew, o_term, o_trunc, o_info = oracle_ix.step(oc, ost, acts[pick, 0])
+        wreck = (((sub_st["flags"] & _abi.F_ABSENT) == 0) & ((sub_st["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
+        slow = (((sub_st["flags"] & _abi.F_ABSENT) == 0) & (np.abs(sub_st["speed"]) < 0.5)).any(1)
+        slow |= ((ost["present"] != 0) & (np.abs(ost["speed"]) < 0.5)).any(1)  # ... or came (nearly) to rest in this step
+        ok = ~wreck & ~slow & ~done_prev[pick]
+        np.testing.assert_array_equal(s_term[ok], o_term[ok], err_msg=f"step {t}")
+        np.testing.assert_allclose(s_obs[ok, 0], o_obs[ok], rtol=0, atol=1e-6, err_msg=f"step {t}")
+        np.testing.assert_allclose(s_rew[ok, 0], o_rew[ok], rtol=0, atol=1e-9, err_msg=f"step {t}")
+        got = sub.get_state()
+        np.testing.assert_allclose(got["x"][ok], ost["x"][ok], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(got["speed"][ok], ost["speed"][ok], rtol=0, atol=1e-8)
+        n_checked += int(ok.sum())
+        # the big batch: determinism, batch independence of the dynamics (obs / reward / flags of the picked envs)
+        out1 = eng.step(acts)
+        out2 = eng2.step(acts)
+        for a, b in zip(out1[:4], out2[:4]):
+            np.testing.assert_array_equal(a, b, err_msg=f"determinism, step {t}")
+        obs, reward, term, trunc, info = out1
+        live = ~done_prev[pick]
+        np.testing.assert_array_equal(s_obs[live], obs[pick][live], err_msg=f"batch independence, step {t}")
+        np.testing.assert_array_equal(s_rew[live], reward[pick][live])
+        np.testing.assert_array_equal(s_term[live], term[pick][live])
+        assert obs.shape == (E_ix, 1, 4, 11, 11) and np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()
+        assert np.isfinite(reward).all()
+        assert (reward[done_prev] == 0).all() and not term[done_prev].any()
+        n_reset += int(done_prev.sum())
+        done_prev = term | trunc
+    assert n_checked > 200 and n_reset > E_ix  # duration 13: every env was re-spawned at least once in 30 steps
+    for e_ in (eng, eng2, sub):
+        e_.close()
