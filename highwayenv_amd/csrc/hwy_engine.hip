@@ -187,7 +187,7 @@ static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
   if (is_ix(eng)) {
     hwy::IxParams ip;
     fill_ix(eng, p, ip);
-    return hwy::launch_ix_step(ip, eng->cfg.num_envs, eng->stream);
+    return hwy::launch_ix_step(ip, eng->cfg.num_envs, eng->stream, eng->waves_per_eu);
   }
   if (is_net(eng)) {
     hwy::NetParams np;
@@ -246,7 +246,10 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
   if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
   // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
-  if (cfg->scenario != HWY_SCENARIO_HIGHWAY && cfg->scenario != HWY_SCENARIO_INTERSECTION) eng->waves_per_eu = 4;
+  // intersection kernel: 172 VGPRs fit 2 waves/SIMD; a 3rd (10 spilled registers) pays once the batch exceeds the 2048 wave
+  // slots of the 2-wave build (measured: +9..13 % at 4096 / 8192 environments, -3 % at 2048)
+  if (cfg->scenario == HWY_SCENARIO_INTERSECTION) eng->waves_per_eu = cfg->num_envs > 2048 ? 3 : 2;
+  else if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
   if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
     const int v = std::atoi(w);
     if (v >= 1 && v <= 4) eng->waves_per_eu = v;

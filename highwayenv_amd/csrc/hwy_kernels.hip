@@ -76,9 +76,17 @@ hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t str
   hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
   return hipGetLastError();
 }
-hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream) {
-  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+template <int WPE>
+static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t stream) {
+  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+}
+hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
+  switch (waves_per_eu) {
+    case 3: launch_ix_step_wpe<3>(ip, num_envs, stream); break;
+    case 4: launch_ix_step_wpe<4>(ip, num_envs, stream); break;
+    default: launch_ix_step_wpe<2>(ip, num_envs, stream); break;
+  }
   return hipGetLastError();
 }
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream) {

@@ -16,7 +16,7 @@ hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream
 hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream);
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream);
 // intersection scenario (hwy_ix.h): one wavefront per environment
-hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream);
+hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu);
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream);
 hipError_t launch_ix_observe(const IxParams &ip, int num_envs, hipStream_t stream);
 }  // namespace hwy
