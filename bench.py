@@ -83,10 +83,39 @@ def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: 
         t_used += time.perf_counter() - t0
         steps_done += 1
     rate = steps_done * E / t_used
-    return {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{E} envs x {steps_done} policy steps of the same workload on 1 host core "
-                      f"(oracle/hwy_oracle{'' if scenario == 'highway' else '_net'}.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
-            "vehicle_steps_per_s": rate * cfg.num_vehicles}
+    out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{E} envs x {steps_done} policy steps of the same workload on 1 host core "
+                     f"(oracle/hwy_oracle{'' if scenario == 'highway' else '_net'}.c, {t_used:.1f} s; host has {os.cpu_count()} cores)",
+           "vehicle_steps_per_s": rate * cfg.num_vehicles}
+    # the same port on many host cores at once ("one env batch per core"): independent batches, one Python
+    # thread each (ctypes releases the GIL inside the C call)
+    import threading
+    n_thr = min(64, os.cpu_count() or 1)
+    if n_thr > 1:
+        counts = [0] * n_thr
+        stop_at = time.perf_counter() + 5.0
+
+        def worker(k):
+            st_k = _abi.copy_state(st0)
+            rng_k = np.random.default_rng(100 + k)
+            n = 0
+            while time.perf_counter() < stop_at:
+                if n % episode_len == 0:
+                    st_k = _abi.copy_state(st0)
+                oracle.step(cfg, st_k, rng_k.integers(0, 5, size=(E, cfg.num_agents)).astype(np.int32))
+                n += 1
+            counts[k] = n
+
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_thr)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        dt_all = time.perf_counter() - t0
+        out["all_threads"] = {"value": sum(counts) * E / dt_all, "unit": "env-steps/s", "cores": n_thr,
+                              "sample": f"{n_thr} threads x {E} envs, {dt_all:.1f} s"}
+    return out
 
 
 def cpu_baseline_intersection(cfg_dict, budget_s: float = 12.0):
