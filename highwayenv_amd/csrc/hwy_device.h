@@ -1128,6 +1128,10 @@ __device__ inline double math_probe(int op, double x) {
     case 4: return asin_bounded(x);
     case 5: return fast_rcp(x);
     case 6: return fast_rsqrt(x);
+    case 8: return atan_fd(x);
+    case 9: return atan2_bounded(x, 0.75);
+    case 10: return atan2_bounded(0.5, x);
+    case 11: return atan2_bounded(-0.5, x);
     default: return wrap_to_pi(x);
   }
 }

@@ -91,7 +91,7 @@ __device__ inline void ix_local(const SH &sh, int L, double x, double y, double 
     *lat = dx * -sh.diry[L] + dy * sh.dirx[L];
   } else {
     const double dx = x - sh.cx[L], dy = y - sh.cy[L];
-    double phi = atan2(dy, dx);
+    double phi = atan2_bounded(dy, dx);
     phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
     const double r = sqrt(dx * dx + dy * dy);
     *s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
@@ -113,8 +113,10 @@ __device__ inline void ix_position(const SH &sh, int L, double s, double *px, do
     *py = sh.sy[L] + s * sh.diry[L] + 0.0 * sh.dirx[L];
   } else {
     const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
-    *px = sh.cx[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * cos(phi);
-    *py = sh.cy[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * sin(phi);
+    double sn, cs;
+    sincos_bounded(phi, &sn, &cs);
+    *px = sh.cx[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * cs;
+    *py = sh.cy[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * sn;
   }
 }
 
@@ -166,7 +168,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
       sh.sl[L][i] = 0.0;
       continue;
     }
-    double phi = atan2(dy, dx);
+    double phi = atan2_bounded(dy, dx);
     phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
     const double s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
     const double lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
@@ -239,7 +241,9 @@ __device__ inline void ix_along_route(const SH &sh, const IxVeh &me, double lon,
 // rect 2 with the reference's +angle rotation (utils.py:79-95)
 __device__ inline bool ix_corner_inside(double c1x, double c1y, double a1, double c2x, double c2y, double a2) {
   const double hl = 1.5 * HWY_VEH_LENGTH / 2, hw = 0.9 * HWY_VEH_WIDTH / 2;
-  const double c = cos(a1), s = sin(a1), c2 = cos(a2), s2 = sin(a2);
+  double c, s, c2, s2;
+  sincos_bounded(a1, &s, &c);
+  sincos_bounded(a2, &s2, &c2);
   bool any = false;
   for (int k = 0; k < 9; ++k) {
     const double qx = (k == 0 || k == 1 || k == 5) ? -hl : ((k == 2 || k == 3 || k == 6) ? hl : (k == 7 ? -0.0 : 0.0));
@@ -641,7 +645,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
                    : fid == HWY_FEAT_COS_H ? ch : fid == HWY_FEAT_SIN_H ? shh : 0.0;
         const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
         if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
-          const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * cos(eh) : ev * sin(eh);
+          const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * wave_bcast(me.ch, ia) : ev * wave_bcast(me.sh, ia);
           val -= origin;
         }
         if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {

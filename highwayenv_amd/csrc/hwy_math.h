@@ -158,4 +158,38 @@ __device__ inline double asin_bounded(double x) {
   return x < 0 ? -r : r;
 }
 
+// ---- atan(x), any finite x: fdlibm s_atan.c (argument reduction to |t| < 7/16 around 0.5, 1, 1.5, inf; the four
+//      branches evaluated as selects so that a wave pays one polynomial, not four) ------------------------------
+__device__ inline double atan_fd(double x) {
+  const double ax = fabs(x);
+  // id: -1 (|x| < 7/16), 0 (< 11/16), 1 (< 19/16), 2 (< 39/16), 3 (>= 39/16)
+  const bool r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+  const double num = r0 ? ax : r1 ? 2.0 * ax - 1.0 : r2 ? ax - 1.0 : r3 ? ax - 1.5 : -1.0;
+  const double den = r0 ? 1.0 : r1 ? 2.0 + ax : r2 ? ax + 1.0 : r3 ? 1.0 + 1.5 * ax : ax;
+  const double t = r0 ? ax : num * fast_rcp(den);
+  const double hi = r0 ? 0.0 : r1 ? 4.63647609000806093515e-01 : r2 ? 7.85398163397448278999e-01
+                  : r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00;
+  const double lo = r0 ? 0.0 : r1 ? 2.26987774529616870924e-17 : r2 ? 3.06161699786838301793e-17
+                  : r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
+  const double z = t * t, w = z * z;
+  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
+                                                 6.66107313738753120669e-02), 9.09088713343650656196e-02),
+                                  1.42857142725034663711e-01), 3.33333333333329318027e-01);
+  const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
+                                          -7.69187620504482999495e-02), -1.11111104054623557880e-01),
+                            -1.99999999998764832476e-01);
+  const double r = r0 ? t - t * (s1 + s2) : hi - ((t * (s1 + s2) - lo) - t);
+  return x < 0 ? -r : r;
+}
+// ---- atan2(y, x) for finite arguments of moderate ratio (positions a few hundred metres apart): fdlibm e_atan2.c
+//      without the inf / nan / huge-ratio cases (|y/x| beyond 2^60 cannot happen for this code's inputs unless x == 0,
+//      which is handled) --------------------------------------------------------------------------------------------------
+__device__ inline double atan2_bounded(double y, double x) {
+  const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+  if (x == 0.0) return y == 0.0 ? (y) : (y > 0 ? pi / 2 : -pi / 2);
+  const double z = atan_fd(fabs(y * fast_rcp(x)));
+  if (x > 0) return y < 0 ? -z : z;
+  return y < 0 ? (z - pi_lo) - pi : pi - (z - pi_lo);
+}
+
 }  // namespace hwy

@@ -325,7 +325,8 @@ int hwy_sync(hwy_engine *eng); /* hipStreamSynchronize on the engine stream */
 /*
  * Self-test hook: evaluate one of the step kernel's own math routines (csrc/hwy_math.h -- bounded-domain
  * log / exp / sincos / asin, Newton-refined v_rcp_f64 / v_rsq_f64, floor-mod angle wrap) on n doubles on
- * the device.  Host pointers.  op: 0 log_pos, 1 exp_bounded, 2 sin, 3 cos, 4 asin_bounded, 5 fast_rcp,
+ * the device.  Host pointers.  op: 0 log_pos, 1 exp_bounded, 2 sin, 3 cos, 4 asin_bounded, 5 fast_rcp, 8 atan_fd,
+ * 9 atan2_bounded(x, 0.75), 10 atan2_bounded(0.5, x), 11 atan2_bounded(-0.5, x),
  * 6 fast_rsqrt, 7 wrap_to_pi.  Lets the accuracy claims (<= 2 ulp on the stated domains) be checked on the GPU.
  */
 int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n);

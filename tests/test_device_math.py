@@ -63,3 +63,18 @@ def test_asin_rcp_rsqrt_wrap(eng):
     assert np.abs(eng.debug_math(WRAP, a) - ref).max() < 4e-12  # |a| up to 1e4: one ulp of a + pi
     inside = np.abs(a) < 3
     assert (eng.debug_math(WRAP, a[inside]) == ref[inside]).all()  # no reduction needed: bit-identical
+
+
+def test_atan_atan2(eng):
+    """fdlibm-style atan / atan2 of the intersection kernel (CircularLane.local_coordinates, lane.py:355-362)."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-3, 3, 200000), 10.0 ** rng.uniform(-12, 6, 50000), -(10.0 ** rng.uniform(-12, 6, 50000)),
+                        [0.0, 0.4375, 0.6875, 1.1875, 2.4375, 1.0, -1.0]])
+    u = ulps(eng.debug_math(8, x), np.arctan(x))
+    assert u[x != 0].max() <= 2.0
+    y = np.concatenate([rng.uniform(-40, 40, 200000), 10.0 ** rng.uniform(-9, 3, 20000), [0.0, 0.75, -0.75]])
+    assert np.abs(eng.debug_math(9, y) - np.arctan2(y, 0.75)).max() < 4.5e-16       # |result| < pi/2: < 2 ulp of pi/2
+    assert ulps(eng.debug_math(9, y), np.arctan2(y, 0.75))[y != 0].max() <= 2.5
+    for op, yy in ((10, 0.5), (11, -0.5)):
+        got = eng.debug_math(op, y)
+        assert np.abs(got - np.arctan2(yy, y)).max() < 9e-16                       # |result| <= pi: 2 ulp of pi
