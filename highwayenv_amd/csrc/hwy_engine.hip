@@ -34,6 +34,8 @@ struct hwy_engine {
   int32_t *d_route = nullptr;       // intersection scenario: planned routes [E x pitch]
   int32_t *d_road_steps = nullptr;  // intersection scenario: RegulatedRoad.steps [E]
   hwy_glane *d_gnet = nullptr;      // intersection scenario: lane table
+  double *d_shadow_f64 = nullptr;   // intersection scenario, pre-warming of next episodes: second copy of the planes
+  int32_t *d_shadow_packed = nullptr, *d_shadow_route = nullptr, *d_shadow_meta = nullptr;
   double *d_time = nullptr;
   uint8_t *d_done = nullptr;
   uint32_t *d_episode = nullptr;
@@ -182,6 +184,17 @@ static void fill_ix(const hwy_engine *eng, const StepParams &p, hwy::IxParams &i
   ip.lanes = eng->d_gnet;
   ip.route = eng->d_route;
   ip.road_steps = eng->d_road_steps;
+  if (eng->d_shadow_meta) {
+    hwy::bind_planes(eng->d_shadow_f64, (size_t)eng->cfg.num_envs * eng->pitch, ip.shadow);
+    ip.shadow.packed = eng->d_shadow_packed;
+    ip.shadow_route = eng->d_shadow_route;
+    ip.shadow_meta = eng->d_shadow_meta;
+  }
+}
+// forget every pre-warmed episode (seeds / episode counters / the state they would follow have changed)
+static hipError_t invalidate_shadows(hwy_engine *eng) {
+  if (!eng->d_shadow_meta) return hipSuccess;
+  return hipMemsetAsync(eng->d_shadow_meta, 0xff, (size_t)eng->cfg.num_envs * 4 * sizeof(int32_t), eng->stream);
 }
 static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
   if (is_ix(eng)) {
@@ -280,6 +293,15 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     if ((e = hipMemsetAsync(eng->d_route, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(eng->d_road_steps, 0, E * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemcpy(eng->d_gnet, cfg->gnet, sizeof(hwy_glane) * HWY_MAX_GLANES, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
+    const char *pw = std::getenv("HWY_IX_PREWARM");  // tuning knob: 0 = every auto-reset runs its warm-up inline
+    if (!(cfg->flags & HWY_C_HOST_TRAFFIC) && !(pw && pw[0] == '0')) {
+      ALLOC(eng->d_shadow_f64, plane * 9 * sizeof(double));
+      ALLOC(eng->d_shadow_packed, plane * sizeof(int32_t));
+      ALLOC(eng->d_shadow_route, plane * sizeof(int32_t));
+      ALLOC(eng->d_shadow_meta, E * 4 * sizeof(int32_t));
+      if ((e = hipMemsetAsync(eng->d_shadow_f64, 0, plane * 9 * sizeof(double), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+      if ((e = hipMemsetAsync(eng->d_shadow_meta, 0xff, E * 4 * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+    }
   }
   ALLOC(eng->d_time, E * sizeof(double));
   ALLOC(eng->d_done, E);
@@ -336,7 +358,8 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out,
-                  eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet};
+                  eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet,
+                  eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -647,6 +670,10 @@ extern "C" int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base
   if (!eng) return HWY_ERR_INVALID_ARG;
   if (int rc = set_reset_params(eng, ego_spacing, vehicles_density, initial_lane_id)) return rc;
   eng->autoreset = enabled ? 1 : 0;
+  if (eng->rp.base_seed != base_seed) {  // pre-warmed next episodes were drawn from the old seeds
+    HWY_HIP(eng, hipSetDevice(eng->device));
+    HWY_HIP(eng, invalidate_shadows(eng));
+  }
   eng->rp.base_seed = base_seed;
   return HWY_OK;
 }

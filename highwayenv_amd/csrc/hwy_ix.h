@@ -35,6 +35,12 @@ struct IxParams {
   const hwy_glane *lanes;  // device memory [n_lanes]
   int32_t *route;          // [E][pitch]
   int32_t *road_steps;     // [E]
+  // next-episode pre-warming (auto-reset): a second copy of the vehicle planes and, per environment,
+  // {episode the shadow belongs to, warm-up progress, RegulatedRoad.steps, unused}; nullptr = off
+  int32_t num_envs, prewarm_pad;
+  DevState shadow;
+  int32_t *shadow_route;
+  int32_t *shadow_meta;    // [E][4]
 };
 
 // packed per-vehicle word of this scenario: lane[0:4] | target_lane[5:9] | speed_index[10:12] | flags[13:19]
@@ -269,36 +275,40 @@ __device__ inline int ix_plan_route(const IxParams &ip, const SH &sh, int lane, 
   return route_make(lane, 0, 0, 1);  // no path: route == [lane_index]
 }
 
-__device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o) {
+__device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o, bool from_shadow = false) {
   const StepParams &p = ip.s;
+  const DevState &st = from_shadow ? ip.shadow : ip.s.st;  // (wave-uniform choice)
+  const int32_t *route = from_shadow ? ip.shadow_route : ip.route;
   const int i = threadIdx.x;
   o = IxVeh{};
   o.flags = HWY_F_ABSENT;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
-    o.x = p.st.x[k]; o.y = p.st.y[k]; o.h = p.st.heading[k]; o.v = p.st.speed[k];
-    o.timer = p.st.timer[k]; o.ts = p.st.target_speed[k]; o.delta = p.st.delta[k];
-    const int w = p.st.packed[k];
+    o.x = st.x[k]; o.y = st.y[k]; o.h = st.heading[k]; o.v = st.speed[k];
+    o.timer = st.timer[k]; o.ts = st.target_speed[k]; o.delta = st.delta[k];
+    const int w = st.packed[k];
     o.lane = ix_word_lane(w); o.tgt = ix_word_target(w); o.sidx = ix_word_speed_index(w); o.flags = ix_word_flags(w);
-    o.route = ip.route[k];
+    o.route = route[k];
     if (o.flags & HWY_F_HAS_IMPACT) {
-      o.impx = p.st.impact_x[k];
-      o.impy = p.st.impact_y[k];
+      o.impx = st.impact_x[k];
+      o.impy = st.impact_y[k];
     }
   }
   sincos_bounded(o.h, &o.sh, &o.ch);
 }
-__device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o) {
+__device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o, bool to_shadow = false) {
   const StepParams &p = ip.s;
+  const DevState &st = to_shadow ? ip.shadow : ip.s.st;
+  int32_t *route = to_shadow ? ip.shadow_route : ip.route;
   const int i = threadIdx.x;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
-    p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
-    p.st.timer[k] = o.timer; p.st.target_speed[k] = o.ts; p.st.delta[k] = o.delta;
-    p.st.packed[k] = ix_pack_word(o.lane, o.tgt, o.sidx, o.flags);
-    ip.route[k] = o.route;
-    p.st.impact_x[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impx : 0.0;
-    p.st.impact_y[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impy : 0.0;
+    st.x[k] = o.x; st.y[k] = o.y; st.heading[k] = o.h; st.speed[k] = o.v;
+    st.timer[k] = o.timer; st.target_speed[k] = o.ts; st.delta[k] = o.delta;
+    st.packed[k] = ix_pack_word(o.lane, o.tgt, o.sidx, o.flags);
+    route[k] = o.route;
+    st.impact_x[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impx : 0.0;
+    st.impact_y[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impy : 0.0;
   }
 }
 
@@ -780,15 +790,12 @@ __device__ inline void ix_clear_spawn(const IxParams &ip, SH &sh, IxVeh &me, uin
   ix_spawn(ip, sh, me, 0.0, 1.0, 1.0, ip.spawn_probability, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
 }
 
-// IntersectionEnv._make_vehicles (intersection_env.py:232-290) on Philox draws
+// IntersectionEnv._make_vehicles (intersection_env.py:232-290) on Philox draws, in three parts so that the warm-up can
+// be spread over several launches (next-episode pre-warming): the initial random traffic, the simulated seconds, the rest.
 template <typename SH>
-__device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
-                                    int &road_steps, int &bits) {
-  const StepParams &p = ip.s;
-  const int i = threadIdx.x;
+__device__ inline void ix_spawn_initial(const IxParams &ip, SH &sh, uint64_t seed, uint32_t episode, IxVeh &me) {
   me = IxVeh{};
   me.flags = HWY_F_ABSENT;
-  road_steps = 0;
   const int n = ip.initial_count;
   for (int t = 0; t < n - 1; ++t) {  // np.linspace(0, 80, n_vehicles)[t]
     double u0, u1, u2, u3, u4, u5, u6, u7;
@@ -799,14 +806,20 @@ __device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t 
     const double lon = n > 1 ? 0.0 + t * ((80.0 - 0.0) / (n - 1)) : 0.0;
     ix_spawn(ip, sh, me, lon, 1.0, 1.0, 0.6, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
   }
-  // three simulated seconds without the ego
-  {
-    int unused;
-    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
-    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
-    const int sim_freq = (int)rint(1 / p.dt);
-    ix_frames(ip, sh, e, me, 3 * sim_freq, nullptr, road_steps, bits);
-  }
+}
+// n_frames of the simulated seconds without the ego (the table walk first: bits / s are not part of the stored state)
+template <typename SH>
+__device__ inline void ix_warm(const IxParams &ip, SH &sh, int e, IxVeh &me, int n_frames, int &road_steps) {
+  int bits, unused;
+  __syncthreads();
+  ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
+  bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+  ix_frames(ip, sh, e, me, n_frames, nullptr, road_steps, bits);
+}
+template <typename SH>
+__device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t seed, uint32_t episode, IxVeh &me) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
   {  // challenger: longitudinal 60, always, straight on, position deviation 0.1, speed deviation 0
     double u0, u1, u2, u3, u4, u5, u6, u7;
     philox_uniform2(seed, 500u, episode, 0u, &u0, &u1);
@@ -846,9 +859,51 @@ __device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t 
     me.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
     sincos_bounded(me.h, &me.sh, &me.ch);
   }
-  int unused;
-  ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
-  bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+}
+template <typename SH>
+__device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
+                                    int &road_steps) {
+  ix_spawn_initial(ip, sh, seed, episode, me);
+  road_steps = 0;
+  ix_warm(ip, sh, e, me, 3 * (int)rint(1 / ip.s.dt), road_steps);
+  ix_spawn_finalise(ip, sh, seed, episode, me);
+}
+
+// Pre-warming block of environment e (blockIdx >= num_envs): advances the shadow copy of e's NEXT episode by one chunk of
+// warm-up frames per launch.  The shadow is a pure function of (seed, episode + 1), so WHEN it is computed cannot change
+// any result; an environment that finishes before its shadow is ready falls back to the inline reset.
+template <typename SH>
+__device__ inline void ix_prewarm(const IxParams &ip, SH &sh, int e) {
+  const StepParams &p = ip.s;
+  const int i = threadIdx.x;
+  if (!p.autoreset || p.st.done[e]) return;  // (the step block of e may be consuming the shadow in this launch)
+  const uint32_t target = p.st.episode[e] + 1u;
+  int32_t *m = ip.shadow_meta + 4 * e;
+  const int total = 3 * (int)rint(1 / p.dt);
+  int prog = m[1], rs = m[2];
+  const bool mine = (uint32_t)m[0] == target;
+  if (mine && prog > total) return;  // ready
+  IxVeh me;
+  const uint64_t seed = p.rp.base_seed + (uint64_t)e;
+  if (!mine) {
+    ix_spawn_initial(ip, sh, seed, target, me);
+    prog = 0;
+    rs = 0;
+  } else {
+    ix_load_vehicle(ip, e, me, true);
+  }
+  const int chunk = p.T < total - prog ? p.T : total - prog;
+  if (chunk > 0) {
+    ix_warm(ip, sh, e, me, chunk, rs);
+    prog += chunk;
+  }
+  if (prog >= total) {
+    ix_spawn_finalise(ip, sh, seed, target, me);
+    prog = total + 1;
+  }
+  ix_store_vehicle(ip, e, me, true);
+  __threadfence();
+  if (i == 0) { m[0] = (int32_t)target; m[1] = prog; m[2] = rs; }
 }
 
 // =============================================================================================================
@@ -856,15 +911,40 @@ template <int WPE, int CAP>
 __global__ void __launch_bounds__(CAP, WPE) hwy_ix_step_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
   __shared__ IxSharedT<CAP> sh;
-  const int e = blockIdx.x, i = threadIdx.x;
+  const int i = threadIdx.x;
+  if ((int)blockIdx.x >= ip.num_envs) {  // wave-uniform: the second half of the grid pre-warms next episodes
+    const int ep = (int)blockIdx.x - ip.num_envs;
+    // most of these blocks have nothing to do (shadow ready, or the environment is being reset right now): leave before
+    // touching LDS
+    if (!p.autoreset || p.st.done[ep]) return;
+    const int32_t *m = ip.shadow_meta + 4 * ep;
+    if ((uint32_t)m[0] == p.st.episode[ep] + 1u && m[1] > 3 * (int)rint(1 / p.dt)) return;
+    ix_load_table(ip, sh);
+    ix_prewarm(ip, sh, ep);
+    return;
+  }
   ix_load_table(ip, sh);
+  const int e = blockIdx.x;
   IxVeh me;
   int road_steps, bits;
   if (p.autoreset && p.st.done[e]) {  // the step after terminated | truncated re-spawns the environment
     const uint32_t episode = p.st.episode[e] + 1u;
-    ix_spawn_env(ip, sh, e, p.rp.base_seed + (uint64_t)e, episode, me, road_steps, bits);
+    const int32_t *m = ip.shadow_meta ? ip.shadow_meta + 4 * e : nullptr;
+    if (m && (uint32_t)m[0] == episode && m[1] > 3 * (int)rint(1 / p.dt)) {  // the pre-warmed episode is ready
+      ix_load_vehicle(ip, e, me, true);
+      road_steps = m[2];
+    } else if (m && (uint32_t)m[0] == episode && m[1] >= 0) {  // partly warmed: finish the remaining frames here
+      const int total = 3 * (int)rint(1 / p.dt);
+      ix_load_vehicle(ip, e, me, true);
+      road_steps = m[2];
+      if (total - m[1] > 0) ix_warm(ip, sh, e, me, total - m[1], road_steps);
+      ix_spawn_finalise(ip, sh, p.rp.base_seed + (uint64_t)e, episode, me);
+    } else {
+      ix_spawn_env(ip, sh, e, p.rp.base_seed + (uint64_t)e, episode, me, road_steps);
+    }
     ix_observe(ip, sh, e, me, false);
     ix_store_vehicle(ip, e, me);
+    __threadfence();  // the shadow has been read before `done` is cleared (ix_prewarm starts over once it sees that)
     if (i == 0) {
       p.reward[e] = 0.0;
       if (p.info_speed) p.info_speed[e] = sh.lim[ip.access_lane[0]];
@@ -905,9 +985,9 @@ __global__ void __launch_bounds__(CAP, WPE) hwy_ix_reset_kernel(const IxParams i
   ix_load_table(ip, sh);
   if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
   IxVeh me;
-  int road_steps, bits;
+  int road_steps;
   const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
-  ix_spawn_env(ip, sh, e, seed, 0u, me, road_steps, bits);
+  ix_spawn_env(ip, sh, e, seed, 0u, me, road_steps);
   ix_observe(ip, sh, e, me, false);
   ix_store_vehicle(ip, e, me);
   if (i == 0) {
@@ -915,6 +995,7 @@ __global__ void __launch_bounds__(CAP, WPE) hwy_ix_reset_kernel(const IxParams i
     p.st.done[e] = 0;
     p.st.episode[e] = 0;
     ip.road_steps[e] = road_steps;
+    if (ip.shadow_meta) ip.shadow_meta[4 * e] = -1;  // whatever was pre-warmed belonged to another seed / episode
   }
 }
 

@@ -53,6 +53,7 @@ inline void ix_params_from_config(const hwy_config &c, const StepParams &p, IP &
   std::memset(&ip, 0, sizeof ip);
   ip.s = p;
   ip.n_lanes = c.gnet_lanes;
+  ip.num_envs = c.num_envs;
   ip.initial_count = c.initial_vehicle_count;
   ip.host_spawn = (c.flags & HWY_C_HOST_TRAFFIC) ? 1 : 0;
   ip.destination = c.destination;

@@ -60,6 +60,16 @@ class EmuEngine:
         self.done = np.zeros(self.E, np.uint8)
         self.episode = np.zeros(self.E, np.uint32)
         self.autoreset = (0, 0, 2.0, 1.0, -1)
+        if self.ix:  # next-episode pre-warming buffers (hwy_engine.hip allocates the same on the device)
+            self.shadow = (np.zeros((9, self.E, self.N)), np.zeros((self.E, self.N), np.int32),
+                           np.zeros((self.E, self.N), np.int32), np.full((self.E, 4), -1, np.int32))
+
+    def _bind_shadow(self):
+        if self.ix:
+            f, pk, rt, meta = self.shadow
+            lib().emu_set_shadow(_p(f, C.c_double), _p(pk, C.c_int32), _p(rt, C.c_int32), _p(meta, C.c_int32))
+        else:
+            lib().emu_set_shadow(None, None, None, None)
 
     def close(self):
         pass
@@ -72,6 +82,8 @@ class EmuEngine:
         return _abi.copy_state(self.st)
 
     def set_autoreset(self, enabled, base_seed=0, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1):
+        if self.ix and int(base_seed) != self.autoreset[1]:
+            self.shadow[3][...] = -1
         self.autoreset = (int(enabled), int(base_seed), float(ego_spacing), float(vehicles_density), int(initial_lane_id))
 
     def _run(self, mode, n_frames, actions):
@@ -85,6 +97,7 @@ class EmuEngine:
         crashed = np.zeros((E, A), np.uint8)
         s = _abi.state_struct(self.st)
         ar = self.autoreset
+        self._bind_shadow()
         rc = lib().emu_run(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
                            C.c_int(mode), C.c_int(n_frames), _p(acts, C.c_int32), _p(obs, C.c_float),
                            _p(reward, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(speed, C.c_double),
@@ -117,6 +130,7 @@ class EmuEngine:
         sd = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         s = _abi.state_struct(self.st)
+        self._bind_shadow()
         rc = lib().emu_reset(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
                              _p(mk, C.c_uint8), _p(sd, C.c_uint64), C.c_uint64(base_seed), C.c_double(ego_spacing),
                              C.c_double(vehicles_density), C.c_int(initial_lane_id), _p(obs, C.c_float))

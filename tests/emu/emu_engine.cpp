@@ -68,6 +68,9 @@ enum Which { STEP, RESET, OBSERVE };
 bool g_force_block = false;
 const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road-network scenarios need the lane table)
 hwy_state *g_st = nullptr;          // host state of the call (intersection scenario: route / road_steps planes)
+// intersection scenario, next-episode pre-warming: shadow planes owned by the Python side (emu_set_shadow)
+double *g_shadow_f64 = nullptr;
+int32_t *g_shadow_packed = nullptr, *g_shadow_route = nullptr, *g_shadow_meta = nullptr;
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
   if (g_cfg && g_cfg->scenario == HWY_SCENARIO_INTERSECTION) {
@@ -76,15 +79,23 @@ void dispatch(Which which, const StepParams &p, int E) {
     ip.lanes = g_cfg->gnet;
     ip.route = g_st->route;  // pitch == N in the emulation
     ip.road_steps = g_st->road_steps;
+    int grid = E;
+    if (g_shadow_meta && !(g_cfg->flags & HWY_C_HOST_TRAFFIC)) {
+      hwy::bind_planes(g_shadow_f64, (size_t)E * p.N, ip.shadow);
+      ip.shadow.packed = g_shadow_packed;
+      ip.shadow_route = g_shadow_route;
+      ip.shadow_meta = g_shadow_meta;
+      if (which == STEP && p.autoreset && p.full_step) grid = 2 * E;
+    }
     if (p.N <= 32) {  // same dispatch rule as hwy_kernels.hip
       switch (which) {
-        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32>(q); }, E, 32, ip); break;
+        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32>(q); }, grid, 32, ip); break;
         case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 32>(q); }, E, 32, ip); break;
         case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1, 32>(q); }, E, 32, ip); break;
       }
     } else {
       switch (which) {
-        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 64>(q); }, E, 64, ip); break;
+        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 64>(q); }, grid, 64, ip); break;
         case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 64>(q); }, E, 64, ip); break;
         case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1, 64>(q); }, E, 64, ip); break;
       }
@@ -199,6 +210,10 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
 }
 
 void emu_force_block_kernel(int on) { g_force_block = on != 0; }
+
+void emu_set_shadow(double *f64, int32_t *packed, int32_t *route, int32_t *meta) {
+  g_shadow_f64 = f64; g_shadow_packed = packed; g_shadow_route = route; g_shadow_meta = meta;
+}
 
 void emu_debug_math(int op, const double *in, double *out, long long n) {
   for (long long k = 0; k < n; ++k) out[k] = hwy::math_probe(op, in[k]);

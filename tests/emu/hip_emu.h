@@ -66,6 +66,7 @@ inline void barrier() {
 #define blockDim (emu::cur->bdim)
 
 inline void __syncthreads() { emu::barrier(); }
+inline void __threadfence() {}  // fibers of one OS thread: program order is memory order
 
 namespace emu {
 inline unsigned long long g_ballot[2][16];
