@@ -774,7 +774,6 @@ __device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double lo
 template <typename SH>
 __device__ inline void ix_clear_spawn(const IxParams &ip, SH &sh, IxVeh &me, uint64_t seed, uint32_t episode,
                                       uint32_t step_no) {
-  const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
   double s = 0.0, lat;
   if (present) ix_local(sh, me.lane, me.x, me.y, &s, &lat);
@@ -786,7 +785,6 @@ __device__ inline void ix_clear_spawn(const IxParams &ip, SH &sh, IxVeh &me, uin
   philox_uniform2(seed, 1000u + step_no, episode, 1u, &u2, &u3);
   philox_uniform2(seed, 1000u + step_no, episode, 2u, &u4, &u5);
   philox_uniform2(seed, 1000u + step_no, episode, 3u, &u6, &u7);
-  (void)i;
   ix_spawn(ip, sh, me, 0.0, 1.0, 1.0, ip.spawn_probability, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
 }
 
