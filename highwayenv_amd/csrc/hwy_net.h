@@ -63,19 +63,9 @@ __device__ inline double net_lat(const NetShared &sh, int L, double s, double y)
   }
   return lat;
 }
-// atan for the lane slope amplitude*pulsation*cos(.) (|t| <= 0.13 on the merge ramps): fdlibm s_atan.c,
-// |x| < 7/16 branch; anything larger goes to the library routine.
-__device__ inline double atan_small(double x) {
-  if (!(fabs(x) < 0.4375)) return atan(x);
-  constexpr double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
-                   aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
-                   aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
-                   aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
-  const double z = x * x, w = z * z;
-  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, aT10, aT8), aT6), aT4), aT2), aT0);
-  const double s2 = w * fma(w, fma(w, fma(w, fma(w, aT9, aT7), aT5), aT3), aT1);
-  return x - x * (s1 + s2);
-}
+// atan for the lane slope amplitude*pulsation*cos(.) (|t| <= 0.13 on the merge ramps): fdlibm s_atan.c through
+// hwy_math.h's atan_fd (all argument ranges, no library call)
+__device__ inline double atan_small(double x) { return atan_fd(x); }
 // heading of lane L at longitudinal s (StraightLane.heading_at == 0; SineLane.heading_at, lane.py:259-265)
 __device__ inline double net_heading_at(const NetShared &sh, int L, double s) {
   const double amp = sh.lamp[L];
