@@ -41,6 +41,16 @@ def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int, obs_floats: int
     return 72 * n_vehicles + (4 * obs_floats + 10) * agents
 
 
+def measured_traffic_other(workload: str, envs_per_gpu: int):
+    """The same for the merge / intersection workloads (profiles/traffic_r01_other.json)."""
+    path = os.path.join(ROOT, "profiles", "traffic_r01_other.json")
+    try:
+        d = json.load(open(path))[workload]
+        return d["traffic_bytes_per_launch_calibrated"] if d["envs"] == envs_per_gpu else None
+    except Exception:
+        return None
+
+
 def measured_traffic(envs_per_gpu: int, fast: bool = True):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
@@ -362,7 +372,8 @@ def main() -> None:
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(E, fast),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(E, fast) if scenario == "highway" else measured_traffic_other(args.workload, E),
                          "kernel": ("hwy_ix_step_kernel  (one 64-wide wavefront per env)" if scenario == "intersection" else
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
