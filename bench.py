@@ -41,6 +41,25 @@ def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int, obs_floats: int
     return 72 * n_vehicles + (4 * obs_floats + 10) * agents
 
 
+def valu_view(envs_per_gpu: int, avg_kernel_s: float):
+    """The compute-side view of the headline kernel (it is VALU-issue bound, not HBM bound: DESIGN.md section 5): f64
+    flops per launch from the committed SQ instruction counts (profiles/r01_pmc_sq.json: add / mul = 1 flop, fma = 2,
+    x 64 lanes x one wave per environment) over the launch duration measured in THIS run, against the 78.6 TFLOP/s
+    f64 vector peak of MI355X, and the measured VALU issue utilisation."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sq.json")
+    try:
+        c = json.load(open(path))["per_wave_per_step"]
+    except Exception:
+        return None
+    flop = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"]) * 64 * envs_per_gpu
+    achieved = flop / avg_kernel_s / 1e12
+    waves_per_simd = min(4.0, envs_per_gpu / 1024.0)
+    return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
+            "valu_instructions_per_env_step": c["SQ_INSTS_VALU"],
+            "valu_issue_utilisation": c["SQ_ACTIVE_INST_VALU"] * waves_per_simd / c["SQ_WAVE_CYCLES"],
+            "source": "profiles/r01_pmc_sq.json (SQ counters of the same kernel and config)"}
+
+
 def measured_traffic_other(workload: str, envs_per_gpu: int):
     """The same for the merge / intersection workloads (profiles/traffic_r01_other.json)."""
     path = os.path.join(ROOT, "profiles", "traffic_r01_other.json")
@@ -378,7 +397,8 @@ def main() -> None:
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
-                         "algorithmic_bytes_per_launch": b_env * E},
+                         "algorithmic_bytes_per_launch": b_env * E,
+                         "valu": valu_view(E, avg_kernel_s) if fast else None},
             "terminated_in_last_step": int(term),
             "host_path_env_steps_per_s": host_rate,
         }
