@@ -20,19 +20,37 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, E, q):
+def _config(kind, E):
+    """The three output shapes the engine produces: [E,1,5,5] (highway-fast), [E,4,5,5] (merge, 4 agents), [E,1,4,11,11]
+    (intersection with the OccupancyGrid observation)."""
+    if kind == "merge_ma4":
+        from highwayenv_amd import merge
+        c = merge.merge_generic_default_config()
+        c.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+                  "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+                  "observation": {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}})
+        return _abi.make_config(c, E, scenario="merge-generic")
+    if kind == "intersection_grid":
+        from highwayenv_amd import intersection
+        c = intersection.intersection_default_config()
+        c.update({"observation": {"type": "OccupancyGrid"}})
+        return _abi.make_config(c, E, scenario="intersection")
+    return _abi.make_config(_abi.highway_fast_default_config(), E, fast=True)
+
+
+def _worker(rank, world, port, E, q, kind="fast"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = _abi.make_config(_abi.highway_fast_default_config(), E, fast=True)
+        cfg = _config(kind, E)
         out = PackedStepOutputs(cfg, "cpu", world, rank)
         v = out.views()
         env_ids = torch.tensor(list(shard_range(E * world, world, rank)))
         # fake "engine outputs": every field encodes the global env id
         v["reward"][:, 0] = env_ids.double() + 0.25
         v["info_speed"][:, 0] = env_ids.double() * 2
-        v["obs"][:] = env_ids.float().view(-1, 1, 1, 1)
+        v["obs"][:] = env_ids.float().view(-1, *([1] * (v["obs"].dim() - 1)))
         v["terminated"][:] = (env_ids % 2).to(torch.uint8)
         v["truncated"][:] = (env_ids % 3 == 0).to(torch.uint8)
         v["info_crashed"][:, 0] = (env_ids % 5 == 0).to(torch.uint8)
@@ -51,11 +69,11 @@ def _worker(rank, world, port, E, q):
             ids = torch.arange(E * world)
             ok &= bool((got["reward"][:, 0] == ids.double() + 0.25).all())
             ok &= bool((got["info_speed"][:, 0] == ids.double() * 2).all())
-            ok &= bool((got["obs"][:, 0, 2, 3] == ids.float()).all())
+            ok &= bool((got["obs"].reshape(E * world, -1)[:, -1] == ids.float()).all())
             ok &= bool((got["terminated"] == (ids % 2).to(torch.uint8)).all())
             ok &= bool((got["truncated"] == (ids % 3 == 0).to(torch.uint8)).all())
             ok &= bool((got["info_crashed"][:, 0] == (ids % 5 == 0).to(torch.uint8)).all())
-            ok &= got["obs"].shape == (E * world, 1, 5, 5)
+            ok &= got["obs"].shape == (E * world, cfg.num_agents, *_abi.obs_shape(cfg))
         else:
             ok &= got is None
         q.put((rank, ok))
@@ -69,12 +87,13 @@ def test_shard_range_partitions_everything():
         assert ids == list(range(total))
 
 
-def test_packed_gather_world2_gloo():
+@pytest.mark.parametrize("kind", ["fast", "merge_ma4", "intersection_grid"])
+def test_packed_gather_world2_gloo(kind):
     world, E = 2, 6
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, E, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, E, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))
