@@ -806,9 +806,11 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
         if (!(i_check || ((chk >> q) & 1))) continue;  // objects.py:98
         const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
                             q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
+        // provable separation on MY two body axes (any axis of either rectangle is one of the SAT's axes, so which
+        // body plays "A" does not matter for a proof of separation); the ordered pair is only built for the SAT
+        if (net_surely_apart(mine, other, p.dt)) continue;
         const bool i_first = i < q;
         const NetBody A = select_nbody(i_first, mine, other), Bb = select_nbody(i_first, other, mine);
-        if (net_surely_apart(A, Bb, p.dt)) continue;
         double tx, ty;
         const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
         if ((r & 2) && q > best && veh) {  // "last pair in loop order wins" == the partner in the highest slot
