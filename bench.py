@@ -217,6 +217,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=16,
+                    help="N > 1: the (obs, reward, done) blocks of this many consecutive steps travel to rank 0 in one RCCL "
+                         "gather (every step's outputs still reach rank 0 inside the timed region); 1 = one gather per step")
     ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge", "intersection", "intersection_kin"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
                          "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024); "
@@ -291,23 +294,30 @@ def main() -> None:
     g.manual_seed(1234 + rank)
     n_actions = 3 if scenario == "intersection" else 5
     actions = torch.randint(0, n_actions, (total, E, A), generator=g, device=dev, dtype=torch.int32)
-    # two alternating output blocks: the RCCL gather of step t (async, on RCCL's stream) overlaps the step kernel of
-    # step t+1, which writes into the other block
-    outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist) for _ in range(2)]
+    # two alternating output buffers of K step blocks each: the RCCL gather of one buffer (async, on RCCL's stream)
+    # overlaps the step kernels that fill the other one.  K = --gather-every (1 without a collective).
+    K = max(1, args.gather_every) if use_dist else 1
+    outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist, depth=K) for _ in range(2)]
     works = [None, None]
+    pending = [False, False]
     out = outs[0]
 
     def one_step(t: int) -> None:
-        k = t & 1
-        if works[k] is not None:
-            works[k].wait()  # stream-level: block k was gathered, the engine may overwrite it
+        k, slot = (t // K) & 1, t % K
+        if slot == 0 and works[k] is not None:
+            works[k].wait()  # stream-level: buffer k was gathered, the engine may overwrite it
             works[k] = None
-        eng.step_device(actions[t].data_ptr(), *outs[k].pointers())
-        if use_dist:
+        eng.step_device(actions[t].data_ptr(), *outs[k].pointers(slot))
+        pending[k] = True
+        if use_dist and slot == K - 1:
             works[k] = outs[k].gather_async()
+            pending[k] = False
 
     def drain() -> None:
         for k in (0, 1):
+            if use_dist and pending[k]:  # a partly filled buffer at the end of a region still travels
+                works[k] = outs[k].gather_async()
+                pending[k] = False
             if works[k] is not None:
                 works[k].wait()
                 works[k] = None
@@ -345,7 +355,7 @@ def main() -> None:
         host_rate = 40 * E / (time.perf_counter() - th)
 
     # statistics of the run (sanity: the workload really stepped and reset)
-    term = out.terminated().sum().item()
+    term = outs[((total - 1) // K) & 1].terminated((total - 1) % K).sum().item()
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -387,7 +397,9 @@ def main() -> None:
                                     f"random actions, per-agent Kinematics 5x5 obs, device spawn + auto-reset") if scenario != "highway" else
                                    (f"highway-v0, {E} envs/GPU x {N - A} IDM vehicles (+1 ego, N={N}), 4 lanes, 15 frames/step, full "
                                     "pairwise collisions, random actions, Kinematics 5x5 obs, device spawn + auto-reset"),
-                       "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}"},
+                       "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}",
+                       "gather": (f"one RCCL gather of every rank's (obs, reward, done) blocks to rank 0 per {K} steps"
+                                  if use_dist else "none (single rank)")},
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

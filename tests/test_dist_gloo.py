@@ -62,6 +62,16 @@ def _worker(rank, world, port, E, q, kind="fast"):
             assert len(per_rank) == world and bool((per_rank[1]["reward"][:, 0] == torch.arange(E, 2 * E).double() + 0.25).all())
         else:
             assert per_rank is None
+        # K steps per collective (bench.py --gather-every): slot s of a depth-K buffer carries step s
+        deep = PackedStepOutputs(cfg, "cpu", world, rank, depth=3)
+        for slot in range(3):
+            deep.views(slot=slot)["reward"][:, 0] = env_ids.double() + 100.0 * slot
+        assert len(set(deep.pointers(s)[1] for s in range(3))) == 3 and deep.pointers(1)[1] - deep.pointers(0)[1] == deep.nbytes
+        deep.gather_async().wait()
+        if rank == 0:
+            for slot in range(3):
+                got_r = deep.rank0_views(slot)[1]["reward"][:, 0]
+                assert bool((got_r == torch.arange(E, 2 * E).double() + 100.0 * slot).all())
         acts_global = (torch.arange(E * world, dtype=torch.int32).view(-1, 1) % 5) if rank == 0 else None
         mine = scatter_actions(acts_global, world, rank, E, "cpu")
         ok = bool((mine[:, 0] == (env_ids % 5).int()).all())
