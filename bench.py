@@ -10,8 +10,8 @@ vehicles (+1 ego = 51) per GPU, 4 lanes, DiscreteMetaAction (uniform random acti
 and resident in HBM), Kinematics 5x5 observation, device-side spawn + auto-reset on
 terminated/truncated.  One "step" == one batched policy step of every env == ONE launch of
 hwy_step_kernel (5 simulation frames + observe + reward + done).  Weak scaling: every rank owns
-4096 envs; with N>1 ranks the (obs, reward, terminated, truncated) block of every rank is gathered
-to rank 0 over RCCL each step.
+4096 envs; with N>1 ranks the (obs, reward, terminated, truncated) blocks of every rank are gathered
+to rank 0 over RCCL, --gather-every (16) steps per collective, overlapped with the following steps.
 
 Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs, inputs resident in HBM.
 """
