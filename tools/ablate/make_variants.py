@@ -150,10 +150,23 @@ VARIANTS = {
 }
 
 
+# compiler-flag experiments on the unmodified sources
+FLAG_VARIANTS = {
+    "f_base": [],
+    "f_noslp": ["-fno-slp-vectorize"],
+    "f_nounroll": ["-fno-unroll-loops"],
+    "f_misched": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
+    "f_os": ["-Os"],
+    "f_o2": ["-O2"],
+    "f_sgprfirst": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=true"],
+    "f_licm": ["-mllvm", "-disable-licm-promotion"],
+}
+
+
 def build(name):
     src = {f: open(os.path.join(CSRC, f)).read() for f in FILES}
     try:
-        for f, fn in VARIANTS[name]:
+        for f, fn in VARIANTS.get(name, []):
             src[f] = fn(src[f])
     except Stale as ex:
         return f"[skip] {name}: pattern not found: {ex}"
@@ -163,7 +176,7 @@ def build(name):
         open(os.path.join(d, f), "w").write(text.replace('#include "../../include/hwy_engine.h"',
                                                          f'#include "{ROOT}/include/hwy_engine.h"'))
     lib = os.path.join(OUT, f"libhwy_engine_{name}.so")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + FLAG_VARIANTS.get(name, [])
     r = subprocess.run(["hipcc", *flags, "-shared", "-o", lib, os.path.join(d, "hwy_kernels.hip"),
                         os.path.join(d, "hwy_engine.hip")], capture_output=True, text=True)
     shutil.rmtree(d)
@@ -172,6 +185,7 @@ def build(name):
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(VARIANTS)
+    assert all(n in VARIANTS or n in FLAG_VARIANTS for n in names), "unknown variant"
     os.makedirs(OUT, exist_ok=True)
     with ThreadPoolExecutor(6) as ex:
         for res in ex.map(build, names):
