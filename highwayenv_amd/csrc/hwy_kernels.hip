@@ -85,8 +85,7 @@ static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t str
 }
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
   switch (waves_per_eu) {
-    case 3: launch_ix_step_wpe<3>(ip, num_envs, stream); break;
-    case 4: launch_ix_step_wpe<4>(ip, num_envs, stream); break;
+    case 3: case 4: launch_ix_step_wpe<3>(ip, num_envs, stream); break;  // (158 VGPRs: 3 waves/SIMD is the most that fits)
     default: launch_ix_step_wpe<2>(ip, num_envs, stream); break;
   }
   return hipGetLastError();
