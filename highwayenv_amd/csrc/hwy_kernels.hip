@@ -81,7 +81,7 @@ static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t str
   // with next-episode pre-warming the grid holds a second block per environment (hwy_ix.h: ix_prewarm)
   const int grid = (ip.shadow_meta && ip.s.autoreset && ip.s.full_step) ? 2 * num_envs : num_envs;
   if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 64>), dim3(grid), dim3(64), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(grid), dim3(64), 0, stream, ip);  // 24 KB of LDS: 2 waves/SIMD
 }
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
   switch (waves_per_eu) {
