@@ -118,11 +118,12 @@ def test_device_reset_follows_the_reference_rule(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_device_step_clears_and_spawns_like_the_host_rule(backend):
+@pytest.mark.parametrize("slots", [24, 40])  # 32-thread and 64-thread workgroups (csrc/hwy_ix.h: CAP)
+def test_device_step_clears_and_spawns_like_the_host_rule(backend, slots):
     """Same start, same actions: the device-traffic engine after each step == the host-traffic engine + the host
     rule fed with the kernel's Philox draws (stream 1000 + step number)."""
     E = 8
-    cfg, c = _config(E, max_vehicles=24, spawn_probability=0.9, duration=40)
+    cfg, c = _config(E, max_vehicles=slots, spawn_probability=0.9, duration=40)
     base = 777
     dev = make_engine(backend, c)
     dev.reset(seeds=np.uint64(base) + np.arange(E, dtype=np.uint64))
