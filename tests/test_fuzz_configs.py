@@ -48,3 +48,32 @@ def test_random_configurations_vs_oracle(chunk):
             rollout("hip", cfg, fast, E=8, steps=8, seed=chunk * 100 + k)
         except AssertionError as ex:  # name the configuration in the failure
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
+
+
+def random_merge_config(rng):
+    from highwayenv_amd import merge
+    cfg = merge.merge_generic_default_config()
+    lanes = int(rng.integers(1, 5))
+    n = int(rng.integers(0, 50))
+    agents = int(rng.integers(1, min(4, n + 1) + 1))
+    cfg.update({"lanes_count": lanes, "vehicles_count": n, "controlled_vehicles": agents,
+                "before_merge_length": int(rng.integers(50, 200)), "converge_merge_length": int(rng.integers(40, 120)),
+                "parallel_merge_length": int(rng.integers(40, 120)), "after_merge_length": int(rng.integers(90, 200)),
+                "simulation_frequency": int(rng.choice([5, 15])), "collision_reward": float(rng.uniform(-2, -0.1)),
+                "merging_speed_reward": float(rng.uniform(-1, -0.1)), "lane_change_reward": float(rng.uniform(-0.2, 0))})
+    if agents > 1:
+        cfg["action"] = {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}}
+        cfg["observation"] = {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}
+    return cfg
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))
+def test_random_merge_configurations_vs_oracle(chunk):
+    from tests.test_net_parity import _rollout_vs_oracle
+    rng = np.random.default_rng(7000 + chunk)
+    for k in range(6):
+        cfg = random_merge_config(rng)
+        try:
+            _rollout_vs_oracle("hip", cfg, "merge-generic", E=6, steps=10, seed=chunk * 100 + k + 1)
+        except AssertionError as ex:
+            raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
