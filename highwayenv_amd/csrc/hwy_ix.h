@@ -576,9 +576,15 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, const 
       sh.brho[i] = s;
     }
     __syncthreads();
-    for (int t = i; t < ip.n_lanes * p.g_nwp; t += NT) {
-      const int k = t / p.g_nwp, j = t - k * p.g_nwp;
-      const double wp = clipd((sh.brho[k] - 100.0) + j * p.g_spacing, 0.0, sh.len[k]);
+    // np.arange(origin - 100, origin + 100, spacing) holds ceil(((origin + 100) - (origin - 100)) / spacing) waypoints:
+    // g_nwp or, when the rounded difference exceeds 200, one more -- and on these short lanes that last waypoint is
+    // clipped to the lane's END, which can be a cell of its own, so the count is evaluated per lane like numpy does
+    const int per_lane = p.g_nwp + 1;
+    for (int t = i; t < ip.n_lanes * per_lane; t += NT) {
+      const int k = t / per_lane, j = t - k * per_lane;
+      const double o = sh.brho[k];
+      if (j >= (int)ceil(((o + 100.0) - (o - 100.0)) / p.g_spacing)) continue;
+      const double wp = clipd((o - 100.0) + j * p.g_spacing, 0.0, sh.len[k]);
       double px, py;
       ix_position(sh, k, wp, &px, &py);
       int ci, cj;

@@ -77,3 +77,78 @@ def test_random_merge_configurations_vs_oracle(chunk):
             _rollout_vs_oracle("hip", cfg, "merge-generic", E=6, steps=10, seed=chunk * 100 + k + 1)
         except AssertionError as ex:
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
+
+
+def random_intersection_config(rng):
+    from highwayenv_amd import intersection as hix
+    cfg = hix.intersection_default_config()
+    kind = int(rng.integers(3))
+    if kind == 1:
+        cfg["observation"] = {"type": "OccupancyGrid"}
+    elif kind == 2:
+        cfg["observation"] = {"type": "OccupancyGrid", "align_to_vehicle_axes": bool(rng.integers(2)),
+                              # (cell borders that are whole multiples of the waypoint spacing away from the observer put
+                              #  every waypoint of an axis-aligned lane through the observer ON a border, where the last
+                              #  bit of np.dot decides the cell: the offsets below keep the borders off that lattice)
+                              "grid_size": [[-31.3, 28.7], [-21.3, 18.7]], "grid_step": [float(rng.choice([2.5, 4, 5]))] * 2,
+                              "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
+                              "features_range": {"x": [-50, 50], "y": [-50, 50], "vx": [-20, 20], "vy": [-20, 20]}}
+    else:
+        cfg["observation"] = dict(cfg["observation"], vehicles_count=int(rng.integers(3, 16)), see_behind=bool(rng.integers(2)),
+                                  absolute=bool(rng.integers(2)))
+    cfg.update({"initial_vehicle_count": int(rng.integers(2, 15)), "spawn_probability": float(rng.uniform(0, 1)),
+                "duration": int(rng.integers(5, 20)), "max_vehicles": int(rng.choice([20, 28, 32, 40])),
+                "destination": f"o{int(rng.integers(0, 4))}", "normalize_reward": bool(rng.integers(2)),
+                "offroad_terminal": bool(rng.integers(2)), "collision_reward": float(rng.uniform(-6, -1)),
+                "arrived_reward": float(rng.uniform(0.5, 2))})
+    return cfg
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))
+def test_random_intersection_configurations_vs_oracle(chunk):
+    """Device-traffic engine drives the episodes (reset, clear, spawn, auto-reset on Philox); every step is replayed from
+    its own state on a host-traffic engine and on the oracle and compared (wreck-free, no vehicle near standstill)."""
+    from highwayenv_amd.engine import Engine
+    from oracle import oracle_ix
+    from tests.golden_util import ix_oracle_config, ix_oracle_state
+    rng = np.random.default_rng(5000 + chunk)
+    for k in range(4):
+        cfg = random_intersection_config(rng)
+        E = 12
+        try:
+            c = _abi.make_config(dict(cfg, host_traffic=False), E, scenario="intersection")
+            ch = _abi.make_config(dict(cfg, host_traffic=True), E, scenario="intersection")
+            dev, host = Engine(c), Engine(ch)
+            oc = ix_oracle_config(dict(cfg, host_traffic=True), ch, E)
+            dev.reset(base_seed=chunk * 1000 + k)
+            dev.set_autoreset(True, base_seed=chunk * 1000 + k)
+            checked = 0
+            done_prev = np.zeros(E, bool)
+            for t in range(10):
+                st = dev.get_state()
+                acts = rng.integers(0, 3, size=(E, 1)).astype(np.int32)
+                ost = ix_oracle_state(st, ch)
+                host.set_state(st)
+                h_obs, h_rew, h_term, h_trunc, _ = host.step(acts)
+                o_obs, o_rew, o_term, o_trunc, _ = oracle_ix.step(oc, ost, acts[:, 0])
+                pres = (st["flags"] & _abi.F_ABSENT) == 0
+                bad = (pres & ((st["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
+                bad |= (pres & (np.abs(st["speed"]) < 0.5)).any(1) | ((ost["present"] != 0) & (np.abs(ost["speed"]) < 0.5)).any(1)
+                bad |= ((ost["present"] != 0) & ((ost["crashed"] != 0) | (ost["has_impact"] != 0))).any(1)
+                ok = ~bad & ~done_prev  # (a finished episode is re-spawned by the device engine in this very step)
+                np.testing.assert_array_equal(h_term[ok], o_term[ok], err_msg=f"step {t}")
+                np.testing.assert_array_equal(h_trunc[ok], o_trunc[ok], err_msg=f"step {t}")
+                np.testing.assert_allclose(h_obs[ok, 0], o_obs[ok], rtol=0, atol=1e-6, err_msg=f"step {t}")
+                np.testing.assert_allclose(h_rew[ok, 0], o_rew[ok], rtol=0, atol=1e-9, err_msg=f"step {t}")
+                got = host.get_state()
+                np.testing.assert_allclose(got["x"][ok], ost["x"][ok], rtol=0, atol=1e-8, err_msg=f"step {t}")
+                np.testing.assert_array_equal(got["lane"][ok][pres[ok]], ost["lane"][ok][pres[ok]], err_msg=f"step {t}")
+                checked += int(ok.sum())
+                d_obs, d_rew, d_term, d_trunc, _ = dev.step(acts)
+                np.testing.assert_array_equal(d_term[ok], h_term[ok])  # same dynamics with device traffic switched on
+                done_prev = d_term | d_trunc
+            assert checked > 20
+            for e_ in (dev, host):
+                e_.close()
+        except AssertionError as ex:
+            raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
