@@ -631,7 +631,8 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
   const int ia = ctz64(egos);
   if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, me, present, ia);
   const int V = p.V, F = p.F;
-  const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia), eh = wave_bcast(me.h, ia);
+  const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
+  const double ech = wave_bcast(me.ch, ia), esh = wave_bcast(me.sh, ia);  // (cross-lane reads stay in uniform control flow)
   const int elane = wave_bcast_i(me.lane, ia);
   const double dxe = me.x - ex, dye = me.y - ey;
   // observer.lane_distance_to(me): both projected on the observer's lane (wave-uniform lane: no divergence)
@@ -661,7 +662,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
                    : fid == HWY_FEAT_COS_H ? ch : fid == HWY_FEAT_SIN_H ? shh : 0.0;
         const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
         if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
-          const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * wave_bcast(me.ch, ia) : ev * wave_bcast(me.sh, ia);
+          const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ech : ev * esh;
           val -= origin;
         }
         if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
