@@ -11,6 +11,7 @@ Every variant is a list of (file, old, new) substitutions on highwayenv_amd/csrc
 no longer matches the source is skipped with a message (the kernels evolve).
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -116,6 +117,18 @@ def net_ticks(text):
     return t
 
 
+def wave_reload(text):
+    """Frame loop of the one-wavefront kernel reads its parameters through a per-iteration view of the kernarg segment
+    (short-lived SGPRs instead of values kept -- and spilled -- across the loop)."""
+    a = text.index("  for (int fr = 0; fr < p.n_frames; ++fr) {\n    // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315)")
+    b = text.index("  }  // frames", a)
+    body = text[a:b]
+    head, rest = body.split("{\n", 1)
+    rest = re.sub(r"\bp\.", "pl.", rest)
+    rest = re.sub(r"\(p, ", "(pl, ", rest)
+    return text[:a] + head + "{\n    HWY_RELOAD_PARAMS(pl, p);\n" + rest + text[b:]
+
+
 NO_LOGEXP = [(D, sub("return r > 0.0 ? log_pos(r) : -__builtin_inf();", "return r;")),
              (D, sub("(1 - exp_bounded(delta * log_ratio))", "(1 - delta * log_ratio)"))]
 
@@ -131,6 +144,7 @@ VARIANTS = {
     "wnosteer": [(W, sub("    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "    double tb = inv_v * 1e-9;"))],
     "wnoobs": [(W, sub("    observe_wave<true>(q, e, me, true, rank);\n", ""))],
     "wticks": [(W, ticks)],
+    "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
     # intersection kernel (hwy_ix.h): sections removed (timing only)
