@@ -35,6 +35,7 @@ C_NORMALIZE_REWARD, C_OFFROAD_TERMINAL, C_OBS_ABSOLUTE, C_OBS_NORMALIZE, C_OBS_C
 C_EGO_ONLY_COLLISIONS = 64
 C_GRID_ALIGN = 128
 C_HOST_TRAFFIC = 256
+C_CONNECTED_LANES = 512
 OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
 HWY_MAX_GRID_CELLS = 65536
 
@@ -52,12 +53,12 @@ class HwyLane(C.Structure):
         ("x0", C.c_double), ("y0", C.c_double), ("length", C.c_double), ("width", C.c_double),
         ("amplitude", C.c_double), ("pulsation", C.c_double), ("phase", C.c_double), ("speed_limit", C.c_double),
         ("road", C.c_int32), ("id", C.c_int32), ("road_first", C.c_int32), ("road_lanes", C.c_int32),
-        ("next_first", C.c_int32), ("next_lanes", C.c_int32), ("forbidden", C.c_int32), ("reserved", C.c_int32),
+        ("next_first", C.c_int32), ("next_lanes", C.c_int32), ("forbidden", C.c_int32), ("connected", C.c_int32),
     ]
 
 
 LANE_F64 = ["x0", "y0", "length", "width", "amplitude", "pulsation", "phase", "speed_limit"]
-LANE_I32 = ["road", "id", "road_first", "road_lanes", "next_first", "next_lanes", "forbidden"]
+LANE_I32 = ["road", "id", "road_first", "road_lanes", "next_first", "next_lanes", "forbidden"]  # (+ "connected", derived)
 
 
 class HwyGLane(C.Structure):
@@ -304,10 +305,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     merge = scenario in ("merge", "merge-generic")
     if scenario != "highway" and not merge and not ix:
         raise ValueError(f"unknown scenario {scenario!r}")
-    if cfg.get("neighbour_vehicles_connected_lanes", False):
-        raise NotImplementedError("neighbour_vehicles_connected_lanes (merge-v1 / merge-generic-v1) is out of scope"
-                                  if merge else
-                                  "neighbour_vehicles_connected_lanes is meaningless on a single-segment highway")
+    # neighbour_vehicles_connected_lanes on the single road 0->1 of highway-v0 adds no lane to the search list
+    # (road.py:513-529: nothing leaves "1", nothing arrives at "0"), so the flag is accepted there and changes nothing
     if merge and grid:
         raise NotImplementedError("OccupancyGrid is not implemented for the merge networks")
     if ix and cfg.get("neighbour_vehicles_connected_lanes", False):
@@ -416,6 +415,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         flags |= C_OBS_CLIP
     if obs.get("see_behind", False):
         flags |= C_OBS_SEE_BEHIND
+    if merge and cfg.get("neighbour_vehicles_connected_lanes", False):
+        flags |= C_CONNECTED_LANES
     if merge and not obs.get("include_obstacles", True):
         raise NotImplementedError("KinematicObservation include_obstacles=False is out of scope")
     if ix:

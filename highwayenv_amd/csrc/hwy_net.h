@@ -41,7 +41,7 @@ struct NetShared {
   double lx0[HWY_MAX_LANES], ly0[HWY_MAX_LANES], llen[HWY_MAX_LANES], lwid[HWY_MAX_LANES], lamp[HWY_MAX_LANES],
       lpuls[HWY_MAX_LANES], lphase[HWY_MAX_LANES], llimit[HWY_MAX_LANES];
   int lroad[HWY_MAX_LANES], lid[HWY_MAX_LANES], lfirst[HWY_MAX_LANES], lcount[HWY_MAX_LANES], lnext[HWY_MAX_LANES],
-      lnextn[HWY_MAX_LANES], lforb[HWY_MAX_LANES];
+      lnextn[HWY_MAX_LANES], lforb[HWY_MAX_LANES], lconn[HWY_MAX_LANES];
   // frame-start snapshot in RANK order
   double x[64], v[64], c[64], s[64], lr[64], ox[64];  // lr = log(v/v0) (IDM), ox = x0 of the vehicle's own lane
   int idx[64], kind[64];                              // kind: 1 = vehicle, 0 = obstacle
@@ -314,7 +314,7 @@ __device__ inline void net_neighbours_scan(const NetShared &sh, u64 pm, int bits
     const int j = ctz64(m);
     const double s_v = wave_bcast(x, j) - x0;
     const int bj = wave_bcast_i(bits, j);
-    if (j == self || !((bj >> Lq) & 1)) continue;
+    if (j == self || !(bj & sh.lconn[Lq])) continue;
     if (s <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
     if (s_v < s && (b < 0 || s_v > s_rear)) { s_rear = s_v; b = j; }
   }
@@ -418,6 +418,8 @@ __device__ inline void net_load_table(const NetParams &np, NetShared &sh) {
     sh.row[i] = NetLaneRow{l.x0, l.y0, l.length, l.length + 5.0, l.width / 2 + 1.0, 0.0};
     sh.lroad[i] = l.road; sh.lid[i] = l.id; sh.lfirst[i] = l.road_first; sh.lcount[i] = l.road_lanes;
     sh.lnext[i] = l.next_first; sh.lnextn[i] = l.next_lanes; sh.lforb[i] = l.forbidden;
+    // lanes searched together with lane i by Road.neighbour_vehicles (road.py:508-529); just the lane itself by default
+    sh.lconn[i] = (np.s.flags & HWY_C_CONNECTED_LANES) ? l.connected : (1 << i);
   }
   __syncthreads();
 }
@@ -597,10 +599,14 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     if (fr == 0) net_rank(me.x, present, pm, rank, has_tie);
     else net_update_rank(me.x, present, pm, n_present, rank, has_tie);
     const int sorted_bits = wave_send_i(bits, rank);
+    // thread i publishes the mask lane i is searched with: its own members and, with connected lanes, those of the
+    // connected segments too (a vehicle on two of them is one bit; all of these lanes measure s from x, so the order
+    // along x is the order of `s_v + offset` of road.py:536-545)
     u64 m_pub = 0;
+    const int my_conn = i < np.n_lanes ? sh.lconn[i] : 0;
     for (int L = 0; L < np.n_lanes; ++L) {
       const u64 b = __ballot((sorted_bits >> L) & 1) & (n_present >= 64 ? ~(u64)0 : (((u64)1 << n_present) - 1));
-      m_pub = (i == L) ? b : m_pub;
+      m_pub |= ((my_conn >> L) & 1) ? b : 0;
     }
     const double log_ratio = veh ? net_log_ratio(me.v, me.ts, sh.llimit[me.lane]) : 0.0;
     __syncthreads();

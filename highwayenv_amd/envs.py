@@ -294,6 +294,25 @@ class BatchedMergeGenericEnv(BatchedMergeEnv):
     GENERIC = True
 
 
+class _ConnectedLaneNeighboursMixin:
+    """ConnectedLaneNeighboursMixin (envs/common/abstract.py:26-37): ``neighbour_vehicles_connected_lanes`` on --
+    Road.neighbour_vehicles also searches the lane segments connected to the queried one (road.py:508-529)."""
+
+    @classmethod
+    def default_config(cls) -> dict:
+        cfg = super().default_config()
+        cfg["neighbour_vehicles_connected_lanes"] = True
+        return cfg
+
+
+class BatchedConnectedLaneMergeEnv(_ConnectedLaneNeighboursMixin, BatchedMergeEnv):
+    """E parallel ``merge-v1`` environments (ConnectedLaneMergeEnv, merge_env.py:189)."""
+
+
+class BatchedConnectedLaneMergeGenericEnv(_ConnectedLaneNeighboursMixin, BatchedMergeGenericEnv):
+    """E parallel ``merge-generic-v1`` environments (ConnectedLaneMergeGenericEnv, merge_env.py:378)."""
+
+
 class BatchedIntersectionEnv(BatchedHighwayEnv):
     """E parallel ``intersection-v0`` environments (IntersectionEnv, highway_env/envs/intersection_env.py): a 4-way
     junction of straight and circular lanes, planned routes, ``RegulatedRoad`` priorities, traffic that is cleared and
@@ -433,6 +452,14 @@ class MergeEnv(_SingleMergeMixin, BatchedMergeEnv):
 
 class MergeGenericEnv(_SingleMergeMixin, BatchedMergeGenericEnv):
     """Drop-in for ``highway_env.envs.merge_env.MergeGenericEnv`` (``merge-generic-v0``)."""
+
+
+class ConnectedLaneMergeEnv(_SingleMergeMixin, BatchedConnectedLaneMergeEnv):
+    """Drop-in for ``highway_env.envs.merge_env.ConnectedLaneMergeEnv`` (``merge-v1``)."""
+
+
+class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeGenericEnv):
+    """Drop-in for ``highway_env.envs.merge_env.ConnectedLaneMergeGenericEnv`` (``merge-generic-v1``)."""
 
 
 def _copy_config(cfg):

@@ -115,6 +115,24 @@ def lane_table(cfg: dict, generic: bool) -> dict:
     return tab
 
 
+def connected_masks(tab: dict) -> list:
+    """hwy_lane.connected: the lanes Road.neighbour_vehicles searches together with lane k when
+    neighbour_vehicles_connected_lanes is on (road.py:508-529): lane k, lane `id` (else 0) of the successor road, lane `id`
+    (else 0) of every road that ends where k's road starts."""
+    n = len(tab["x0"])
+    out = []
+    for k in range(n):
+        m = 1 << k
+        _id = int(tab["id"][k])
+        if tab["next_first"][k] >= 0:
+            m |= 1 << (int(tab["next_first"][k]) + (_id if _id < tab["next_lanes"][k] else 0))
+        for q in range(n):   # one visit per road (its lane 0) whose successor is k's road
+            if tab["id"][q] == 0 and tab["next_first"][q] == tab["road_first"][k]:
+                m |= 1 << (q + (_id if _id < tab["road_lanes"][q] else 0))
+        out.append(m)
+    return out
+
+
 def table_from_config(c: _abi.HwyConfig) -> dict:
     n = c.net_lanes
     tab = {k: np.array([getattr(c.net[i], k) for i in range(n)], np.float64) for k in _abi.LANE_F64}
@@ -148,6 +166,8 @@ def fill_config(c: _abi.HwyConfig, cfg: dict, generic: bool) -> None:
             setattr(c.net[k], f, float(tab[f][k]))
         for f in _abi.LANE_I32:
             setattr(c.net[k], f, int(tab[f][k]))
+    for k, m in enumerate(connected_masks(tab)):
+        c.net[k].connected = m
     # MergeEnv._rewards tests `vehicle.lane_index == ("b", "c", 2)` literally (merge_env.py:72): the acceleration
     # lane when lanes_count == 2, a HIGHWAY lane of b->c when MergeGenericEnv has more lanes.  a->b holds `lanes`
     # entries and b->c starts right after them.

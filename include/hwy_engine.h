@@ -84,6 +84,8 @@ enum {
   HWY_C_OBS_SEE_BEHIND = 32,  /* KinematicObservation.see_behind    observation.py:171 */
   HWY_C_EGO_ONLY_COLLISIONS = 64, /* HighwayEnvFast: spawned traffic has check_collisions=False (highway_env.py:177-182) */
   HWY_C_GRID_ALIGN = 128,     /* OccupancyGridObservation.align_to_vehicle_axes  observation.py:294,431-435 */
+  HWY_C_CONNECTED_LANES = 512, /* Road.neighbour_vehicles_connected_lanes (road.py:483-547; merge-v1, merge-generic-v1): the
+                                 leader / follower search on a lane also looks at hwy_lane.connected */
   HWY_C_HOST_TRAFFIC = 256    /* HWY_SCENARIO_INTERSECTION: the HOST clears / spawns vehicles between policy steps (the
                                  reference-stream mode of highwayenv_amd/intersection.py); otherwise the step kernel does
                                  it on Philox draws */
@@ -150,7 +152,9 @@ typedef struct hwy_lane {
   int32_t next_first;                 /* table index of lane 0 of the road that starts at `to`, -1 if none */
   int32_t next_lanes;                 /* its lane count (RoadNetwork.next_lane, road.py:73-127) */
   int32_t forbidden;                  /* lane.forbidden (is_reachable_from, lane.py:110-111) */
-  int32_t reserved;
+  int32_t connected;                  /* bit K: lane K is searched together with this lane when HWY_C_CONNECTED_LANES is
+                                         set -- the lane itself, lane `id` (else 0) of the successor road, lane `id` (else 0) of
+                                         every road ending where this one starts (road.py:508-529) */
 } hwy_lane;
 
 /* meta-actions: DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:204 */

@@ -287,21 +287,44 @@ static void handle_collisions(ent_t *self, ent_t *other, double dt) {
   }
 }
 
-/* ---- road/road.py:483-547 (neighbour_vehicles_connected_lanes == False): vehicles + objects ----- */
+/* ---- road/road.py:483-547: vehicles + objects.  With HWY_C_CONNECTED_LANES the search list is the lane, then lane `id`
+ * (else 0) of the road leaving `_to` (offset +lane.length), then lane `id` (else 0) of every road arriving at `_from`
+ * (offset -prev.length), in graph-insertion order == table order; a vehicle counts on the FIRST list entry it is on. ----- */
 static void neighbour_vehicles(const net_t *r, const ent_t *vehicle, int lane, int *front, int *rear) {
-  const hwy_lane *l = &r->cfg->net[lane];
+  const hwy_config *c = r->cfg;
+  const hwy_lane *l = &c->net[lane];
   double s, lat;
   lane_local(l, vehicle->x, vehicle->y, &s, &lat);
   double s_front = 0, s_rear = 0;
   *front = *rear = -1;
+  int search[1 + HWY_MAX_LANES], n_search = 0;
+  double offset[1 + HWY_MAX_LANES];
+  search[n_search] = lane; offset[n_search++] = 0;
+  if (c->flags & HWY_C_CONNECTED_LANES) {
+    if (l->next_first >= 0) {   /* at most one road leaves a node of the merge networks */
+      search[n_search] = l->next_first + (l->id < l->next_lanes ? l->id : 0);
+      offset[n_search++] = l->length;
+    }
+    for (int q = 0; q < c->net_lanes; q++) {   /* roads in table order, one visit each (their lane 0) */
+      const hwy_lane *pl = &c->net[q];
+      if (pl->id != 0 || pl->next_first != l->road_first) continue;
+      const int k = q + (l->id < pl->road_lanes ? l->id : 0);
+      search[n_search] = k; offset[n_search++] = -c->net[k].length;
+    }
+  }
   for (int j = 0; j < r->n; j++) {
     const ent_t *v = &r->v[j];
     if (!v->present || v == vehicle) continue;
-    double s_v, lat_v;
-    lane_local(l, v->x, v->y, &s_v, &lat_v);
-    if (!lane_on_lane(l, v->x, v->y, 1.0)) continue;
-    if (s <= s_v && (*front < 0 || s_v <= s_front)) { s_front = s_v; *front = j; }
-    if (s_v < s && (*rear < 0 || s_v > s_rear)) { s_rear = s_v; *rear = j; }
+    for (int k = 0; k < n_search; k++) {
+      const hwy_lane *sl = &c->net[search[k]];
+      double s_v, lat_v;
+      lane_local(sl, v->x, v->y, &s_v, &lat_v);
+      if (!lane_on_lane(sl, v->x, v->y, 1.0)) continue;
+      s_v += offset[k];
+      if (s <= s_v && (*front < 0 || s_v <= s_front)) { s_front = s_v; *front = j; }
+      if (s_v < s && (*rear < 0 || s_v > s_rear)) { s_rear = s_v; *rear = j; }
+      break;
+    }
   }
 }
 

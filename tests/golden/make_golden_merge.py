@@ -37,7 +37,8 @@ from oracle import ref_stub  # noqa: E402
 
 ref_stub.install()
 
-from highway_env.envs.merge_env import MergeEnv, MergeGenericEnv  # noqa: E402
+from highway_env.envs.merge_env import (ConnectedLaneMergeEnv, ConnectedLaneMergeGenericEnv,  # noqa: E402
+                                         MergeEnv, MergeGenericEnv)
 from highway_env.road.lane import SineLane  # noqa: E402
 from highway_env.vehicle.behavior import IDMVehicle  # noqa: E402
 from highway_env.vehicle.controller import MDPVehicle  # noqa: E402
@@ -177,6 +178,12 @@ SCENARIOS = [
     dict(name="merge_ma4", cls=MergeGenericMultiAgent,
          config=dict(MA_CFG, lanes_count=4, vehicles_count=40, controlled_vehicles=4),
          seeds=[0, 1, 2], steps=11, action_seed=34, frames_for=1, n_slots=43),
+    # merge-v1 / merge-generic-v1: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
+    dict(name="merge_v1", cls=ConnectedLaneMergeEnv, config={}, seeds=list(range(8)), steps=14, action_seed=35,
+         frames_for=3, n_slots=6),
+    dict(name="merge_generic_v1", cls=ConnectedLaneMergeGenericEnv, config={"lanes_count": 3, "vehicles_count": 20},
+         seeds=list(range(5)), steps=13, action_seed=36, frames_for=2, n_slots=23,
+         action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),
 ]
 
 

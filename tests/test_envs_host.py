@@ -129,15 +129,29 @@ class EmuBatchedMergeGeneric(envs.BatchedMergeGenericEnv):
     _engine_factory = staticmethod(_emu_factory)
 
 
+class EmuMergeV1(envs._SingleMergeMixin, envs.BatchedConnectedLaneMergeEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+class EmuMergeGenericV1(envs._SingleMergeMixin, envs.BatchedConnectedLaneMergeGenericEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
 @pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
-@pytest.mark.parametrize("name", ["merge_default", "merge_generic_l3"])
+@pytest.mark.parametrize("name", ["merge_default", "merge_generic_l3", "merge_v1", "merge_generic_v1"])
 def test_single_merge_env_dropin_matches_reference_episode(real, name):
-    """MergeEnv() / MergeGenericEnv(config): reset(seed=s), golden actions -> the reference's obs/reward/flags."""
+    """MergeEnv() / MergeGenericEnv(config) and their ConnectedLane* (merge-v1, merge-generic-v1) variants:
+    reset(seed=s), golden actions -> the reference's obs/reward/flags."""
     from tests.golden_util import GoldenMerge
     g = GoldenMerge(name)
-    over = {k: v for k, v in g.config.items() if envs.BatchedMergeGenericEnv.default_config().get(k) != v} if g.generic else None
-    cls = {(False, False): EmuMerge, (False, True): EmuMergeGeneric,
-           (True, False): envs.MergeEnv, (True, True): envs.MergeGenericEnv}[(real, g.generic)]
+    v1 = name.endswith("_v1")
+    cls = {(False, False, False): EmuMerge, (False, True, False): EmuMergeGeneric,
+           (True, False, False): envs.MergeEnv, (True, True, False): envs.MergeGenericEnv,
+           (False, False, True): EmuMergeV1, (False, True, True): EmuMergeGenericV1,
+           (True, False, True): envs.ConnectedLaneMergeEnv,
+           (True, True, True): envs.ConnectedLaneMergeGenericEnv}[(real, g.generic, v1)]
+    over = {k: v for k, v in g.config.items() if cls.default_config().get(k) != v} if g.generic else None
+    assert cls.default_config()["neighbour_vehicles_connected_lanes"] is v1
     env = cls(over)
     e = 1
     obs, info = env.reset(seed=int(g.seeds[e]))

@@ -65,7 +65,8 @@ def random_merge_config(rng):
                 "before_merge_length": int(rng.integers(50, 200)), "converge_merge_length": int(rng.integers(40, 120)),
                 "parallel_merge_length": int(rng.integers(40, 120)), "after_merge_length": int(rng.integers(90, 200)),
                 "simulation_frequency": int(rng.choice([5, 15])), "collision_reward": float(rng.uniform(-2, -0.1)),
-                "merging_speed_reward": float(rng.uniform(-1, -0.1)), "lane_change_reward": float(rng.uniform(-0.2, 0))})
+                "merging_speed_reward": float(rng.uniform(-1, -0.1)), "lane_change_reward": float(rng.uniform(-0.2, 0)),
+                "neighbour_vehicles_connected_lanes": bool(rng.integers(2))})   # merge-generic-v0 / -v1
     if agents > 1:
         cfg["action"] = {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}}
         cfg["observation"] = {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}

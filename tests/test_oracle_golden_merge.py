@@ -83,3 +83,35 @@ def test_oracle_free_running_steps(name):
         assert_net_state_close(sub(st), sub(want), atol=1e-8, what=what)
         live &= ~g.z["terminated"][t].astype(bool)
     assert not live.all() or g.steps < 12  # the fixtures do reach termination
+
+
+@pytest.mark.parametrize("name", ["merge_v1", "merge_generic_v1"])
+def test_connected_lanes_flag_is_load_bearing(name):
+    """merge-v1 / merge-generic-v1 (neighbour_vehicles_connected_lanes, road.py:508-529): without the flag the
+    restatement must NOT reproduce the reference's v1 frames -- i.e. the fixtures do exercise the connected search."""
+    g = GoldenMerge(name)
+    cfg = g.hwy_config(g.frames_for)
+    assert cfg.flags & _abi.C_CONNECTED_LANES
+    cfg.flags &= ~_abi.C_CONNECTED_LANES
+    worst = 0.0
+    for k in range(g.steps * g.T):
+        st = g.state("init", envs=slice(0, g.frames_for)) if k == 0 else g.state("frame", k - 1)
+        oracle.frames(cfg, st, g.actions[k // g.T, :g.frames_for] if k % g.T == 0 else None, 1)
+        want = g.state("frame", k)
+        pres = (want["flags"] & _abi.F_ABSENT) == 0
+        worst = max(worst, float(np.abs(st["speed"] - want["speed"])[pres].max()))
+    assert worst > 1e-3
+
+
+def test_connected_lane_masks():
+    """hwy_lane.connected on the merge-v0 table [ab0 ab1 | bc0 bc1 lbc | cd0 cd1 | jk | kb]: lane id (else 0) of the road
+    leaving `_to` and of every road arriving at `_from`."""
+    from highwayenv_amd import merge
+    masks = merge.connected_masks(merge.lane_table(merge.merge_default_config(), generic=False))
+    bit = lambda *ks: sum(1 << k for k in ks)  # noqa: E731
+    assert masks == [bit(0, 2), bit(1, 3),                       # a->b: next b->c same id
+                     bit(2, 5, 0, 8), bit(3, 6, 1, 8),           # b->c: next c->d, prev a->b same id, prev k->b lane 0
+                     bit(4, 5, 0, 8),                            # lbc (id 2): c->d has 2 lanes -> lane 0; a->b lane 0; k->b
+                     bit(5, 2), bit(6, 3),                       # c->d: prev b->c same id
+                     bit(7, 8),                                  # j->k: next k->b
+                     bit(8, 2, 7)]                               # k->b (id 0): next b->c LANE 0, prev j->k
