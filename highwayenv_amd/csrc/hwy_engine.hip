@@ -259,9 +259,14 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
   if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
   // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
-  // intersection kernel: 172 VGPRs fit 2 waves/SIMD; a 3rd (10 spilled registers) pays once the batch exceeds the 2048 wave
-  // slots of the 2-wave build (measured: +9..13 % at 4096 / 8192 environments, -3 % at 2048)
-  if (cfg->scenario == HWY_SCENARIO_INTERSECTION) eng->waves_per_eu = cfg->num_envs > 2048 ? 3 : 2;
+  // intersection kernel with helper lanes (N <= 32, hwy_ix.h): 208 VGPRs, 2 waves/SIMD is the faster build at every batch
+  // size measured (a 3rd wave costs 125 spilled registers).  Without them (N > 32, or HWY_IX_HELPERS=0): 176 VGPRs fit 2
+  // waves/SIMD; a 3rd pays once the batch exceeds the 2048 wave slots of the 2-wave build (+8 % at 4096 environments)
+  if (cfg->scenario == HWY_SCENARIO_INTERSECTION) {
+    const char *h = std::getenv("HWY_IX_HELPERS");
+    const bool helpers = cfg->num_vehicles <= 32 && !(h && h[0] == '0');
+    eng->waves_per_eu = (cfg->num_envs > 2048 && !helpers) ? 3 : 2;
+  }
   else if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
   if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
     const int v = std::atoi(w);

@@ -37,7 +37,8 @@ struct IxParams {
   int32_t *road_steps;     // [E]
   // next-episode pre-warming (auto-reset): a second copy of the vehicle planes and, per environment,
   // {episode the shadow belongs to, warm-up progress, RegulatedRoad.steps, unused}; nullptr = off
-  int32_t num_envs, prewarm_pad;
+  int32_t num_envs;
+  int32_t helpers;         // N <= 32: launch 64 threads per environment, lanes 32..63 help (see IxSharedT); 0 = 32 threads
   DevState shadow;
   int32_t *shadow_route;
   int32_t *shadow_meta;    // [E][4]
@@ -67,20 +68,33 @@ struct IxVeh {
 
 #define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
 
-// CAP = slots per environment the LDS arrays are sized for == threads per workgroup (32 or 64: a 32-thread workgroup
-// still occupies one wavefront, with the upper half of the lanes masked off)
-template <int CAP>
+// CAP = slots per environment the per-vehicle LDS tables are sized for; NT = threads per workgroup (one wavefront).
+//   NT == CAP (32 or 64): thread i == slot i (a 32-thread workgroup still occupies a wavefront, upper half masked off);
+//   NT == 2 * CAP (CAP 32): HELPER LANES.  Threads 32..63 are empty slots everywhere except in the three sections of
+//   a frame that are loops over independent items -- the walk over the lane table, the partner loop of the collision
+//   check, the samples and the partner loop of the regulation -- where thread t works for vehicle t & 31 on the items
+//   of parity t >> 5; partial results meet through LDS (ix_xchg) with the same tie rules the serial loops have
+//   (closest lane: minimum distance then lowest table index; impact: highest partner slot), so the results are the
+//   serial ones bit for bit.
+template <int CAP, int NT = CAP>
 struct IxSharedT {
+  static constexpr int kCap = CAP, kNH = NT / CAP;
   // lane table (struct of arrays: per-thread lane indices read it with one ds_read each)
   int kind[HWY_MAX_GLANES], ldir[HWY_MAX_GLANES], prio[HWY_MAX_GLANES], from[HWY_MAX_GLANES], to[HWY_MAX_GLANES],
       exitl[HWY_MAX_GLANES];
+  int ord[HWY_MAX_GLANES], n_straight;  // table indices: straight lanes ascending, then circular lanes ascending
   double sx[HWY_MAX_GLANES], sy[HWY_MAX_GLANES], lhead[HWY_MAX_GLANES], dirx[HWY_MAX_GLANES], diry[HWY_MAX_GLANES],
       cx[HWY_MAX_GLANES], cy[HWY_MAX_GLANES], rad[HWY_MAX_GLANES], sph[HWY_MAX_GLANES], len[HWY_MAX_GLANES],
       wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
   u64 mask[HWY_MAX_GLANES];  // slot-space membership (on_lane, margin 1) of every lane
-  // frame snapshot by slot
-  double x[CAP], y[CAP], v[CAP], c[CAP], s[CAP];
-  double bcx[CAP], bcy[CAP], brho[CAP];  // regulation: a circle around the 11 predicted positions of slot i
+  // frame snapshot by slot (indexed by thread where every thread writes)
+  double x[NT], y[NT], v[NT], c[NT], s[NT];
+  double bcx[NT], bcy[NT], brho[NT];  // regulation: a circle around the 11 predicted positions of slot i
+  // helper-lane exchange (kNH == 2 only): one double and two ints per thread, plus what a helper needs of its vehicle
+  double xd[kNH > 1 ? NT : 1];
+  int xi[kNH > 1 ? NT : 1], xb[kNH > 1 ? NT : 1];
+  double hd[kNH > 1 ? CAP : 1];
+  int vw[kNH > 1 ? CAP : 1];
   union {
     double sl[HWY_MAX_GLANES][CAP];          // longitudinal coordinate of slot i on lane L (act phase)
     double traj[HWY_IX_SAMPLES][3][CAP];     // predicted (x, y, heading) of slot i at sample k (regulation)
@@ -137,7 +151,30 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
     sh.cx[i] = l.cx; sh.cy[i] = l.cy; sh.rad[i] = l.radius; sh.sph[i] = l.start_phase; sh.len[i] = l.length;
     sh.wid[i] = l.width; sh.lim[i] = l.speed_limit;
   }
+  if (i == 0) {
+    int n = 0;
+    for (int L = 0; L < ip.n_lanes; ++L)
+      if (ip.lanes[L].kind == 0) sh.ord[n++] = L;
+    sh.n_straight = n;
+    for (int L = 0; L < ip.n_lanes; ++L)
+      if (ip.lanes[L].kind != 0) sh.ord[n++] = L;
+  }
   __syncthreads();
+}
+
+// helper lanes (IxSharedT): combine the two halves' partial (distance, lane) minima and membership bits
+template <typename SH>
+__device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits) {
+  if constexpr (SH::kNH > 1) {
+    const int t = threadIdx.x, o = t ^ SH::kCap;
+    sh.xd[t] = bd; sh.xi[t] = best; sh.xb[t] = bits;
+    __syncthreads();
+    const double obd = sh.xd[o];
+    const int ob = sh.xi[o];
+    bits |= sh.xb[o];
+    if (obd < bd || (obd == bd && ob < best)) { bd = obd; best = ob; }
+    __syncthreads();
+  }
 }
 
 // One walk over the lane table for my body (lane index wave-uniform): membership bits (on_lane margin 1, lane.py:80-102),
@@ -149,29 +186,47 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
 template <typename SH>
 __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, double x, double y, double h, int tgt,
                                     int *bits_out, int *closest_out) {
-  const int i = threadIdx.x;
-  int bits = 0, best = 0;
+  constexpr int NH = SH::kNH;
+  const int t = threadIdx.x, vi = t & (SH::kCap - 1), half = NH > 1 ? t / SH::kCap : 0;
+  if constexpr (NH > 1) {  // a helper works on the body of vehicle t & 31
+    __syncthreads();
+    if (half == 0) { sh.x[vi] = x; sh.y[vi] = y; sh.hd[vi] = h; sh.vw[vi] = tgt | (present ? 256 : 0); }
+    __syncthreads();
+    x = sh.x[vi]; y = sh.y[vi]; h = sh.hd[vi];
+    const int w = sh.vw[vi];
+    tgt = w & 255; present = (w & 256) != 0;
+  }
+  int bits = 0, best = 0x7fffffff;
   double bd = __builtin_inf();
-  for (int L = 0; L < ip.n_lanes; ++L) {
-    if (sh.kind[L] != 0) continue;  // wave-uniform
+  const int ns = sh.n_straight, n = ip.n_lanes;
+  for (int k = 0; k < ns; k += NH) {  // wave-uniform trip, one lane per half
+    const bool mine = k + half < ns;
+    const int L = sh.ord[mine ? k + half : k];
     const double dx = x - sh.sx[L], dy = y - sh.sy[L];
     const double s = dx * sh.dirx[L] + dy * sh.diry[L];
     const double lat = dx * -sh.diry[L] + dy * sh.dirx[L];
     const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
-    bits |= on ? (1 << L) : 0;
-    sh.sl[L][i] = s;
     const double angle = fabs(wrap_to_pi(h - sh.lhead[L]));
     const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-    if (d < bd) { bd = d; best = L; }
+    if (mine) {
+      bits |= on ? (1 << L) : 0;
+      sh.sl[L][vi] = s;
+      if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
+    }
   }
-  for (int L = 0; L < ip.n_lanes; ++L) {
-    if (sh.kind[L] == 0) continue;  // wave-uniform
+  {
+    int none = 0;
+    ix_xchg(sh, bd, best, none);  // the arcs are filtered against the best distance over ALL straight lanes
+  }
+  for (int k = ns; k < n; k += NH) {
+    const bool mine = k + half < n;
+    const int L = sh.ord[mine ? k + half : k];
     const double dx = x - sh.cx[L], dy = y - sh.cy[L];
     const double r = sqrt(dx * dx + dy * dy);
     const double lat = sh.ldir[L] * (sh.rad[L] - r);
-    const bool need = present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);
+    const bool need = mine && present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);
     if (__ballot(need) == 0) {
-      sh.sl[L][i] = 0.0;
+      if (mine) sh.sl[L][vi] = 0.0;
       continue;
     }
     double phi = atan2_bounded(dy, dx);
@@ -179,12 +234,15 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
     const double s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
     const double lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
     const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
-    bits |= on ? (1 << L) : 0;
-    sh.sl[L][i] = s;
     const double angle = fabs(wrap_to_pi(h - lane_h));
     const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-    if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
+    if (mine) {
+      bits |= on ? (1 << L) : 0;
+      sh.sl[L][vi] = s;
+      if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
+    }
   }
+  ix_xchg(sh, bd, best, bits);
   *bits_out = bits;
   *closest_out = best;
 }
@@ -405,65 +463,92 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         me.ts = sh.lim[me.lane];
         me.flags &= ~HWY_F_YIELDING;
       }
-      const double s_me = sh.sl[me.lane][i];
+      // (helper lanes, IxSharedT: thread t works for vehicle vi = t & 31 -- the samples and the partners of parity t >> 5)
+      constexpr int NH = SH::kNH;
+      const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
+      double s_me = veh ? sh.sl[me.lane][vi] : 0.0, v_me = me.v, x_me = me.x, y_me = me.y, c_me = ch, sn_me = shh;
+      int route_me = me.route, lane_me = me.lane;
+      bool veh_v = veh;
+      if constexpr (NH > 1) {
+        if (half == 0) { sh.xd[i] = s_me; sh.xi[i] = me.route; sh.xb[i] = me.lane | (veh ? 256 : 0); }
+      }
       __syncthreads();  // sl[][] is dead from here on: the trajectories share its storage
-      if (veh) {
-        for (int k = 0; k < HWY_IX_SAMPLES; ++k) {
+      if constexpr (NH > 1) {
+        s_me = sh.xd[vi]; route_me = sh.xi[vi];
+        lane_me = sh.xb[vi] & 255; veh_v = (sh.xb[vi] & 256) != 0;
+        v_me = sh.v[vi]; x_me = sh.x[vi]; y_me = sh.y[vi]; c_me = sh.c[vi]; sn_me = sh.s[vi];  // frame snapshot (B)
+      }
+      if (veh_v) {
+        IxVeh r{};
+        r.route = route_me; r.lane = lane_me;
+        for (int k = half; k < HWY_IX_SAMPLES; k += NH) {
           double px, py, hd;
-          ix_along_route(sh, me, s_me + me.v * (0.25 + k * 0.25), &px, &py, &hd);
-          sh.traj[k][0][i] = px; sh.traj[k][1][i] = py; sh.traj[k][2][i] = hd;
+          ix_along_route(sh, r, s_me + v_me * (0.25 + k * 0.25), &px, &py, &hd);
+          sh.traj[k][0][vi] = px; sh.traj[k][1][vi] = py; sh.traj[k][2][vi] = hd;
         }
       }
+      if constexpr (NH > 1) __syncthreads();
       // Two vehicles can only conflict if at some sample their predicted positions are within LENGTH of each other
       // (regulation.py:103): bound every vehicle's 11 positions by a circle (centre = the middle sample) and skip a
       // partner for the whole wave when no pair of circles comes within LENGTH (triangle inequality, 1e-6 of slack)
       double my_cx = 0.0, my_cy = 0.0, my_rho = 0.0;
-      if (veh) {
-        my_cx = sh.traj[HWY_IX_SAMPLES / 2][0][i];
-        my_cy = sh.traj[HWY_IX_SAMPLES / 2][1][i];
+      if (veh_v) {
+        my_cx = sh.traj[HWY_IX_SAMPLES / 2][0][vi];
+        my_cy = sh.traj[HWY_IX_SAMPLES / 2][1][vi];
         for (int k = 0; k < HWY_IX_SAMPLES; ++k) {
-          const double dx = sh.traj[k][0][i] - my_cx, dy = sh.traj[k][1][i] - my_cy;
+          const double dx = sh.traj[k][0][vi] - my_cx, dy = sh.traj[k][1][vi] - my_cy;
           my_rho = fmax(my_rho, sqrt(dx * dx + dy * dy));
         }
       }
-      sh.bcx[i] = my_cx; sh.bcy[i] = my_cy; sh.brho[i] = my_rho;
+      if (half == 0) { sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho; }
       __syncthreads();
       bool yield = false;
-      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j
-        const int j = ctz64(m);
+      // partner trips: one slot per half (NH == 2: slots j0 and j0 + 1), skipped when nobody is there
+      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform
+        const int j = ctz64(m) + half;
+        const bool pj = NH > 1 ? ((pm >> j) & 1) != 0 : true;
         const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
-        const bool possible = veh && i != j && sqrt(bdx * bdx + bdy * bdy) <= my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;
+        const bool possible =
+            veh_v && pj && vi != j && sqrt(bdx * bdx + bdy * bdy) <= my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;
         if (__ballot(possible) == 0) continue;
-        const int lane_j = wave_bcast_i(me.lane, j);
+        int lane_j;
+        if constexpr (NH > 1) lane_j = sh.xb[j] & 255;
+        else lane_j = wave_bcast_i(me.lane, j);
         bool conflict = false;
         if (possible) {
           for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
-            const double ax = sh.traj[k][0][i], ay = sh.traj[k][1][i], bx = sh.traj[k][0][j], by = sh.traj[k][1][j];
+            const double ax = sh.traj[k][0][vi], ay = sh.traj[k][1][vi], bx = sh.traj[k][0][j], by = sh.traj[k][1][j];
             const double dx = bx - ax, dy = by - ay;
             if (sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH) continue;
-            const double ah = sh.traj[k][2][i], bh = sh.traj[k][2][j];
+            const double ah = sh.traj[k][2][vi], bh = sh.traj[k][2][j];
             // rotated_rectangles_intersect(rect(lower slot), rect(higher slot)) is symmetric in its arguments
             conflict = ix_corner_inside(ax, ay, ah, bx, by, bh) || ix_corner_inside(bx, by, bh, ax, ay, ah);
           }
         }
         if (conflict) {
           // respect_priorities(v1 = lower slot, v2 = higher slot) (regulation.py:70-86)
-          const int pj = sh.prio[lane_j], pi_ = sh.prio[me.lane];
-          const bool i_low = i < j;
-          const int p1 = i_low ? pi_ : pj, p2 = i_low ? pj : pi_;
+          const int pj_ = sh.prio[lane_j], pi_ = sh.prio[lane_me];
+          const bool i_low = vi < j;
+          const int p1 = i_low ? pi_ : pj_, p2 = i_low ? pj_ : pi_;
           bool low_yields;
           if (p1 > p2) low_yields = false;
           else if (p1 < p2) low_yields = true;
           else {
-            const double fd_i = ch * (sh.x[j] - me.x) + shh * (sh.y[j] - me.y);          // i.front_distance_to(j)
-            const double fd_j = sh.c[j] * (me.x - sh.x[j]) + sh.s[j] * (me.y - sh.y[j]);  // j.front_distance_to(i)
+            const double fd_i = c_me * (sh.x[j] - x_me) + sn_me * (sh.y[j] - y_me);       // i.front_distance_to(j)
+            const double fd_j = sh.c[j] * (x_me - sh.x[j]) + sh.s[j] * (y_me - sh.y[j]);  // j.front_distance_to(i)
             const double f1 = i_low ? fd_i : fd_j, f2 = i_low ? fd_j : fd_i;
             low_yields = f1 > f2;
           }
           yield = yield || (low_yields == i_low);
         }
       }
-      if (yield && !controlled) {  // only a ControlledVehicle that is not the MDPVehicle is stopped
+      if constexpr (NH > 1) {  // a vehicle yields iff one of its halves found a pair that names it
+        __syncthreads();
+        sh.xi[i] = yield ? 1 : 0;
+        __syncthreads();
+        yield = yield || sh.xi[i ^ SH::kCap] != 0;
+      }
+      if (present && yield && !controlled) {  // only a ControlledVehicle that is not the MDPVehicle is stopped
         me.ts = 0.0;
         me.flags |= HWY_F_YIELDING;
       }
@@ -503,33 +588,54 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
 
     // ---- F. collisions (road.py:477-481, objects.py:92-138): every pair; the highest partner slot's impact stays ----
     {
+      constexpr int NH = SH::kNH;
+      const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
       const double c2 = me.ch, s2 = me.sh;
       __syncthreads();
       sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
       __syncthreads();
-      const Body mine{me.x, me.y, me.v, c2, s2};
-      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j, ascending
-        const int j = ctz64(m);
+      // (helper lanes: thread t checks vehicle t & 31 against the partners of parity t >> 5)
+      const Body mine = NH > 1 ? Body{sh.x[vi], sh.y[vi], sh.v[vi], sh.c[vi], sh.s[vi]} : Body{me.x, me.y, me.v, c2, s2};
+      const bool present_v = NH > 1 ? ((pm >> vi) & 1) != 0 : present;
+      int j_imp = -1;
+      double imp_x = 0.0, imp_y = 0.0;
+      bool crash = false;
+      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform, ascending
+        const int j = ctz64(m) + half;
         bool near = false;
-        if (present && i != j) {
-          const double dx = sh.x[j] - me.x, dy = sh.y[j] - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[j])) * p.dt;
+        if (present_v && vi != j && (NH == 1 || ((pm >> j) & 1))) {
+          const double dx = sh.x[j] - mine.x, dy = sh.y[j] - mine.y;
+          const double lim = 5.5 + fmax(fabs(mine.v), fabs(sh.v[j])) * p.dt;
           near = dx * dx + dy * dy <= lim * lim;
         }
         if (near) {
           const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
-          const bool i_first = i < j;
+          const bool i_first = vi < j;
           const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
           double tx, ty;
           const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
           if (r & 2) {
-            me.impx = i_first ? tx / 2 : -tx / 2;
-            me.impy = i_first ? ty / 2 : -ty / 2;
-            me.flags |= HWY_F_HAS_IMPACT;
+            imp_x = i_first ? tx / 2 : -tx / 2;
+            imp_y = i_first ? ty / 2 : -ty / 2;
+            j_imp = j;
           }
-          if (r & 1) me.flags |= HWY_F_CRASHED;
+          if (r & 1) crash = true;
         }
       }
+      if constexpr (NH > 1) {  // the other half's verdict: the impact of the higher partner slot stays
+        __syncthreads();
+        sh.xd[i] = imp_x; sh.bcx[i] = imp_y; sh.xi[i] = j_imp; sh.xb[i] = crash ? 1 : 0;
+        __syncthreads();
+        const int o = i ^ SH::kCap;
+        if (sh.xi[o] > j_imp) { imp_x = sh.xd[o]; imp_y = sh.bcx[o]; j_imp = sh.xi[o]; }
+        crash = crash || sh.xb[o] != 0;
+      }
+      if (present && j_imp >= 0) {
+        me.impx = imp_x;
+        me.impy = imp_y;
+        me.flags |= HWY_F_HAS_IMPACT;
+      }
+      if (present && crash) me.flags |= HWY_F_CRASHED;
     }
   }
 }
@@ -912,10 +1018,10 @@ __device__ inline void ix_prewarm(const IxParams &ip, SH &sh, int e) {
 }
 
 // =============================================================================================================
-template <int WPE, int CAP>
-__global__ void __launch_bounds__(CAP, WPE) hwy_ix_step_kernel(const IxParams ip) {
+template <int WPE, int CAP, int NT = CAP>
+__global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
-  __shared__ IxSharedT<CAP> sh;
+  __shared__ IxSharedT<CAP, NT> sh;
   const int i = threadIdx.x;
   if ((int)blockIdx.x >= ip.num_envs) {  // wave-uniform: the second half of the grid pre-warms next episodes
     const int ep = (int)blockIdx.x - ip.num_envs;
@@ -982,10 +1088,10 @@ __global__ void __launch_bounds__(CAP, WPE) hwy_ix_step_kernel(const IxParams ip
 }
 
 // Reset kernel: AbstractEnv.reset for the masked environments + first observation.
-template <int WPE, int CAP>
-__global__ void __launch_bounds__(CAP, WPE) hwy_ix_reset_kernel(const IxParams ip) {
+template <int WPE, int CAP, int NT = CAP>
+__global__ void __launch_bounds__(NT, WPE) hwy_ix_reset_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
-  __shared__ IxSharedT<CAP> sh;
+  __shared__ IxSharedT<CAP, NT> sh;
   const int e = blockIdx.x, i = threadIdx.x;
   ix_load_table(ip, sh);
   if (p.reset_mask && !p.reset_mask[e]) return;  // block-uniform
@@ -1005,9 +1111,9 @@ __global__ void __launch_bounds__(CAP, WPE) hwy_ix_reset_kernel(const IxParams i
 }
 
 // Observation-only kernel (hwy_observe).
-template <int WPE, int CAP>
-__global__ void __launch_bounds__(CAP, WPE) hwy_ix_observe_kernel(const IxParams ip) {
-  __shared__ IxSharedT<CAP> sh;
+template <int WPE, int CAP, int NT = CAP>
+__global__ void __launch_bounds__(NT, WPE) hwy_ix_observe_kernel(const IxParams ip) {
+  __shared__ IxSharedT<CAP, NT> sh;
   ix_load_table(ip, sh);
   IxVeh me;
   ix_load_vehicle(ip, blockIdx.x, me);

@@ -80,7 +80,8 @@ template <int WPE>
 static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t stream) {
   // with next-episode pre-warming the grid holds a second block per environment (hwy_ix.h: ix_prewarm)
   const int grid = (ip.shadow_meta && ip.s.autoreset && ip.s.full_step) ? 2 * num_envs : num_envs;
-  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
+  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32, 64>), dim3(grid), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
   else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(grid), dim3(64), 0, stream, ip);  // 24 KB of LDS: 2 waves/SIMD
 }
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
@@ -91,7 +92,8 @@ hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, 
   return hipGetLastError();
 }
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream) {
-  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
   else hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }

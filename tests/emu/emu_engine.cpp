@@ -87,7 +87,13 @@ void dispatch(Which which, const StepParams &p, int E) {
       ip.shadow_meta = g_shadow_meta;
       if (which == STEP && p.autoreset && p.full_step) grid = 2 * E;
     }
-    if (p.N <= 32) {  // same dispatch rule as hwy_kernels.hip
+    if (p.N <= 32 && ip.helpers) {  // same dispatch rule as hwy_kernels.hip
+      switch (which) {
+        case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32, 64>(q); }, grid, 64, ip); break;
+        case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 32, 64>(q); }, E, 64, ip); break;
+        case OBSERVE: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_observe_kernel<1, 32>(q); }, E, 32, ip); break;
+      }
+    } else if (p.N <= 32) {
       switch (which) {
         case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32>(q); }, grid, 32, ip); break;
         case RESET: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_reset_kernel<1, 32>(q); }, E, 32, ip); break;

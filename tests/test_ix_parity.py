@@ -109,3 +109,34 @@ def test_policy_steps_vs_reference(backend, name):
         np.testing.assert_allclose(info["speed"][rows][clean, 0], g.z["info_speed"][t][clean], rtol=0, atol=1e-9, err_msg=what)
         live &= ~g.z["terminated"][t].astype(bool)
     eng.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name", ["intersection_default", "intersection_dense"])
+def test_helper_lanes_are_bit_identical_to_the_serial_loops(backend, name, monkeypatch):
+    """N <= 32: threads 32..63 of the wavefront split the lane-table walk, the collision partners and the regulation
+    samples / partners with the vehicle's own thread (hwy_ix.h, IxSharedT).  Same arithmetic, same tie rules: the state
+    after whole policy steps (device clear / spawn included) must equal the 32-thread build's (HWY_IX_HELPERS=0) BIT FOR BIT."""
+    g = GoldenIntersection(name)
+    E = g.E
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 3, size=(6, E, 1)).astype(np.int32)
+    out = []
+    for helpers in ("1", "0"):
+        monkeypatch.setenv("HWY_IX_HELPERS", helpers)
+        cfg = _hwy_config(g, E, host_traffic=False)
+        eng = make_engine(backend, cfg)
+        eng.set_state(ix_engine_state(g, g.state("init"), cfg))
+        rows = []
+        for t in range(acts.shape[0]):
+            obs, reward, term, trunc, info = eng.step(acts[t])
+            st = eng.get_state()
+            rows.append((obs.copy(), reward.copy(), term.copy(), {k: v.copy() for k, v in st.items()}))
+        out.append(rows)
+        eng.close()
+    for (o1, r1, t1, s1), (o0, r0, t0, s0) in zip(*out):
+        np.testing.assert_array_equal(o1, o0)
+        np.testing.assert_array_equal(r1, r0)
+        np.testing.assert_array_equal(t1, t0)
+        for k in s1:
+            np.testing.assert_array_equal(s1[k], s0[k], err_msg=k)
