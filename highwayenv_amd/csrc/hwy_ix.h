@@ -497,8 +497,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         my_cy = sh.traj[HWY_IX_SAMPLES / 2][1][vi];
         for (int k = 0; k < HWY_IX_SAMPLES; ++k) {
           const double dx = sh.traj[k][0][vi] - my_cx, dy = sh.traj[k][1][vi] - my_cy;
-          my_rho = fmax(my_rho, sqrt(dx * dx + dy * dy));
+          my_rho = fmax(my_rho, dx * dx + dy * dy);
         }
+        my_rho = sqrt(my_rho);  // == the maximum of the 11 distances (sqrt is monotone)
       }
       if (half == 0) { sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho; }
       __syncthreads();
@@ -508,8 +509,8 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         const int j = ctz64(m) + half;
         const bool pj = NH > 1 ? ((pm >> j) & 1) != 0 : true;
         const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
-        const bool possible =
-            veh_v && pj && vi != j && sqrt(bdx * bdx + bdy * bdy) <= my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;
+        const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
+        const bool possible = veh_v && pj && vi != j && bdx * bdx + bdy * bdy <= reach * reach;
         if (__ballot(possible) == 0) continue;
         int lane_j;
         if constexpr (NH > 1) lane_j = sh.xb[j] & 255;
@@ -834,14 +835,37 @@ __device__ inline void ix_compact(IxVeh &me, bool keep) {
 #undef MOVE_D
 }
 
+// get_closest_lane_index (road.py:55-71) of ONE wave-uniform pose: thread L measures lane L, the minimum (first one in
+// table order) is picked from the broadcast distances.  Call in wave-uniform control flow.
+template <typename SH>
+__device__ inline int ix_closest_lane_uniform(const IxParams &ip, const SH &sh, double px, double py, double ph) {
+  const int i = threadIdx.x;
+  double d = 0.0;
+  if (i < ip.n_lanes) {
+    double s, lat;
+    ix_local(sh, i, px, py, &s, &lat);
+    const double angle = fabs(wrap_to_pi(ph - ix_heading_at(sh, i, s)));
+    d = fabs(lat) + fmax(s - sh.len[i], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
+  }
+  int best = 0;
+  double bd = wave_bcast(d, 0);
+  for (int L = 1; L < ip.n_lanes; ++L) {
+    const double dl = wave_bcast(d, L);
+    if (dl < bd) { bd = dl; best = L; }
+  }
+  return best;
+}
+
 // IntersectionEnv._spawn_vehicle (intersection_env.py:292-324) on given draws; thread `slot` becomes the new vehicle
 template <typename SH>
 __device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double longitudinal, double position_deviation,
                                 double speed_deviation, double spawn_probability, bool go_straight, double u_spawn,
-                                double u_r0, double u_r1, double z_pos, double z_speed, double u_delta) {
+                                double u_r0, double u_r1, double u_z0, double u_z1, double u_z2, double u_z3,
+                                double u_delta) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   if (u_spawn > spawn_probability) return;  // wave-uniform
+  const double z_pos = ix_normal(u_z0, u_z1), z_speed = ix_normal(u_z2, u_z3);  // (only a spawn pays for the normals)
   // route = choice(range(4), size=2, replace=False): r0 uniform over 4, r1 uniform over the other 3
   int r0 = (int)(u_r0 * 4);
   r0 = r0 > 3 ? 3 : r0;
@@ -861,17 +885,8 @@ __device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double lo
   const u64 pm = __ballot(present);
   const int slot = __popcll(pm);  // the list is compact
   if (slot >= p.N) return;        // capacity reached: no spawn (documented deviation; size num_vehicles accordingly)
+  const int best = ix_closest_lane_uniform(ip, sh, nx, ny, nh);  // lane index: get_closest_lane_index(position, heading)
   if (i == slot) {
-    // lane index: get_closest_lane_index(position, heading)
-    int best = 0;
-    double bd = 0.0;
-    for (int L = 0; L < ip.n_lanes; ++L) {
-      double s, lat;
-      ix_local(sh, L, nx, ny, &s, &lat);
-      const double angle = fabs(wrap_to_pi(nh - ix_heading_at(sh, L, s)));
-      const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-      if (L == 0 || d < bd) { bd = d; best = L; }
-    }
     me = IxVeh{};
     me.x = nx; me.y = ny; me.h = nh; me.v = speed; me.ts = speed;
     me.lane = me.tgt = best;
@@ -898,7 +913,7 @@ __device__ inline void ix_clear_spawn(const IxParams &ip, SH &sh, IxVeh &me, uin
   philox_uniform2(seed, 1000u + step_no, episode, 1u, &u2, &u3);
   philox_uniform2(seed, 1000u + step_no, episode, 2u, &u4, &u5);
   philox_uniform2(seed, 1000u + step_no, episode, 3u, &u6, &u7);
-  ix_spawn(ip, sh, me, 0.0, 1.0, 1.0, ip.spawn_probability, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+  ix_spawn(ip, sh, me, 0.0, 1.0, 1.0, ip.spawn_probability, false, u0, u1, u2, u3, u4, u5, u6, u7);
 }
 
 // IntersectionEnv._make_vehicles (intersection_env.py:232-290) on Philox draws, in three parts so that the warm-up can
@@ -915,7 +930,7 @@ __device__ inline void ix_spawn_initial(const IxParams &ip, SH &sh, uint64_t see
     philox_uniform2(seed, (uint32_t)t, episode, 2u, &u4, &u5);
     philox_uniform2(seed, (uint32_t)t, episode, 3u, &u6, &u7);
     const double lon = n > 1 ? 0.0 + t * ((80.0 - 0.0) / (n - 1)) : 0.0;
-    ix_spawn(ip, sh, me, lon, 1.0, 1.0, 0.6, false, u0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+    ix_spawn(ip, sh, me, lon, 1.0, 1.0, 0.6, false, u0, u1, u2, u3, u4, u5, u6, u7);
   }
 }
 // n_frames of the simulated seconds without the ego (the table walk first: bits / s are not part of the stored state)
@@ -937,7 +952,7 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
     philox_uniform2(seed, 500u, episode, 1u, &u2, &u3);
     philox_uniform2(seed, 500u, episode, 2u, &u4, &u5);
     philox_uniform2(seed, 500u, episode, 3u, &u6, &u7);
-    ix_spawn(ip, sh, me, 60.0, 0.1, 0.0, 1.0, true, 0.0, u1, u2, ix_normal(u3, u4), ix_normal(u5, u6), u7);
+    ix_spawn(ip, sh, me, 60.0, 0.1, 0.0, 1.0, true, 0.0, u1, u2, u3, u4, u5, u6, u7);
   }
   // the ego on ("o0", "ir0", 0) at 60 + 5 * normal(1.0), speed = speed_limit, route to config["destination"]
   double u0, u1;
@@ -950,18 +965,11 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
   const bool keep = present && !(sqrt(dx * dx + dy * dy) < 20);  // "prevent early collisions" (:283-290)
   ix_compact(me, keep);
   const int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
+  const double eh = ix_heading_at(sh, access, 60.0);
+  const int best = ix_closest_lane_uniform(ip, sh, ex, ey, eh);
   if (i == slot && slot < p.N) {
     me = IxVeh{};
-    me.x = ex; me.y = ey; me.h = ix_heading_at(sh, access, 60.0); me.v = sh.lim[access];
-    int best = 0;
-    double bd = 0.0;
-    for (int L = 0; L < ip.n_lanes; ++L) {
-      double s, lat;
-      ix_local(sh, L, ex, ey, &s, &lat);
-      const double angle = fabs(wrap_to_pi(me.h - ix_heading_at(sh, L, s)));
-      const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-      if (L == 0 || d < bd) { bd = d; best = L; }
-    }
+    me.x = ex; me.y = ey; me.h = eh; me.v = sh.lim[access];
     me.lane = me.tgt = best;
     me.route = ix_plan_route(ip, sh, best, ip.destination);
     const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);

@@ -150,8 +150,13 @@ VARIANTS = {
     # intersection kernel (hwy_ix.h): sections removed (timing only)
     "ixbase": [],
     "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],
-    "ixnocoll": [(IX, sub("      for (u64 m = pm; m; m &= m - 1) {  // wave-uniform partner j, ascending", "      for (u64 m = 0; m; m &= m - 1) {"))],
-    "ixnoarc": [(IX, sub("    const bool need = present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);", "    const bool need = false;"))],
+    "ixnocoll": [(IX, sub("      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform, ascending", "      for (u64 m = 0; m; m &= m - 1) {"))],
+    "ixnoarc": [(IX, sub("    const bool need = mine && present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);", "    const bool need = false;"))],
+    "ixnostraight": [(IX, sub("  for (int k = 0; k < ns; k += NH) {  // wave-uniform trip, one lane per half", "  for (int k = 0; k < 0; k += NH) {"))],
+    "ixnomask": [(IX, sub("    for (int L = 0; L < ip.n_lanes; ++L) {\n      const u64 b = __ballot(present && ((bits >> L) & 1));", "    for (int L = 0; L < 0; ++L) {\n      const u64 b = __ballot(present && ((bits >> L) & 1));"))],
+    "ixnoobs": [(IX, sub("    ix_observe(ip, sh, e, me, true);\n", "    ;\n"))],
+    "ixnospawn": [(IX, sub("    if (!ip.host_spawn) ix_clear_spawn(", "    if (false) ix_clear_spawn("))],
+    "ixnointeg": [(IX, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n    }\n    __syncthreads();  // the trajectories", "    }\n    __syncthreads();  // the trajectories"))],
     "ixnoreset": [(IX, sub("  if (p.autoreset && p.st.done[e]) {  // the step after", "  if (false) {  // the step after"))],
     "ixnoact": [(IX, sub("    if (acts) {\n      // follow_road", "    if (false) {\n      // follow_road"))],
     # generic workgroup kernel (hwy_device.h)
