@@ -309,8 +309,6 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     # (road.py:513-529: nothing leaves "1", nothing arrives at "0"), so the flag is accepted there and changes nothing
     if merge and grid:
         raise NotImplementedError("OccupancyGrid is not implemented for the merge networks")
-    if ix and cfg.get("neighbour_vehicles_connected_lanes", False):
-        raise NotImplementedError("neighbour_vehicles_connected_lanes (intersection-v2) is out of scope")
     if not grid and obs.get("order", "sorted") != "sorted":
         raise NotImplementedError("KinematicObservation order='shuffled' is out of scope")
 
@@ -415,7 +413,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         flags |= C_OBS_CLIP
     if obs.get("see_behind", False):
         flags |= C_OBS_SEE_BEHIND
-    if merge and cfg.get("neighbour_vehicles_connected_lanes", False):
+    if (merge or ix) and cfg.get("neighbour_vehicles_connected_lanes", False):
         flags |= C_CONNECTED_LANES
     if merge and not obs.get("include_obstacles", True):
         raise NotImplementedError("KinematicObservation include_obstacles=False is out of scope")

@@ -67,6 +67,7 @@ struct IxVeh {
 };
 
 #define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
+#define HWY_IX_MAX_CONN 8  // connected lanes per lane (4-way junction: 3 + 1)
 
 // CAP = slots per environment the per-vehicle LDS tables are sized for; NT = threads per workgroup (one wavefront).
 //   NT == CAP (32 or 64): thread i == slot i (a 32-thread workgroup still occupies a wavefront, upper half masked off);
@@ -83,6 +84,10 @@ struct IxSharedT {
   int kind[HWY_MAX_GLANES], ldir[HWY_MAX_GLANES], prio[HWY_MAX_GLANES], from[HWY_MAX_GLANES], to[HWY_MAX_GLANES],
       exitl[HWY_MAX_GLANES];
   int ord[HWY_MAX_GLANES], n_straight;  // table indices: straight lanes ascending, then circular lanes ascending
+  // neighbour_vehicles_connected_lanes (road.py:508-529): the lanes searched after lane L itself -- those leaving its end
+  // node, then those arriving at its start node, in table order (every road of this network has one lane)
+  signed char conn[HWY_MAX_GLANES][HWY_IX_MAX_CONN];
+  int n_next[HWY_MAX_GLANES], n_conn[HWY_MAX_GLANES];
   double sx[HWY_MAX_GLANES], sy[HWY_MAX_GLANES], lhead[HWY_MAX_GLANES], dirx[HWY_MAX_GLANES], diry[HWY_MAX_GLANES],
       cx[HWY_MAX_GLANES], cy[HWY_MAX_GLANES], rad[HWY_MAX_GLANES], sph[HWY_MAX_GLANES], len[HWY_MAX_GLANES],
       wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
@@ -150,6 +155,20 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
     sh.sx[i] = l.sx; sh.sy[i] = l.sy; sh.lhead[i] = l.heading; sh.dirx[i] = l.dirx; sh.diry[i] = l.diry;
     sh.cx[i] = l.cx; sh.cy[i] = l.cy; sh.rad[i] = l.radius; sh.sph[i] = l.start_phase; sh.len[i] = l.length;
     sh.wid[i] = l.width; sh.lim[i] = l.speed_limit;
+  }
+  if (i < ip.n_lanes) {
+    int n = 0;
+    if (ip.s.flags & HWY_C_CONNECTED_LANES) {
+      const int to = ip.lanes[i].to_node, from = ip.lanes[i].from_node;
+      for (int K = 0; K < ip.n_lanes && n < HWY_IX_MAX_CONN; ++K)
+        if (ip.lanes[K].from_node == to) sh.conn[i][n++] = (signed char)K;
+      sh.n_next[i] = n;
+      for (int K = 0; K < ip.n_lanes && n < HWY_IX_MAX_CONN; ++K)
+        if (ip.lanes[K].to_node == from) sh.conn[i][n++] = (signed char)K;
+    } else {
+      sh.n_next[i] = 0;
+    }
+    sh.n_conn[i] = n;
   }
   if (i == 0) {
     int n = 0;
@@ -247,17 +266,37 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
   *closest_out = best;
 }
 
-// Road.neighbour_vehicles (road.py:483-547, connected lanes off): the leader on lane L among the members of mask[L]
-// (slot order == list order: `<=` lets a later vehicle at the same s win, like the reference's scan)
+// Road.neighbour_vehicles (road.py:483-547): the leader on lane L among the members of mask[L] (slot order == list
+// order: `<=` lets a later vehicle at the same s win, like the reference's scan).  With connected lanes (n_conn[L] > 0)
+// the members of the lanes leaving L's end (s + L.length) and of those arriving at its start (s - their length) are
+// candidates too; a vehicle that is on several of these lanes counts on the first one of the list.  The reference
+// walks vehicles in the outer loop and the list in the inner one, so the tie rule runs over SLOT order: the walk below
+// keeps, per candidate, its slot, and lets the later slot win an exact tie.
 template <typename SH>
 __device__ inline int ix_front(const SH &sh, int L, int self) {
   const double s = sh.sl[L][self];
   int f = -1;
   double s_front = 0.0;
-  for (u64 m = sh.mask[L] & ~((u64)1 << self); m; m &= m - 1) {
+  u64 seen = (u64)1 << self;
+  for (u64 m = sh.mask[L] & ~seen; m; m &= m - 1) {
     const int j = ctz64(m);
     const double s_v = sh.sl[L][j];
     if (s <= s_v && (f < 0 || s_v <= s_front)) { s_front = s_v; f = j; }
+  }
+  const int nc = sh.n_conn[L];
+  if (nc > 0) {
+    seen |= sh.mask[L];
+    const int nn = sh.n_next[L];
+    for (int k = 0; k < nc; ++k) {
+      const int K = sh.conn[L][k];
+      const double off = k < nn ? sh.len[L] : -sh.len[K];
+      for (u64 m = sh.mask[K] & ~seen; m; m &= m - 1) {
+        const int j = ctz64(m);
+        const double s_v = sh.sl[K][j] + off;
+        if (s <= s_v && (f < 0 || s_v < s_front || (s_v == s_front && j > f))) { s_front = s_v; f = j; }
+      }
+      seen |= sh.mask[K];
+    }
   }
   return f;
 }

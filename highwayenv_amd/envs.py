@@ -446,6 +446,14 @@ class IntersectionEnv(_SingleIntersectionMixin, BatchedIntersectionEnv):
     """Drop-in for ``highway_env.envs.intersection_env.IntersectionEnv`` (``intersection-v0``)."""
 
 
+class BatchedConnectedLaneIntersectionEnv(_ConnectedLaneNeighboursMixin, BatchedIntersectionEnv):
+    """E parallel ``intersection-v2`` environments (ConnectedLaneIntersectionEnv, intersection_env.py:423)."""
+
+
+class ConnectedLaneIntersectionEnv(_SingleIntersectionMixin, BatchedConnectedLaneIntersectionEnv):
+    """Drop-in for ``highway_env.envs.intersection_env.ConnectedLaneIntersectionEnv`` (``intersection-v2``)."""
+
+
 class MergeEnv(_SingleMergeMixin, BatchedMergeEnv):
     """Drop-in for ``highway_env.envs.merge_env.MergeEnv`` (``merge-v0``)."""
 

@@ -60,7 +60,8 @@ typedef struct {
 typedef struct {
   int32_t num_envs, n_slots, n_lanes, n_route, frames_per_step, num_target_speeds, obs_vehicles, obs_features;
   int32_t obs_feature_ids[IX_MAX_FEATURES];
-  int32_t obs_absolute, obs_normalize, obs_clip, obs_see_behind, normalize_reward, offroad_terminal, pad0, pad1;
+  int32_t obs_absolute, obs_normalize, obs_clip, obs_see_behind, normalize_reward, offroad_terminal,
+      connected_lanes /* Road.neighbour_vehicles_connected_lanes (intersection-v2) */, pad1;
   double dt, policy_dt, duration, perception_distance;
   double distance_wanted, time_wanted, comfort_acc_max, comfort_acc_min; /* IDMVehicle class attributes (:243-247) */
   double target_speeds[8];
@@ -380,25 +381,51 @@ static void handle_collisions(veh_t *self, veh_t *other, double dt) {
   }
 }
 
-/* ---- road/road.py:483-547 (neighbour_vehicles_connected_lanes == False) ---------------------------------- */
+/* ---- road/road.py:483-547.  With connected_lanes the search list is the lane, then lane `id` (else 0) of every road
+ * leaving `_to` (offset +lane.length), then lane `id` (else 0) of every road arriving at `_from` (offset -prev.length),
+ * both in graph order == table order; a vehicle counts on the FIRST list entry it is on. ---------------------------------- */
 static void neighbour_vehicles(const road_t *r, const veh_t *vehicle, int lane, int *front, int *rear) {
-  const ix_lane *l = &r->cfg->lanes[lane];
+  const ix_config *c = r->cfg;
+  const ix_lane *l = &c->lanes[lane];
   double s, lat;
   lane_local(l, vehicle->x, vehicle->y, &s, &lat);
   double s_front = 0, s_rear = 0;
   *front = *rear = -1;
+  int search[1 + 2 * IX_MAX_LANES], n_search = 0;
+  double offset[1 + 2 * IX_MAX_LANES];
+  search[n_search] = lane; offset[n_search++] = 0;
+  if (c->connected_lanes) {
+    for (int pass = 0; pass < 2; pass++) {
+      for (int k = 0; k < c->n_lanes; k++) {   /* roads in table order; k = lane 0 of a road */
+        const ix_lane *q = &c->lanes[k];
+        if (q->id != 0) continue;
+        if (pass == 0 ? q->from_node != l->to_node : q->to_node != l->from_node) continue;
+        int n_road = 1;                          /* lanes of the road (from, to) are consecutive, ordered by id */
+        while (k + n_road < c->n_lanes && c->lanes[k + n_road].from_node == q->from_node &&
+               c->lanes[k + n_road].to_node == q->to_node && c->lanes[k + n_road].id == n_road)
+          n_road++;
+        const int pick = k + (l->id < n_road ? l->id : 0);
+        search[n_search] = pick;
+        offset[n_search++] = pass == 0 ? l->length : -c->lanes[pick].length;
+      }
+    }
+  }
   for (int j = 0; j < r->n; j++) {
     const veh_t *v = &r->v[j];
     if (v == vehicle) continue;
-    double s_v, lat_v;
-    lane_local(l, v->x, v->y, &s_v, &lat_v);
-    if (!lane_on_lane(l, v->x, v->y, 1.0)) continue;
-    if (s <= s_v && (*front < 0 || s_v <= s_front)) { s_front = s_v; *front = j; }
-    if (s_v < s && (*rear < 0 || s_v > s_rear)) { s_rear = s_v; *rear = j; }
+    for (int k = 0; k < n_search; k++) {
+      const ix_lane *sl = &c->lanes[search[k]];
+      double s_v, lat_v;
+      lane_local(sl, v->x, v->y, &s_v, &lat_v);
+      if (!lane_on_lane(sl, v->x, v->y, 1.0)) continue;
+      s_v += offset[k];
+      if (s <= s_v && (*front < 0 || s_v <= s_front)) { s_front = s_v; *front = j; }
+      if (s_v < s && (*rear < 0 || s_v > s_rear)) { s_rear = s_v; *rear = j; }
+      break;
+    }
   }
 }
 
-/* ---- vehicle/behavior.py ------------------------------------------------------------------- */
 static double desired_gap(const ix_config *c, const veh_t *ego, const veh_t *front) { /* behavior.py:192-217 */
   double d0 = c->distance_wanted, tau = c->time_wanted, ab = -c->comfort_acc_max * c->comfort_acc_min;
   double ce = cos(ego->heading), se = sin(ego->heading);

@@ -34,7 +34,7 @@ class IxConfig(C.Structure):
                                           "num_target_speeds", "obs_vehicles", "obs_features"]]
                 + [("obs_feature_ids", C.c_int32 * IX_MAX_FEATURES)]
                 + [(k, C.c_int32) for k in ["obs_absolute", "obs_normalize", "obs_clip", "obs_see_behind",
-                                            "normalize_reward", "offroad_terminal", "pad0", "pad1"]]
+                                            "normalize_reward", "offroad_terminal", "connected_lanes", "pad1"]]
                 + [(k, C.c_double) for k in ["dt", "policy_dt", "duration", "perception_distance", "distance_wanted",
                                              "time_wanted", "comfort_acc_max", "comfort_acc_min"]]
                 + [("target_speeds", C.c_double * 8)]
@@ -111,6 +111,7 @@ def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots
     c.arrived_reward = float(config["arrived_reward"])
     c.reward_speed_range[0], c.reward_speed_range[1] = map(float, config["reward_speed_range"])
     c.normalize_reward, c.offroad_terminal = int(config["normalize_reward"]), int(config["offroad_terminal"])
+    c.connected_lanes = int(bool(config.get("neighbour_vehicles_connected_lanes", False)))
     c.spawn_probability = float(config["spawn_probability"])
     return c
 

@@ -36,7 +36,7 @@ from oracle import ref_stub  # noqa: E402
 
 ref_stub.install()
 
-from highway_env.envs.intersection_env import IntersectionEnv  # noqa: E402
+from highway_env.envs.intersection_env import ConnectedLaneIntersectionEnv, IntersectionEnv  # noqa: E402
 from highway_env.road.lane import CircularLane, StraightLane  # noqa: E402
 from highway_env.vehicle.behavior import IDMVehicle  # noqa: E402
 from highway_env.vehicle.controller import MDPVehicle  # noqa: E402
@@ -160,6 +160,10 @@ SCENARIOS = [
                                  "grid_step": [4, 4], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
                                  "features_range": {"x": [-40, 40], "y": [-40, 40], "vx": [-20, 20], "vy": [-20, 20]}}},
          seeds=[31, 32], steps=12, action_seed=44, frames_for=0, n_slots=24),
+    # intersection-v2: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
+    dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
+         config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},
+         seeds=[41, 42, 43, 44], steps=15, action_seed=45, frames_for=2, n_slots=32),
 ]
 
 
@@ -171,7 +175,7 @@ def run_scenario(sc: dict) -> dict:
     out: dict = {"seeds": np.asarray(seeds, np.int64), "actions": actions}
     per_env, tab0 = [], None
     for e, seed in enumerate(seeds):
-        env = IntersectionEnv(dict(sc["config"]))
+        env = (ConnectedLaneIntersectionEnv if sc.get("cls") == "ConnectedLaneIntersectionEnv" else IntersectionEnv)(dict(sc["config"]))
         obs0, _ = env.reset(seed=int(seed))
         tab, index, nodes = lane_table(env.road.network)
         tab0 = tab if tab0 is None else tab0

@@ -156,7 +156,7 @@ def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
 
 
-INTERSECTION = ["intersection_default", "intersection_dense"]   # per-frame fixtures (Kinematics observation)
+INTERSECTION = ["intersection_default", "intersection_dense", "intersection_v2"]   # per-frame fixtures (Kinematics observation)
 INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned"]  # per-step fixtures, OccupancyGrid observation
 
 

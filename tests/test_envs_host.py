@@ -206,16 +206,25 @@ class EmuBatchedIntersection(envs.BatchedIntersectionEnv):
     _engine_factory = staticmethod(_emu_factory)
 
 
+class EmuIntersectionV2(envs._SingleIntersectionMixin, envs.BatchedConnectedLaneIntersectionEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
 @pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
-@pytest.mark.parametrize("e", [0, 2])
-def test_single_intersection_env_dropin_matches_reference_episode(real, e):
+@pytest.mark.parametrize("e,v2", [(0, False), (2, False), (0, True), (3, True)])
+def test_single_intersection_env_dropin_matches_reference_episode(real, e, v2):
     """IntersectionEnv(): reset(seed=s) -- host spawns on the reference's numpy stream, the three warm-up seconds of
     _make_vehicles on the engine -- then golden actions, clearing and spawning on the same stream: the reference's
     obs / reward / terminated / truncated while the episode is live (stop at the first wreck or near-standstill:
     see tests/test_oracle_golden_intersection.py on the ill-conditioned steering of a stopped car)."""
     from tests.golden_util import GoldenIntersection
-    g = GoldenIntersection("intersection_default")
-    env = envs.IntersectionEnv() if real else EmuIntersection()
+    g = GoldenIntersection("intersection_v2" if v2 else "intersection_default")
+    if v2:  # intersection-v2 (ConnectedLaneIntersectionEnv): the fixture's traffic settings on top of the class defaults
+        cls = envs.ConnectedLaneIntersectionEnv if real else EmuIntersectionV2
+        assert cls.default_config()["neighbour_vehicles_connected_lanes"] is True
+        env = cls({k: g.config[k] for k in ("initial_vehicle_count", "spawn_probability", "duration")} | {"max_vehicles": g.N})
+    else:
+        env = envs.IntersectionEnv() if real else EmuIntersection()
     obs, info = env.reset(seed=int(g.z["seeds"][e]))
     assert obs.shape == (15, 7) and obs.dtype == np.float32
     np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)

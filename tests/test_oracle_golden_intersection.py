@@ -117,3 +117,30 @@ def test_oracle_free_running_episodes(name):
         assert_ix_state_close(_sub(st, live), _sub(nxt, live), atol=1e-8, what=f"{what}: after clear/spawn")
         live &= ~g.z["terminated"][t].astype(bool)
     assert compared >= 2 * g.E
+
+
+def test_connected_lanes_flag_is_load_bearing():
+    """intersection-v2 (neighbour_vehicles_connected_lanes, road.py:508-529): without the flag the restatement must NOT
+    reproduce the reference's ConnectedLaneIntersectionEnv frames, i.e. the fixture does exercise the connected search."""
+    g = GoldenIntersection("intersection_v2")
+    assert g.config["neighbour_vehicles_connected_lanes"] is True
+    Ef = g.frames_for
+    cfg = g.ix_config(Ef)
+    assert cfg.connected_lanes == 1
+    cfg.connected_lanes = 0
+    envs = slice(0, Ef)
+    steps0 = g.z["road_steps0"][:Ef]
+    worst = 0.0
+    for step in range(g.steps):
+        for fr in range(g.T):
+            k = step * g.T + fr
+            if fr == 0:
+                st = g.state("init", envs=envs) if step == 0 else g.state("next", step - 1, envs=envs)
+            else:
+                st = g.state("frame", k - 1)
+            st["road_steps"][...] = steps0 + k
+            g.ix.frames(cfg, st, g.actions[step, :Ef, 0] if fr == 0 else None, 1)
+            want = g.state("frame", k)
+            pres = want["present"] != 0
+            worst = max(worst, float(np.abs(st["speed"] - want["speed"])[pres].max()))
+    assert worst > 1e-3
