@@ -1027,110 +1027,100 @@ __device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t 
   ix_spawn_finalise(ip, sh, seed, episode, me);
 }
 
-// Pre-warming block of environment e (blockIdx >= num_envs): advances the shadow copy of e's NEXT episode by one chunk of
-// warm-up frames per launch.  The shadow is a pure function of (seed, episode + 1), so WHEN it is computed cannot change
-// any result; an environment that finishes before its shadow is ready falls back to the inline reset.
-template <typename SH>
-__device__ inline void ix_prewarm(const IxParams &ip, SH &sh, int e) {
-  const StepParams &p = ip.s;
-  const int i = threadIdx.x;
-  if (!p.autoreset || p.st.done[e]) return;  // (the step block of e may be consuming the shadow in this launch)
-  const uint32_t target = p.st.episode[e] + 1u;
-  int32_t *m = ip.shadow_meta + 4 * e;
-  const int total = 3 * (int)rint(1 / p.dt);
-  int prog = m[1], rs = m[2];
-  const bool mine = (uint32_t)m[0] == target;
-  if (mine && prog > total) return;  // ready
-  IxVeh me;
-  const uint64_t seed = p.rp.base_seed + (uint64_t)e;
-  if (!mine) {
-    ix_spawn_initial(ip, sh, seed, target, me);
-    prog = 0;
-    rs = 0;
-  } else {
-    ix_load_vehicle(ip, e, me, true);
-  }
-  const int chunk = p.T < total - prog ? p.T : total - prog;
-  if (chunk > 0) {
-    ix_warm(ip, sh, e, me, chunk, rs);
-    prog += chunk;
-  }
-  if (prog >= total) {
-    ix_spawn_finalise(ip, sh, seed, target, me);
-    prog = total + 1;
-  }
-  ix_store_vehicle(ip, e, me, true);
-  __threadfence();
-  if (i == 0) { m[0] = (int32_t)target; m[1] = prog; m[2] = rs; }
-}
-
 // =============================================================================================================
+// The step kernel.  One workgroup (one wavefront) per environment and, with next-episode pre-warming, a second one
+// (blockIdx >= num_envs) that advances the shadow copy of the environment's NEXT episode by one chunk of warm-up
+// frames per launch: the shadow is a pure function of (seed, episode + 1), so WHEN it is computed cannot change any
+// result; an environment that finishes before its shadow is ready finishes the remaining frames inline.
+//
+// Every role runs the SAME three stages -- set up the vehicle planes, run n frames, finish -- so that the frame loop, the
+// spawn rules and the observation are instantiated ONCE in the kernel: inlined per role they made 250 KB of code, four
+// times the instruction cache a pair of CUs shares.
 template <int WPE, int CAP, int NT = CAP>
 __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip) {
   const StepParams &p = ip.s;
   __shared__ IxSharedT<CAP, NT> sh;
   const int i = threadIdx.x;
-  if ((int)blockIdx.x >= ip.num_envs) {  // wave-uniform: the second half of the grid pre-warms next episodes
-    const int ep = (int)blockIdx.x - ip.num_envs;
-    // most of these blocks have nothing to do (shadow ready, or the environment is being reset right now): leave before
-    // touching LDS
-    if (!p.autoreset || p.st.done[ep]) return;
-    const int32_t *m = ip.shadow_meta + 4 * ep;
-    if ((uint32_t)m[0] == p.st.episode[ep] + 1u && m[1] > 3 * (int)rint(1 / p.dt)) return;
-    ix_load_table(ip, sh);
-    ix_prewarm(ip, sh, ep);
-    return;
+  const bool shadow_block = (int)blockIdx.x >= ip.num_envs;  // wave-uniform, like everything that selects a role below
+  const int e = shadow_block ? (int)blockIdx.x - ip.num_envs : (int)blockIdx.x;
+  const int total = 3 * (int)rint(1 / p.dt);  // frames of the simulated seconds of _make_vehicles
+  const bool resetting = p.autoreset && p.st.done[e];
+  const int32_t *m = ip.shadow_meta ? ip.shadow_meta + 4 * e : nullptr;  // {episode, progress, RegulatedRoad.steps, -}
+  const uint32_t next_episode = p.st.episode[e] + 1u;
+  const bool shadow_mine = m && (uint32_t)m[0] == next_episode;
+  if (shadow_block) {
+    // most of these blocks have nothing to do (the environment is being reset right now -- its step block may be
+    // consuming the shadow in this launch -- or the shadow is ready): leave before touching LDS
+    if (!p.autoreset || resetting) return;
+    if (shadow_mine && m[1] > total) return;
   }
   ix_load_table(ip, sh);
-  const int e = blockIdx.x;
+  const uint64_t seed = p.rp.base_seed + (uint64_t)e;
+
+  // ---- stage 1: whose planes, how many frames, what comes after them -------------------------------------------------
+  enum { STEP, RESPAWN, PREWARM };
+  const int role = shadow_block ? PREWARM : (resetting ? RESPAWN : STEP);
+  int n_run = 0, road_steps = 0, prog = 0;
+  bool from_scratch = false, finalise = false;
+  const int32_t *actions = nullptr;
+  uint32_t step_no = 0;
+  if (role == STEP) {
+    n_run = p.n_frames;
+    actions = p.actions;
+    road_steps = ip.road_steps[e];
+    step_no = (uint32_t)rint(p.st.time[e] / p.policy_dt);  // read before anybody advances the clock
+  } else {
+    const bool usable = shadow_mine && m[1] >= 0;  // (RESPAWN: ready, or partly warmed; PREWARM: in progress)
+    from_scratch = !usable;
+    prog = usable ? m[1] : 0;
+    road_steps = usable ? m[2] : 0;
+    const int left = total - prog;  // < 0: the shadow is ready (challenger and ego included)
+    n_run = left < 0 ? 0 : (role == PREWARM && p.T < left ? p.T : left);
+    finalise = left >= 0 && n_run == left;
+  }
   IxVeh me;
-  int road_steps, bits;
-  if (p.autoreset && p.st.done[e]) {  // the step after terminated | truncated re-spawns the environment
-    const uint32_t episode = p.st.episode[e] + 1u;
-    const int32_t *m = ip.shadow_meta ? ip.shadow_meta + 4 * e : nullptr;
-    if (m && (uint32_t)m[0] == episode && m[1] > 3 * (int)rint(1 / p.dt)) {  // the pre-warmed episode is ready
-      ix_load_vehicle(ip, e, me, true);
-      road_steps = m[2];
-    } else if (m && (uint32_t)m[0] == episode && m[1] >= 0) {  // partly warmed: finish the remaining frames here
-      const int total = 3 * (int)rint(1 / p.dt);
-      ix_load_vehicle(ip, e, me, true);
-      road_steps = m[2];
-      if (total - m[1] > 0) ix_warm(ip, sh, e, me, total - m[1], road_steps);
-      ix_spawn_finalise(ip, sh, p.rp.base_seed + (uint64_t)e, episode, me);
-    } else {
-      ix_spawn_env(ip, sh, e, p.rp.base_seed + (uint64_t)e, episode, me, road_steps);
+  if (from_scratch) ix_spawn_initial(ip, sh, seed, next_episode, me);
+  else ix_load_vehicle(ip, e, me, role != STEP);
+
+  // ---- stage 2: the frames (the table walk first: bits / s are not part of the stored state) ----------------------------
+  if (n_run > 0) {
+    int bits, unused;
+    __syncthreads();
+    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
+    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
+    ix_frames(ip, sh, e, me, n_run, actions, road_steps, bits);
+  }
+  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);
+
+  // ---- stage 3 ---------------------------------------------------------------------------------------------------------
+  if (role == PREWARM) {
+    ix_store_vehicle(ip, e, me, true);
+    __threadfence();
+    if (i == 0) {
+      int32_t *mw = ip.shadow_meta + 4 * e;
+      mw[0] = (int32_t)next_episode; mw[1] = finalise ? total + 1 : prog + n_run; mw[2] = road_steps;
     }
-    ix_observe(ip, sh, e, me, false);
-    ix_store_vehicle(ip, e, me);
-    __threadfence();  // the shadow has been read before `done` is cleared (ix_prewarm starts over once it sees that)
+    return;
+  }
+  if (role == RESPAWN || p.full_step) {
+    __syncthreads();
+    ix_observe(ip, sh, e, me, role == STEP);
+  }
+  if (role == STEP && p.full_step && !ip.host_spawn) ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);
+  ix_store_vehicle(ip, e, me);
+  if (role == RESPAWN) {  // the step after terminated | truncated re-spawned the environment
+    __threadfence();  // the shadow has been read before `done` is cleared (the pre-warming block starts over once it sees that)
     if (i == 0) {
       p.reward[e] = 0.0;
       if (p.info_speed) p.info_speed[e] = sh.lim[ip.access_lane[0]];
       if (p.info_crashed) p.info_crashed[e] = 0;
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
-      p.st.episode[e] = episode;
+      p.st.episode[e] = next_episode;
       p.terminated[e] = 0;
       p.truncated[e] = 0;
-      ip.road_steps[e] = road_steps;
     }
-    return;
   }
-  ix_load_vehicle(ip, e, me);
-  road_steps = ip.road_steps[e];
-  const uint32_t step_no = (uint32_t)rint(p.st.time[e] / p.policy_dt);  // read before anybody advances the clock
-  {
-    int unused;
-    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
-    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
-  }
-  ix_frames(ip, sh, e, me, p.n_frames, p.actions, road_steps, bits);
-  if (p.full_step) {
-    __syncthreads();
-    ix_observe(ip, sh, e, me, true);
-    if (!ip.host_spawn) ix_clear_spawn(ip, sh, me, p.rp.base_seed + (uint64_t)e, p.st.episode[e], step_no);
-  }
-  ix_store_vehicle(ip, e, me);
   if (i == 0) ip.road_steps[e] = road_steps;
 }
 

@@ -105,6 +105,7 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
 }
 }  // namespace emu
 #define __builtin_amdgcn_readlane(v, lane) emu::readlane((v), (lane))
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt(x))
 #define __builtin_amdgcn_ds_permute(addr, v) emu::ds_permute((addr), (v))
