@@ -1,7 +1,8 @@
 // hwy_ix.h -- the fused policy-step kernel for the INTERSECTION scenario (IntersectionEnv,
 // highway_env/envs/intersection_env.py): ONE 64-wide wavefront per environment,
 // thread i == slot i of the vehicle arrays (Road.vehicles order; HWY_F_ABSENT slots after the last vehicle, the list
-// is re-compacted whenever vehicles are cleared).
+// is re-compacted whenever vehicles are cleared); with at most 32 slots the upper half of the wavefront works as
+// helper lanes in the item-parallel loops of a frame (IxSharedT).
 //
 // What differs from the x-aligned formulations (hwy_wave.h, hwy_net.h): the lanes of this network point in every
 // direction and a third of them are circular arcs, so there is no single sort key along "the road".  Instead every
