@@ -470,5 +470,30 @@ class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeG
     """Drop-in for ``highway_env.envs.merge_env.ConnectedLaneMergeGenericEnv`` (``merge-generic-v1``)."""
 
 
+# The ids `highway_env/__init__.py:30-190` registers for this path (gym.make(id) -> the entry-point class): single
+# environment and batched class.  Ids of scenarios outside the path (parking, racetrack, roundabout, ...), the
+# continuous-action and multi-agent intersection ids raise KeyError.
+REGISTRY = {
+    "highway-v0": (HighwayEnv, BatchedHighwayEnv),
+    "highway-fast-v0": (HighwayEnvFast, BatchedHighwayEnvFast),
+    "merge-v0": (MergeEnv, BatchedMergeEnv),
+    "merge-v1": (ConnectedLaneMergeEnv, BatchedConnectedLaneMergeEnv),
+    "merge-generic-v0": (MergeGenericEnv, BatchedMergeGenericEnv),
+    "merge-generic-v1": (ConnectedLaneMergeGenericEnv, BatchedConnectedLaneMergeGenericEnv),
+    "intersection-v0": (IntersectionEnv, BatchedIntersectionEnv),
+    "intersection-v2": (ConnectedLaneIntersectionEnv, BatchedConnectedLaneIntersectionEnv),
+}
+
+
+def make(env_id: str, config: dict = None, **kwargs):
+    """``gym.make(env_id, config=config)`` for the ids of REGISTRY: the drop-in single environment."""
+    return REGISTRY[env_id][0](config, **kwargs)
+
+
+def make_vec(env_id: str, num_envs: int, config: dict = None, **kwargs):
+    """``num_envs`` environments of ``env_id`` stepped by one kernel launch (gymnasium "next-step" auto-reset)."""
+    return REGISTRY[env_id][1](config, num_envs=num_envs, **kwargs)
+
+
 def _copy_config(cfg):
     return copy.deepcopy(cfg)

@@ -288,3 +288,22 @@ def test_intersection_env_with_occupancy_grid_matches_reference(real):
         np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=f"step {t}")
         assert abs(r - g.z["reward"][t, e]) < 1e-9
     env.close()
+
+
+def test_registry_mirrors_the_reference_ids():
+    """highway_env/__init__.py registers id -> entry-point class; the same ids resolve to the drop-in classes here and
+    the class names match the reference's entry points."""
+    ref = {"highway-v0": "HighwayEnv", "highway-fast-v0": "HighwayEnvFast", "merge-v0": "MergeEnv",
+           "merge-v1": "ConnectedLaneMergeEnv", "merge-generic-v0": "MergeGenericEnv",
+           "merge-generic-v1": "ConnectedLaneMergeGenericEnv", "intersection-v0": "IntersectionEnv",
+           "intersection-v2": "ConnectedLaneIntersectionEnv"}
+    assert {k: v[0].__name__ for k, v in envs.REGISTRY.items()} == ref
+    for env_id, (single, batched) in envs.REGISTRY.items():
+        assert issubclass(single, batched)
+        assert single.default_config()["neighbour_vehicles_connected_lanes"] is env_id.endswith(("-v1", "-v2"))
+    with pytest.raises(KeyError):
+        envs.make("parking-v0")
+    with pytest.raises(RuntimeError):  # no GPU in the build container: loud, no fallback
+        if __import__("torch").cuda.is_available():
+            raise RuntimeError("skip")
+        envs.make("merge-v1")

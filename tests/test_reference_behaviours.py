@@ -113,14 +113,17 @@ def test_stop_before_obstacle(backend):
     eng.close()
 
 
-@pytest.mark.parametrize("spec", ["highway-v0", "highway-fast-v0", "merge-v0", "intersection-v0"])
+@pytest.mark.parametrize("spec", ["highway-v0", "highway-fast-v0", "merge-v0", "merge-v1", "merge-generic-v0", "merge-generic-v1",
+                                  "intersection-v0", "intersection-v2"])
 def test_env_step(backend, spec):
     """test_gym.py:65-91: reset, then random actions until terminated / truncated; every observation is finite, has the
     space's shape and (normalised + clipped features) stays in [-1, 1]."""
     from highwayenv_amd import envs
     from tests.test_envs_host import _emu_factory
     base = {"highway-v0": envs.BatchedHighwayEnv, "highway-fast-v0": envs.BatchedHighwayEnvFast,
-            "merge-v0": envs.BatchedMergeEnv, "intersection-v0": envs.BatchedIntersectionEnv}[spec]
+            "merge-v0": envs.BatchedMergeEnv, "merge-v1": envs.BatchedConnectedLaneMergeEnv,
+            "merge-generic-v0": envs.BatchedMergeGenericEnv, "merge-generic-v1": envs.BatchedConnectedLaneMergeGenericEnv,
+            "intersection-v0": envs.BatchedIntersectionEnv, "intersection-v2": envs.BatchedConnectedLaneIntersectionEnv}[spec]
     cls = base if backend == "hip" else type("Emu" + base.__name__, (base,), {"_engine_factory": staticmethod(_emu_factory)})
     env = cls(num_envs=1)
     obs, info = env.reset(seed=3)
