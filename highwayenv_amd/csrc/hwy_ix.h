@@ -97,7 +97,7 @@ struct IxSharedT {
   double x[NT], y[NT], v[NT], c[NT], s[NT];
   double bcx[NT], bcy[NT], brho[NT];  // regulation: a circle around the 11 predicted positions of slot i
   // helper-lane exchange (kNH == 2 only): one double and two ints per thread, plus what a helper needs of its vehicle
-  double xd[kNH > 1 ? NT : 1];
+  double xd[kNH > 1 ? NT : 1], xl[kNH > 1 ? NT : 1];
   int xi[kNH > 1 ? NT : 1], xb[kNH > 1 ? NT : 1];
   double hd[kNH > 1 ? CAP : 1];
   int vw[kNH > 1 ? CAP : 1];
@@ -184,15 +184,17 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
 
 // helper lanes (IxSharedT): combine the two halves' partial (distance, lane) minima and membership bits
 template <typename SH>
-__device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits) {
+__device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double *lat_t = nullptr, bool has_lat = false) {
   if constexpr (SH::kNH > 1) {
     const int t = threadIdx.x, o = t ^ SH::kCap;
-    sh.xd[t] = bd; sh.xi[t] = best; sh.xb[t] = bits;
+    sh.xd[t] = bd; sh.xi[t] = best; sh.xb[t] = bits | (has_lat ? (1 << 30) : 0);
+    if (lat_t) sh.xl[t] = *lat_t;
     __syncthreads();
     const double obd = sh.xd[o];
-    const int ob = sh.xi[o];
-    bits |= sh.xb[o];
+    const int ob = sh.xi[o], obits = sh.xb[o];
+    bits |= obits & ~(1 << 30);
     if (obd < bd || (obd == bd && ob < best)) { bd = obd; best = ob; }
+    if (lat_t && !has_lat && (obits & (1 << 30))) *lat_t = sh.xl[o];  // the other half walked my target lane
     __syncthreads();
   }
 }
@@ -202,10 +204,11 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits) {
 // the lanes that can matter -> sh.sl[L][i].  Straight lanes first; a CircularLane costs an atan2, and it can neither hold
 // me (|lateral| > width / 2 + 1) nor be my closest lane (its distance is at least |lateral| = |radius - r|, which already
 // exceeds the best distance found) nor be my target lane for most vehicles most of the time: when that is so for the
-// whole wave the arc is skipped.  sl[L][i] is only read for members of L, for my own lane and for my target lane.
+// whole wave the arc is skipped.  sl[L][i] is only read for members of L, for my own lane and for my target lane; the
+// lateral coordinate on the target lane comes back too (the steering of the next frame needs exactly this projection).
 template <typename SH>
 __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, double x, double y, double h, int tgt,
-                                    int *bits_out, int *closest_out) {
+                                    int *bits_out, int *closest_out, double *lat_tgt_out) {
   constexpr int NH = SH::kNH;
   const int t = threadIdx.x, vi = t & (SH::kCap - 1), half = NH > 1 ? t / SH::kCap : 0;
   if constexpr (NH > 1) {  // a helper works on the body of vehicle t & 31
@@ -217,7 +220,8 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
     tgt = w & 255; present = (w & 256) != 0;
   }
   int bits = 0, best = 0x7fffffff;
-  double bd = __builtin_inf();
+  double bd = __builtin_inf(), lat_t = 0.0;  // lat_t: my lateral coordinate on my target lane (the next frame steers by it)
+  bool has_lat = false;
   const int ns = sh.n_straight, n = ip.n_lanes;
   for (int k = 0; k < ns; k += NH) {  // wave-uniform trip, one lane per half
     const bool mine = k + half < ns;
@@ -232,6 +236,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
       bits |= on ? (1 << L) : 0;
       sh.sl[L][vi] = s;
       if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
+      if (L == tgt) { lat_t = lat; has_lat = true; }
     }
   }
   {
@@ -260,11 +265,13 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
       bits |= on ? (1 << L) : 0;
       sh.sl[L][vi] = s;
       if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
+      if (L == tgt) { lat_t = lat; has_lat = true; }
     }
   }
-  ix_xchg(sh, bd, best, bits);
-  *bits_out = bits;
+  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);
+  *bits_out = present ? bits : 0;  // (`present` is the vehicle's: a helper lane returns its vehicle's bits)
   *closest_out = best;
+  *lat_tgt_out = lat_t;
 }
 
 // Road.neighbour_vehicles (road.py:483-547): the leader on lane L among the members of mask[L] (slot order == list
@@ -413,7 +420,7 @@ __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &
 // ---- n_frames x { [meta-action]; Road.act(); RegulatedRoad.step(dt) } on the wave's registers + LDS --------------
 template <typename SH>
 __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, int n_frames, const int32_t *actions,
-                                 int &road_steps, int &bits) {
+                                 int &road_steps, int &bits, double &lat_tgt) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const int every = (int)(1 / p.dt / 2);  // int(1 / dt / REGULATION_FREQUENCY) (regulation.py:38)
@@ -434,9 +441,20 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     }
     // ---- B. membership masks + snapshot ---------------------------------------------------------------------------
     __syncthreads();
-    for (int L = 0; L < ip.n_lanes; ++L) {
-      const u64 b = __ballot(present && ((bits >> L) & 1));
-      if (i == 0) sh.mask[L] = b;
+    if constexpr (SH::kNH > 1) {  // helper lanes carry their vehicle's bits: one ballot yields the masks of two lanes
+      const int HL = (ip.n_lanes + 1) >> 1, half = i / SH::kCap;
+      for (int L = 0; L < HL; ++L) {
+        const u64 b = __ballot((bits >> (L + half * HL)) & 1);
+        if (i == 0) {
+          sh.mask[L] = b & 0xffffffffull;
+          if (L + HL < ip.n_lanes) sh.mask[L + HL] = b >> 32;
+        }
+      }
+    } else {
+      for (int L = 0; L < ip.n_lanes; ++L) {
+        const u64 b = __ballot((bits >> L) & 1);
+        if (i == 0) sh.mask[L] = b;
+      }
     }
     const double ch = me.ch, shh = me.sh;
     sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = ch; sh.s[i] = shh;
@@ -452,16 +470,17 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       // follow_road (controller.py:135-143): AbstractLane.after_end on the target lane (lane.py:120-125)
       if (sh.sl[me.tgt][i] > sh.len[me.tgt] - 5.0 / 2) {
         me.tgt = ix_next_lane(ip, sh, me.tgt, me);
-        // my coordinate on the new target lane (the table walk skipped it if I was not near it; only I read this slot
+        // my coordinates on the new target lane (the table walk skipped it if I was not near it; only I read this slot
         // unless I am a member of that lane, in which case the walk wrote the same value)
         double s_new, lat_new;
         ix_local(sh, me.tgt, me.x, me.y, &s_new, &lat_new);
         sh.sl[me.tgt][i] = s_new;
+        lat_tgt = lat_new;
       }
       if (!controlled && me.lane == me.tgt && HWY_LC_DELAY < me.timer) me.timer = 0.0;  // behavior.py:246-248
       {
-        double s_t, lat_t;
-        ix_local(sh, me.tgt, me.x, me.y, &s_t, &lat_t);
+        // target_lane.local_coordinates(position): the projection the table walk made after the last integration
+        const double s_t = sh.sl[me.tgt][i], lat_t = lat_tgt;
         const double lane_future_heading = ix_heading_at(sh, me.tgt, s_t + me.v * (0.5 * 0.2));
         tb = net_steer_tan_beta(lat_t, lane_future_heading, me.h, fast_rcp(not_zero(me.v)));
       }
@@ -622,9 +641,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     __syncthreads();  // the trajectories (if any) are dead: sl[][] is written again
     {
       int cl_new, bits_new;  // on_state_update + the next frame's membership bits and s table
-      ix_lane_pass(ip, sh, present, me.x, me.y, me.h, me.tgt, &bits_new, &cl_new);
+      ix_lane_pass(ip, sh, present, me.x, me.y, me.h, me.tgt, &bits_new, &cl_new, &lat_tgt);
       if (present) me.lane = cl_new;
-      bits = present ? bits_new : 0;
+      bits = bits_new;  // (0 for an empty slot; a helper lane keeps its vehicle's bits for the mask ballots)
     }
 
     // ---- F. collisions (road.py:477-481, objects.py:92-138): every pair; the highest partner slot's impact stays ----
@@ -977,10 +996,10 @@ __device__ inline void ix_spawn_initial(const IxParams &ip, SH &sh, uint64_t see
 template <typename SH>
 __device__ inline void ix_warm(const IxParams &ip, SH &sh, int e, IxVeh &me, int n_frames, int &road_steps) {
   int bits, unused;
+  double lat_tgt;
   __syncthreads();
-  ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
-  bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
-  ix_frames(ip, sh, e, me, n_frames, nullptr, road_steps, bits);
+  ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused, &lat_tgt);
+  ix_frames(ip, sh, e, me, n_frames, nullptr, road_steps, bits, lat_tgt);
 }
 template <typename SH>
 __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t seed, uint32_t episode, IxVeh &me) {
@@ -1086,10 +1105,10 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
   // ---- stage 2: the frames (the table walk first: bits / s are not part of the stored state) ----------------------------
   if (n_run > 0) {
     int bits, unused;
+    double lat_tgt;
     __syncthreads();
-    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused);
-    bits = (me.flags & HWY_F_ABSENT) ? 0 : bits;
-    ix_frames(ip, sh, e, me, n_run, actions, road_steps, bits);
+    ix_lane_pass(ip, sh, !(me.flags & HWY_F_ABSENT), me.x, me.y, me.h, me.tgt, &bits, &unused, &lat_tgt);
+    ix_frames(ip, sh, e, me, n_run, actions, road_steps, bits, lat_tgt);
   }
   if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);
 
