@@ -891,6 +891,24 @@ int orc_ix_frames(const ix_config *c, ix_state *st, const int32_t *actions, int3
   return 0;
 }
 
+/* Road.neighbour_vehicles(vehicle = the slot-th PRESENT vehicle of environment e, lane_index = table index `lane`) ->
+ * list positions of the preceding / following vehicle or -1 (tests/test_oracle_reference_neighbours.py) */
+int orc_ix_neighbours(const ix_config *c, const ix_state *st, int32_t e, int32_t slot, int32_t lane, int32_t *front,
+                      int32_t *rear) {
+  veh_t *buf = (veh_t *)malloc(sizeof(veh_t) * (size_t)c->n_slots);
+  road_t r = {c, buf, 0, 0};
+  r.n = load_env(c, st, e, buf);
+  int rc = -1;
+  if (slot >= 0 && slot < r.n && lane >= 0 && lane < c->n_lanes) {
+    int f, b;
+    neighbour_vehicles(&r, &buf[slot], lane, &f, &b);
+    *front = f; *rear = b;
+    rc = 0;
+  }
+  free(buf);
+  return rc;
+}
+
 int orc_ix_observe(const ix_config *c, const ix_state *st, float *obs) {
   veh_t *buf = (veh_t *)malloc(sizeof(veh_t) * (size_t)c->n_slots);
   size_t per = ix_obs_len(c);

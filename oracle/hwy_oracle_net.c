@@ -674,6 +674,23 @@ int orc_net_frames(const hwy_config *c, hwy_state *st, const int32_t *actions, i
   return 0;
 }
 
+/* Road.neighbour_vehicles(vehicle = slot `slot` of environment e, lane_index = table index `lane`) -> slot indices of the
+ * preceding / following vehicle or -1 (the checker of tests/test_oracle_reference_neighbours.py, which restates the
+ * reference's own tests/road/test_neighbour_vehicles.py) */
+int orc_net_neighbours(const hwy_config *c, const hwy_state *st, int32_t e, int32_t slot, int32_t lane, int32_t *front,
+                       int32_t *rear) {
+  int N = c->num_vehicles;
+  if (e < 0 || e >= c->num_envs || slot < 0 || slot >= N || lane < 0 || lane >= c->net_lanes) return HWY_ERR_INVALID_ARG;
+  ent_t *v = (ent_t *)malloc(sizeof(ent_t) * (size_t)N);
+  load_env(c, st, e, v);
+  net_t r = {c, v, N};
+  int f, b;
+  neighbour_vehicles(&r, &v[slot], lane, &f, &b);
+  *front = f; *rear = b;
+  free(v);
+  return 0;
+}
+
 int orc_net_observe(const hwy_config *c, const hwy_state *st, float *obs) {
   int N = c->num_vehicles, A = c->num_agents;
   size_t VF = (size_t)c->obs_vehicles * c->obs_features;

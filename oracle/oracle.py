@@ -56,6 +56,16 @@ def frames(cfg: _abi.HwyConfig, st: dict, actions, n_frames: int) -> None:
     assert rc == 0, rc
 
 
+def net_neighbours(cfg: _abi.HwyConfig, st: dict, e: int, slot: int, lane: int) -> tuple:
+    """Road.neighbour_vehicles(vehicle, lane_index) on a road-network scenario: (front slot | None, rear slot | None)."""
+    f, b = C.c_int32(-1), C.c_int32(-1)
+    s = _abi.state_struct(st)
+    rc = lib().orc_net_neighbours(C.byref(cfg), C.byref(s), C.c_int32(e), C.c_int32(slot), C.c_int32(lane),
+                                  C.byref(f), C.byref(b))
+    assert rc == 0, rc
+    return (None if f.value < 0 else f.value), (None if b.value < 0 else b.value)
+
+
 def observe(cfg: _abi.HwyConfig, st: dict) -> np.ndarray:
     obs = np.zeros((cfg.num_envs, cfg.num_agents, *_abi.obs_shape(cfg)), np.float32)
     s = _abi.state_struct(st)

@@ -151,6 +151,16 @@ def frames(cfg: IxConfig, st: dict, actions, n_frames: int) -> None:
     assert rc == 0, rc
 
 
+def neighbours(cfg: IxConfig, st: dict, e: int, slot: int, lane: int) -> tuple:
+    """Road.neighbour_vehicles(vehicle, lane_index): (front | None, rear | None) as positions in the vehicle list."""
+    f, b = C.c_int32(-1), C.c_int32(-1)
+    s = _struct(st)
+    rc = _lib().orc_ix_neighbours(C.byref(cfg), C.byref(s), C.c_int32(e), C.c_int32(slot), C.c_int32(lane),
+                                  C.byref(f), C.byref(b))
+    assert rc == 0, rc
+    return (None if f.value < 0 else f.value), (None if b.value < 0 else b.value)
+
+
 def obs_shape(cfg: IxConfig) -> tuple:
     return (cfg.obs_features, cfg.grid_shape[0], cfg.grid_shape[1]) if cfg.obs_type == 1 else (cfg.obs_vehicles, cfg.obs_features)
 
