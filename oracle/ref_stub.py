@@ -129,6 +129,7 @@ class _RecordConstructorArgs:
 
 def install() -> None:
     """Put the stubs in sys.modules and the reference on sys.path (idempotent)."""
+    sys.dont_write_bytecode = True  # /root/reference is read-only for us: importing it must not leave __pycache__ behind
     if "gymnasium" not in sys.modules:
         gym = types.ModuleType("gymnasium")
         gym.Env = _Env
