@@ -194,3 +194,51 @@ def test_neighbours_across_connected_segments(backend, connected):
     assert bool(got["target_lane"][3, 1] == BC1) == connected                 # the unseen follower lets the change through
     assert bool(got["target_lane"][3, 1] == BC0) != connected
     eng.close()
+
+
+def test_network(backend):
+    """/root/reference/tests/road/test_road.py:10-41: a ControlledVehicle without a route on a diamond of five straight lanes
+    (0->1, 1->2, 2->0, 1->3, 3->0) keeps choosing the closest lane leaving each node (RoadNetwork.next_lane, road.py:
+    73-133): its target lane changes at least 3 times in 20 s at 15 Hz.  The lane table of the intersection scenario is
+    replaced by the diamond through the ABI's general lane table (hwy_config.gnet); the oracle must follow frame by frame."""
+    from highwayenv_amd import intersection as hix
+    from oracle import oracle_ix
+    from tests.golden_util import ix_oracle_config, ix_oracle_state
+    cfg = hix.intersection_default_config()
+    cfg.update({"host_traffic": True, "max_vehicles": 4})
+    c = _abi.make_config(cfg, 1, scenario="intersection")
+    oc = ix_oracle_config(cfg, c, 1)
+    diamond = [((0, 0), (10, 0), 0, 1), ((10, 0), (5, 5), 1, 2), ((5, 5), (0, 0), 2, 0), ((10, 0), (5, -5), 1, 3),
+               ((5, -5), (0, 0), 3, 0)]
+    c.gnet_lanes = oc.n_lanes = len(diamond)
+    for q in range(4):  # (the spawn entries of the intersection: unused with host traffic, but validated by hwy_create)
+        c.access_lane[q] = c.exit_of[q] = 0
+    for k, (s, e, f, t) in enumerate(diamond):
+        d = np.asarray(e, float) - np.asarray(s, float)
+        length = float(np.linalg.norm(d))
+        d = d / length
+        for g in (c.gnet[k], oc.lanes[k]):
+            g.kind, g.direction, g.priority, g.forbidden, g.from_node, g.to_node, g.exit_lane = 0, 0, 0, 0, f, t, 0
+            g.sx, g.sy, g.heading, g.dirx, g.diry = float(s[0]), float(s[1]), float(np.arctan2(d[1], d[0])), float(d[0]), float(d[1])
+            g.length, g.width, g.speed_limit = length, 4.0, 20.0   # StraightLane defaults (lane.py:150-181)
+        oc.lanes[k].id = 0
+    st = _abi.alloc_state_ix(1, c.num_vehicles)
+    # ControlledVehicle(road, [5, 0], heading=0, target_speed=2): speed 0, lane index (0, 1, 0), no route
+    st["x"][0, 0], st["y"][0, 0], st["target_speed"][0, 0] = 5.0, 0.0, 2.0
+    st["flags"][0, 0] = _abi.F_CONTROLLED | _abi.F_CHECK_COLLISIONS
+    ref = ix_oracle_state(st, c)
+    eng = make_engine(backend, c)
+    eng.set_state(st)
+    assert eng.get_state()["lane"][0, 0] == 0
+    lane_changes, tgt = 0, 0
+    for _ in range(int(20 * FPS)):
+        eng.step_frames(None, 1)
+        oracle_ix.frames(oc, ref, None, 1)
+        got = eng.get_state()
+        assert abs(got["x"][0, 0] - ref["x"][0, 0]) < 1e-7 and abs(got["y"][0, 0] - ref["y"][0, 0]) < 1e-7
+        assert got["target_lane"][0, 0] == ref["target_lane"][0, 0]
+        if got["target_lane"][0, 0] != tgt:
+            tgt = got["target_lane"][0, 0]
+            lane_changes += 1
+    assert lane_changes >= 3
+    eng.close()
