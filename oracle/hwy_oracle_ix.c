@@ -590,6 +590,13 @@ static int has_corner_inside(double c1x, double c1y, double l1, double w1, doubl
   }
   return any;
 }
+/* utils.rotated_rectangles_intersect (utils.py:99-116); exported for the reference's own known-answer vectors
+ * (tests/test_utils.py:19-28 -> tests/test_oracle_reference_neighbours.py) */
+int orc_ix_rotated_rectangles_intersect(double c1x, double c1y, double l1, double w1, double a1, double c2x, double c2y,
+                                        double l2, double w2, double a2) {
+  return has_corner_inside(c1x, c1y, l1, w1, a1, c2x, c2y, l2, w2, a2) ||
+         has_corner_inside(c2x, c2y, l2, w2, a2, c1x, c1y, l1, w1, a1);
+}
 /* RegulatedRoad.is_conflict_possible (regulation.py:88-111), predict_trajectory_constant_speed (controller.py:236-253) */
 static int is_conflict_possible(const ix_config *c, const veh_t *v1, const veh_t *v2) {
   double s1, s2, lat;

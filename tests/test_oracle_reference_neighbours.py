@@ -174,3 +174,21 @@ def test_front_on_curve_segment():
         st["present"][0, i], st["x"][0, i], st["y"][0, i], st["speed"][0, i] = 1, x, y, 10.0
         st["lane"][0, i] = st["target_lane"][0, i] = lane
     assert oracle_ix.neighbours(c, st, 0, 0, 0)[0] == 1
+
+
+def test_rotated_rectangles_intersect():
+    """/root/reference/tests/test_utils.py:19-28: the five known-answer vectors of utils.rotated_rectangles_intersect, the
+    predicate RegulatedRoad.is_conflict_possible rests on (regulation.py:103-108)."""
+    lib = oracle.lib()
+    lib.orc_ix_rotated_rectangles_intersect.argtypes = [C.c_double] * 10
+    lib.orc_ix_rotated_rectangles_intersect.restype = C.c_int
+
+    def rri(r1, r2):
+        (c1, l1, w1, a1), (c2, l2, w2, a2) = r1, r2
+        return bool(lib.orc_ix_rotated_rectangles_intersect(c1[0], c1[1], l1, w1, a1, c2[0], c2[1], l2, w2, a2))
+
+    assert rri(([12.86076812, 28.60182391], 5.0, 2.0, -0.4675779906495494), ([9.67753944, 28.90585412], 5.0, 2.0, -0.3417019364473201))
+    assert rri(([0, 0], 2, 1, 0), ([0, 1], 2, 1, 0))
+    assert not rri(([0, 0], 2, 1, 0), ([0, 2.1], 2, 1, 0))
+    assert not rri(([0, 0], 2, 1, 0), ([1, 1.1], 2, 1, 0))
+    assert rri(([0, 0], 2, 1, np.pi / 4), ([1, 1.1], 2, 1, 0))

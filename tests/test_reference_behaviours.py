@@ -242,3 +242,19 @@ def test_network(backend):
             lane_changes += 1
     assert lane_changes >= 3
     eng.close()
+
+
+def test_occupancy_grid_shape_no_uint8_overflow(backend):
+    """/root/reference/tests/envs/test_observations.py:27-43: a grid with more than 255 cells along an axis keeps its shape
+    (the reference once cast grid_shape to uint8): highway-v0 with a 600 m x 20 m grid of 2 m cells -> (4, 300, 10)."""
+    from highwayenv_amd import envs
+    from tests.test_envs_host import _emu_factory
+    base = envs.HighwayEnv
+    cls = base if backend == "hip" else type("EmuHighwayEnv", (base,), {"_engine_factory": staticmethod(_emu_factory)})
+    env = cls({"observation": {"type": "OccupancyGrid", "grid_size": [[-300, 300], [-10, 10]], "grid_step": [2, 2]}})
+    obs, _ = env.reset(seed=0)
+    assert env.single_observation_shape == (4, 300, 10) and obs.shape == (4, 300, 10) and obs.dtype == np.float32
+    assert obs[0].sum() >= 1 and obs[3].sum() > 0   # the ego's own cell; the road layer
+    obs, reward, terminated, truncated, info = env.step(1)
+    assert obs.shape == (4, 300, 10) and np.isfinite(obs).all()
+    env.close()
