@@ -147,6 +147,21 @@ VARIANTS = {
     "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
+    # wave timeline: every wavefront of hwy_step_wave_kernel writes its start / end s_memrealtime (100 MHz) and HW_ID /
+    # XCC_ID over the first four observation words of its environment (tools/wave_timeline.py reads them)
+    "wtimeline": [(W, sub("  typedef EnvBlock<1> B;\n  __shared__ WaveShared sh;\n  const int e = blockIdx.x, i = threadIdx.x;\n  const int N = p.N;",
+                          "  typedef EnvBlock<1> B;\n  __shared__ WaveShared sh;\n  const int e = blockIdx.x, i = threadIdx.x;\n"
+                          "  const unsigned long long tl_t0 = wall_clock64();\n"
+                          "  const unsigned tl_hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), tl_xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
+                          "  const int N = p.N;")),
+                  (W, sub("  store_vehicle<1>(q, e, me, false);\n}",
+                          "  store_vehicle<1>(q, e, me, false);\n"
+                          "  if (q.obs && i == 0) {\n"
+                          "    __builtin_amdgcn_s_waitcnt(0);\n"
+                          "    const unsigned long long tl_t1 = wall_clock64();\n"
+                          "    unsigned *o = (unsigned *)(q.obs + (size_t)e * q.A * q.V * q.F);\n"
+                          "    o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc;\n"
+                          "  }\n}"))],
     # intersection kernel (hwy_ix.h): sections removed (timing only)
     "ixbase": [],
     "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],
