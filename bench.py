@@ -160,34 +160,8 @@ def cpu_baseline_intersection(cfg_dict, budget_s: float = 12.0):
     eng.reset(base_seed=11)
     st_h = eng.get_state()
     eng.close()
-    tab = hix.table_from_config(cfg)
-    lane_tab = {k: tab[k] for k in tab}
-    lane_tab["ex"] = lane_tab["ey"] = lane_tab["end_phase"] = np.zeros_like(tab["sx"])
-    lane_tab["id"] = np.zeros_like(tab["kind"])
-    oc = oracle_ix.make_config(cfg_dict, lane_tab, hix.NODE_NAMES, E, cfg.num_vehicles, 4)
-
-    def to_oracle(h):
-        st = oracle_ix.alloc_state(E, cfg.num_vehicles, 4)
-        for k in oracle_ix.STATE_F64:
-            st[k][...] = h[k]
-        f = h["flags"]
-        st["present"][...] = (f & _abi.F_ABSENT) == 0
-        for k, bit in (("crashed", _abi.F_CRASHED), ("has_impact", _abi.F_HAS_IMPACT), ("controlled", _abi.F_CONTROLLED),
-                       ("is_yielding", _abi.F_YIELDING)):
-            st[k][...] = (f & bit) != 0
-        for k in ("lane", "target_lane", "speed_index"):
-            st[k][...] = h[k]
-        for e in range(E):
-            for i in range(cfg.num_vehicles):
-                r = hix.route_unpack(int(h["route"][e, i])) if st["present"][e, i] else []
-                st["route_len"][e, i] = len(r)
-                for q, l in enumerate(r):
-                    st["route_from"][e, i, q], st["route_to"][e, i, q] = tab["from_node"][l], tab["to_node"][l]
-                    st["route_id"][e, i, q] = -1 if q else 0
-        st["road_steps"][...] = h["road_steps"]
-        return st
-
-    st0 = to_oracle(st_h)
+    oc = oracle_ix.config_from_engine(cfg_dict, cfg, E)
+    st0 = oracle_ix.state_from_engine(st_h, cfg)
     rng = np.random.default_rng(3)
     steps_done, t_used = 0, 0.0
     st = {k: v.copy() for k, v in st0.items()}
@@ -227,7 +201,10 @@ def main() -> None:
                          "per env); merge = merge-v0 defaults; intersection = BASELINE config 4's world model "
                          "(intersection-v0, 30 vehicle slots, OccupancyGrid 4 x 11 x 11 obs; use --envs-per-gpu 2048); intersection_kin = "
                          "the same with intersection-v0's default Kinematics 15 x 7 observation")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds); repeatable")
     args = ap.parse_args()
+    tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
 
     import torch
     import torch.distributed as dist
@@ -279,7 +256,7 @@ def main() -> None:
         if args.workload == "v0_n100":
             cfg_dict.update({"vehicles_count": 100})
     E = args.envs_per_gpu
-    cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario)
+    cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario, tuning=tuning)
     N, A = cfg.num_vehicles, cfg.num_agents
     spawn_kw = ({"ego_spacing": cfg_dict["ego_spacing"], "vehicles_density": cfg_dict["vehicles_density"]}
                 if scenario == "highway" else {})

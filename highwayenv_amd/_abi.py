@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-HWY_ABI_VERSION = 4
+HWY_ABI_VERSION = 5
 HWY_MAX_AGENTS = 16
 HWY_MAX_FEATURES = 16
 HWY_MAX_TARGET_SPEEDS = 8
@@ -131,6 +131,13 @@ class HwyConfig(C.Structure):
         ("idm_comfort_acc_max", C.c_double),
         ("idm_comfort_acc_min", C.c_double),
         ("gnet", HwyGLane * HWY_MAX_GLANES),
+        # tuning (ABI v5): 0 = the engine's own choice
+        ("tune_block_kernel", C.c_int32),
+        ("tune_waves_per_eu", C.c_int32),
+        ("tune_ix_no_helpers", C.c_int32),
+        ("tune_ix_no_prewarm", C.c_int32),
+        ("tune_extra_lds", C.c_int32),
+        ("tune_reserved", C.c_int32 * 3),
     ]
 
 
@@ -264,8 +271,15 @@ def agent_indices(vehicles_count: int, controlled: int) -> list:
     return idx
 
 
-def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str = "highway") -> HwyConfig:
+TUNING_KEYS = ("block_kernel", "waves_per_eu", "ix_no_helpers", "ix_no_prewarm", "extra_lds")
+
+
+def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str = "highway",
+                tuning: dict | None = None) -> HwyConfig:
     """Flatten a reference-style config dict into the POD the engine takes.
+
+    ``tuning``: optional ``hwy_config.tune_*`` knobs (keys of ``TUNING_KEYS``; also read from ``config["tuning"]``);
+    they select kernel variants and never change a result.
 
     ``scenario``: "highway" (HighwayEnv / HighwayEnvFast), "merge" (MergeEnv) or "merge-generic"
     (MergeGenericEnv) -- the latter two are filled in by ``highwayenv_amd.merge``.
@@ -315,6 +329,10 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     c = HwyConfig()
     c.abi_version = HWY_ABI_VERSION
     c.num_envs = int(num_envs)
+    for key, val in {**(cfg.get("tuning") or {}), **(tuning or {})}.items():
+        if key not in TUNING_KEYS:
+            raise KeyError(f"unknown tuning knob {key!r} (known: {TUNING_KEYS})")
+        setattr(c, "tune_" + key, int(val))
     A = int(cfg.get("controlled_vehicles", 1))
     c.num_agents = A
     if not (1 <= A <= HWY_MAX_AGENTS):

@@ -13,7 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhwy_engine.so")
 SOURCES = ["hwy_kernels.hip", "hwy_engine.hip"]
-HEADERS = ["hwy_device.h", "hwy_wave.h", "hwy_math.h", "hwy_launch.h", "hwy_params.h", os.path.join("..", "..", "include", "hwy_engine.h")]
+import glob
+
+# every header the two translation units can include: csrc/*.h (hwy_device.h, hwy_wave.h, hwy_net.h, hwy_ix.h, ...)
+# plus the public ABI header -- globbed so that a new kernel header can never be forgotten by is_stale()
+HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"))) + [
+    os.path.join("..", "..", "include", "hwy_engine.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 

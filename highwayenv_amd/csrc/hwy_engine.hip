@@ -26,8 +26,8 @@ struct hwy_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int pitch = 0;
-  bool force_block_kernel = false;  // HWY_STEP_KERNEL=block: use the generic workgroup kernel even for N <= 64
-  int waves_per_eu = 3;  // register-allocation variant of the step kernel (tuning: HWY_STEP_WAVES_PER_EU)
+  bool force_block_kernel = false;  // hwy_config.tune_block_kernel: use the generic workgroup kernel even for N <= 64
+  int waves_per_eu = 3;  // register-allocation variant of the step kernel (hwy_config.tune_waves_per_eu)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -117,6 +117,8 @@ static int validate(const hwy_config *c, std::string &why) {
     if (c->agent_index[a] < 0 || c->agent_index[a] >= c->num_vehicles) BAD("agent_index[%d] out of range", a);
   if (c->lanes_count < 1 || c->lanes_count > HWY_MAX_LANES) BAD("lanes_count must be in [1,%d]", HWY_MAX_LANES);
   if (c->frames_per_step < 0) BAD("frames_per_step must be >= 0");
+  if (c->tune_extra_lds < 0 || c->tune_extra_lds > 65536) BAD("tune_extra_lds must be in [0,65536]");
+  if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
   if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");
   if (c->obs_type == HWY_OBS_OCCUPANCY_GRID) {
@@ -207,7 +209,8 @@ static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p) {
     hwy::net_params_from_config(eng->cfg, p, np);
     return hwy::launch_net_step(np, eng->cfg.num_envs, eng->stream, eng->waves_per_eu);
   }
-  return hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel);
+  return hwy::launch_step(p, eng->cfg.num_envs, eng->stream, eng->waves_per_eu, eng->force_block_kernel,
+                          eng->cfg.tune_extra_lds);
 }
 static hipError_t launch_reset_any(const hwy_engine *eng, const StepParams &p) {
   if (is_ix(eng)) {
@@ -257,21 +260,17 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->cfg = *cfg;
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
-  if (const char *k = std::getenv("HWY_STEP_KERNEL")) eng->force_block_kernel = std::strcmp(k, "block") == 0;
+  eng->force_block_kernel = cfg->tune_block_kernel != 0;
   // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
   // intersection kernel with helper lanes (N <= 32, hwy_ix.h): 208 VGPRs, 2 waves/SIMD is the faster build at every batch
-  // size measured (a 3rd wave costs 125 spilled registers).  Without them (N > 32, or HWY_IX_HELPERS=0): 176 VGPRs fit 2
+  // size measured (a 3rd wave costs 125 spilled registers).  Without them (N > 32, or tune_ix_no_helpers): 176 VGPRs fit 2
   // waves/SIMD; a 3rd pays once the batch exceeds the 2048 wave slots of the 2-wave build (+8 % at 4096 environments)
   if (cfg->scenario == HWY_SCENARIO_INTERSECTION) {
-    const char *h = std::getenv("HWY_IX_HELPERS");
-    const bool helpers = cfg->num_vehicles <= 32 && !(h && h[0] == '0');
+    const bool helpers = cfg->num_vehicles <= 32 && !cfg->tune_ix_no_helpers;
     eng->waves_per_eu = (cfg->num_envs > 2048 && !helpers) ? 3 : 2;
   }
   else if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
-  if (const char *w = std::getenv("HWY_STEP_WAVES_PER_EU")) {
-    const int v = std::atoi(w);
-    if (v >= 1 && v <= 4) eng->waves_per_eu = v;
-  }
+  if (cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4) eng->waves_per_eu = cfg->tune_waves_per_eu;
   auto bail = [&](hipError_t e, const char *what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
     hwy_destroy(eng);
@@ -298,8 +297,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     if ((e = hipMemsetAsync(eng->d_route, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(eng->d_road_steps, 0, E * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemcpy(eng->d_gnet, cfg->gnet, sizeof(hwy_glane) * HWY_MAX_GLANES, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
-    const char *pw = std::getenv("HWY_IX_PREWARM");  // tuning knob: 0 = every auto-reset runs its warm-up inline
-    if (!(cfg->flags & HWY_C_HOST_TRAFFIC) && !(pw && pw[0] == '0')) {
+    if (!(cfg->flags & HWY_C_HOST_TRAFFIC) && !cfg->tune_ix_no_prewarm) {  // (tuning: every auto-reset runs its warm-up inline)
       ALLOC(eng->d_shadow_f64, plane * 9 * sizeof(double));
       ALLOC(eng->d_shadow_packed, plane * sizeof(int32_t));
       ALLOC(eng->d_shadow_route, plane * sizeof(int32_t));

@@ -3,8 +3,6 @@
 // (hwy_engine.cpp).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "hwy_device.h"
 #include "hwy_wave.h"
 #include "hwy_net.h"
@@ -36,19 +34,10 @@ static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t
   }
   return hipGetLastError();
 }
-// Tuning knob HWY_STEP_EXTRA_LDS=<bytes>: dynamic LDS reserved per workgroup, i.e. fewer resident wavefronts per SIMD, so
-// that part of the grid is dispatched as wavefronts retire (the hardware then balances unevenly loaded SIMDs)
-static int extra_lds_bytes() {
-  static const int v = [] {
-    const char *s = std::getenv("HWY_STEP_EXTRA_LDS");
-    const int b = s ? std::atoi(s) : 0;
-    return b > 0 && b <= 65536 ? b : 0;
-  }();
-  return v;
-}
 template <int WPE>
-static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
-  const int lds = extra_lds_bytes();
+static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t stream, int lds) {
+  // lds = hwy_config.tune_extra_lds: dynamic LDS reserved per workgroup, i.e. fewer resident wavefronts per SIMD, so that part
+  // of the grid is dispatched as wavefronts retire (the hardware then balances unevenly loaded SIMDs)
   if (p.flags & HWY_C_EGO_ONLY_COLLISIONS)
     hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
   else
@@ -56,13 +45,14 @@ static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t
   return hipGetLastError();
 }
 // N <= 64: one wavefront per environment (hwy_wave.h); otherwise ceil(N/64) wavefronts per workgroup.
-hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel) {
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
+                       int extra_lds) {
   if (p.N <= 64 && !force_block_kernel) {
     switch (waves_per_eu) {
-      case 1: return launch_wave_wpe<1>(p, num_envs, stream);
-      case 2: return launch_wave_wpe<2>(p, num_envs, stream);
-      case 3: return launch_wave_wpe<3>(p, num_envs, stream);
-      default: return launch_wave_wpe<4>(p, num_envs, stream);
+      case 1: return launch_wave_wpe<1>(p, num_envs, stream, extra_lds);
+      case 2: return launch_wave_wpe<2>(p, num_envs, stream, extra_lds);
+      case 3: return launch_wave_wpe<3>(p, num_envs, stream, extra_lds);
+      default: return launch_wave_wpe<4>(p, num_envs, stream, extra_lds);
     }
   }
   switch (waves_per_eu) {

@@ -7,7 +7,8 @@
 #include "hwy_ix.h"
 
 namespace hwy {
-hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel);
+hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
+                       int extra_lds);
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *in, double *out, long long n, hipStream_t stream);
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream);

@@ -55,10 +55,7 @@ inline void ix_params_from_config(const hwy_config &c, const StepParams &p, IP &
   ip.s = p;
   ip.n_lanes = c.gnet_lanes;
   ip.num_envs = c.num_envs;
-  {  // tuning knob: HWY_IX_HELPERS=0 launches the 32-thread workgroups (no helper lanes) for N <= 32
-    const char *h = std::getenv("HWY_IX_HELPERS");
-    ip.helpers = (h && h[0] == '0') ? 0 : 1;
-  }
+  ip.helpers = c.tune_ix_no_helpers ? 0 : 1;  // 0: 32-thread workgroups (no helper lanes) for N <= 32
   ip.initial_count = c.initial_vehicle_count;
   ip.host_spawn = (c.flags & HWY_C_HOST_TRAFFIC) ? 1 : 0;
   ip.destination = c.destination;

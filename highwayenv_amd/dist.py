@@ -111,14 +111,34 @@ class PackedStepOutputs:
         return {k: torch.cat([v[k] for v in per_rank], dim=0) for k in per_rank[0]}
 
 
-def scatter_actions(actions_global, world: int, rank: int, envs_per_rank: int, device):
-    """Rank 0 holds int32 [world*E, A] actions; every rank receives its [E, A] block."""
+def scatter_actions(actions_global, world: int, rank: int, envs_per_rank: int, device, total_envs: int | None = None):
+    """Rank 0 holds int32 [total_envs, A] actions; rank r receives the rows of ``shard_range(total_envs, world, r)``.
+
+    ``dist.scatter`` needs equal-sized pieces, so every piece is padded to the largest shard (``ceil(total / world)``
+    rows) and the receiver drops the padding: the split follows ``shard_range`` exactly, also when ``total_envs`` is
+    not a multiple of ``world``.  ``envs_per_rank`` is this rank's own shard size."""
     if world == 1:
         return actions_global
+    if total_envs is None:
+        total_envs = envs_per_rank * world  # equal shards
+    mine = shard_range(total_envs, world, rank)
+    if len(mine) != envs_per_rank:
+        raise ValueError(f"rank {rank} owns {len(mine)} of {total_envs} envs, not {envs_per_rank}")
     A = actions_global.shape[-1] if rank == 0 else None
     shape = torch.tensor([A or 0], device=device)
     dist.broadcast(shape, src=0)
-    out = torch.empty((envs_per_rank, int(shape.item())), dtype=torch.int32, device=device)
-    chunks = list(actions_global.contiguous().chunk(world, dim=0)) if rank == 0 else None
+    A = int(shape.item())
+    rows = -(-total_envs // world)
+    out = torch.empty((rows, A), dtype=torch.int32, device=device)
+    chunks = None
+    if rank == 0:
+        if actions_global.shape[0] != total_envs:
+            raise ValueError(f"actions_global has {actions_global.shape[0]} rows, expected {total_envs}")
+        chunks = []
+        for r in range(world):
+            rr = shard_range(total_envs, world, r)
+            piece = torch.zeros((rows, A), dtype=torch.int32, device=device)
+            piece[:len(rr)] = actions_global[rr.start:rr.stop]
+            chunks.append(piece)
     dist.scatter(out, chunks, src=0)
-    return out
+    return out[:envs_per_rank]

@@ -54,7 +54,26 @@ class Engine:
 
     # -- state --------------------------------------------------------------------------------
     def set_state(self, st: dict):
-        st = {k: np.ascontiguousarray(v) for k, v in st.items()}
+        """hwy_set_state reads E*N elements per vehicle field and E per env field through raw pointers: every array is
+        coerced to its dtype and its shape is checked here, so a dict built for another batch raises instead of
+        reading out of bounds."""
+        E, N = self.E, self.N
+        ix = self.cfg.scenario == _abi.SCENARIO_INTERSECTION
+        want = {k: (np.float64, (E, N)) for k in _abi.STATE_F64}
+        want.update({k: (np.int32, (E, N)) for k in _abi.STATE_I32})
+        want["time"] = (np.float64, (E,))
+        if ix:
+            want["route"], want["road_steps"] = (np.int32, (E, N)), (np.int32, (E,))
+        out = {}
+        for k, (dt, shape) in want.items():
+            if k not in st:
+                raise ValueError(f"set_state: missing field {k!r}")
+            a = np.ascontiguousarray(st[k], dtype=dt)
+            if a.shape != shape:
+                raise ValueError(f"set_state: field {k!r} has shape {a.shape}, this engine needs {shape} "
+                                 f"(num_envs={E}, slots per env={N})")
+            out[k] = a
+        st = out
         s = _abi.state_struct(st)
         self._check(self._lib.hwy_set_state(self._h, C.byref(s)))
 

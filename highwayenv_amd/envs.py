@@ -164,7 +164,13 @@ class BatchedHighwayEnv:
             sd = np.array([np.random.SeedSequence(s).generate_state(1, np.uint64)[0] if s is None else s
                            for s in seeds], np.uint64)
             obs = eng.reset(seeds=sd, **self._device_spawn_args())
-        eng.set_autoreset(self.autoreset, base_seed=int(seeds[0] or 0) + 0x9E3779B9, **self._device_spawn_args())
+        # auto-reset episodes: derived from the given seed (reproducible), or as unseeded as the first episode when
+        # seed is None (fresh OS entropy -- otherwise every seed=None worker would replay the same later episodes)
+        if seeds[0] is None:
+            base_seed = int(np.random.SeedSequence(None).generate_state(1, np.uint64)[0] >> np.uint64(1))
+        else:
+            base_seed = int(seeds[0]) + 0x9E3779B9
+        eng.set_autoreset(self.autoreset, base_seed=base_seed, **self._device_spawn_args())
         self.time[:] = 0
         self.steps = 0
         st = eng.get_state()
@@ -196,7 +202,16 @@ class BatchedHighwayEnv:
             raise NotImplementedError("The road and vehicle must be initialized in the environment implementation")
         E, A = self.num_envs, self._hcfg.num_agents
         acts = np.asarray(action)
-        acts = acts.reshape(E, A) if acts.size == E * A else np.broadcast_to(acts, (E, A))
+        # accepted shapes: scalar (every env, every agent), (E,) = one action per env (single-agent envs; with A > 1 it
+        # drives every agent of env e, never "agent a of every env"), (E, A) / (E*A,) as is
+        if acts.ndim == 0:
+            acts = np.broadcast_to(acts, (E, A))
+        elif acts.shape == (E,) and not (A > 1 and E == 1):
+            acts = np.broadcast_to(acts[:, None], (E, A))
+        elif acts.shape == (E, A) or (acts.ndim == 1 and acts.size == E * A):
+            acts = acts.reshape(E, A)
+        else:
+            raise ValueError(f"action must be a scalar, shape ({E},) or shape ({E}, {A}); got {acts.shape}")
         obs, reward, term, trunc, info = self._engine.step(acts.astype(np.int32))  # KeyError on bad action id
         self.time += 1 / self.config["policy_frequency"]
         self.steps += self._hcfg.frames_per_step

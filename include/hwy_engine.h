@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HWY_ABI_VERSION 4
+#define HWY_ABI_VERSION 5
 
 #define HWY_MAX_AGENTS 16
 #define HWY_MAX_FEATURES 16
@@ -219,6 +219,16 @@ typedef struct hwy_config {
   double idm_distance_wanted, idm_time_wanted, idm_comfort_acc_max, idm_comfort_acc_min; /* set on the vehicle class by
                                           IntersectionEnv._make_vehicles (intersection_env.py:243-247): 7, 1.5, 6, -3 */
   hwy_glane gnet[HWY_MAX_GLANES];
+  /* Tuning (ABI v5; 0 everywhere = the engine's own choice).  These replace the process-global environment variables
+   * earlier builds read with getenv: a knob now belongs to ONE engine and is part of its documented configuration.
+   * None of them changes any result (tests/test_engine_parity.py, tests/test_ix_parity.py compare the variants). */
+  int32_t tune_block_kernel;           /* 1: run the generic workgroup kernel (hwy_device.h) even for N <= 64 */
+  int32_t tune_waves_per_eu;           /* 1..4: register-allocation variant (resident wavefronts per SIMD) of the step kernel */
+  int32_t tune_ix_no_helpers;          /* 1: HWY_SCENARIO_INTERSECTION with N <= 32 runs 32-thread workgroups (no helper lanes) */
+  int32_t tune_ix_no_prewarm;          /* 1: HWY_SCENARIO_INTERSECTION auto-resets run their warm-up frames inline */
+  int32_t tune_extra_lds;              /* bytes of dynamic LDS per workgroup of the one-wavefront step kernel (<= 65536):
+                                          fewer resident wavefronts per SIMD, the rest dispatched as wavefronts retire */
+  int32_t tune_reserved[3];
 } hwy_config;
 
 /*

@@ -118,7 +118,7 @@ void dispatch(Which which, const StepParams &p, int E) {
     }
     return;
   }
-  if (which == STEP && nw == 1 && !g_force_block) {  // same dispatch rule as hwy_kernels.hip
+  if (which == STEP && nw == 1 && !g_force_block && !g_cfg->tune_block_kernel) {  // same dispatch rule as hwy_kernels.hip
     if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, false>(q); }, E, 64, p);
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
     return;

@@ -263,38 +263,10 @@ def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what=""):
 
 
 def ix_oracle_state(h: dict, cfg) -> dict:
-    """The product's hwy_state dict of the intersection scenario -> the oracle's (oracle/oracle_ix.py) layout."""
-    from highwayenv_amd import intersection as hix
     from oracle import oracle_ix
-    tab = hix.table_from_config(cfg)
-    E, N = h["x"].shape
-    st = oracle_ix.alloc_state(E, N, 4)
-    for k in oracle_ix.STATE_F64:
-        st[k][...] = h[k]
-    f = h["flags"]
-    st["present"][...] = (f & _abi.F_ABSENT) == 0
-    for k, bit in (("crashed", _abi.F_CRASHED), ("has_impact", _abi.F_HAS_IMPACT), ("controlled", _abi.F_CONTROLLED),
-                   ("is_yielding", _abi.F_YIELDING)):
-        st[k][...] = (f & bit) != 0
-    for k in ("lane", "target_lane", "speed_index"):
-        st[k][...] = h[k]
-    for e in range(E):
-        for i in range(N):
-            r = hix.route_unpack(int(h["route"][e, i])) if st["present"][e, i] else []
-            st["route_len"][e, i] = len(r)
-            for q, l in enumerate(r):
-                st["route_from"][e, i, q], st["route_to"][e, i, q] = tab["from_node"][l], tab["to_node"][l]
-                st["route_id"][e, i, q] = -1 if q else 0
-    st["road_steps"][...] = h["road_steps"]
-    st["time"][...] = h["time"]
-    return st
+    return oracle_ix.state_from_engine(h, cfg)
 
 
 def ix_oracle_config(cfg_dict: dict, cfg, num_envs: int):
-    from highwayenv_amd import intersection as hix
     from oracle import oracle_ix
-    tab = hix.table_from_config(cfg)
-    lane_tab = dict(tab)
-    lane_tab["ex"] = lane_tab["ey"] = lane_tab["end_phase"] = np.zeros_like(tab["sx"])
-    lane_tab["id"] = np.zeros_like(tab["kind"])
-    return oracle_ix.make_config(cfg_dict, lane_tab, hix.NODE_NAMES, num_envs, cfg.num_vehicles, 4)
+    return oracle_ix.config_from_engine(cfg_dict, cfg, num_envs)

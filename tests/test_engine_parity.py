@@ -175,24 +175,15 @@ def test_multi_agent_vs_oracle(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_block_kernel_for_small_envs_matches_oracle(backend, monkeypatch):
+def test_block_kernel_for_small_envs_matches_oracle(backend):
     """N <= 64 normally runs the one-wavefront-per-env kernel (hwy_wave.h); the generic workgroup
-    kernel (hwy_device.h, the N > 64 path) must give the same answers on the same inputs."""
-    if backend == "emu":
-        from tests.emu import emu
-        emu.force_block_kernel(True)
-    else:
-        monkeypatch.setenv("HWY_STEP_KERNEL", "block")
-    try:
-        cfg = _abi.highway_fast_default_config()
-        cfg.update({"vehicles_count": 50, "lanes_count": 4})
-        _random_rollout_vs_oracle(backend, cfg, True, 6 if backend == "emu" else 256, 6 if backend == "emu" else 30, seed=4)
-        cfg = _abi.highway_default_config()
-        cfg.update({"vehicles_count": 30, "duration": 20})
-        _random_rollout_vs_oracle(backend, cfg, False, 3 if backend == "emu" else 64, 2 if backend == "emu" else 8, seed=5)
-    finally:
-        if backend == "emu":
-            emu.force_block_kernel(False)
+    kernel (hwy_device.h, the N > 64 path; hwy_config.tune_block_kernel) must give the same answers on the same inputs."""
+    cfg = _abi.highway_fast_default_config()
+    cfg.update({"vehicles_count": 50, "lanes_count": 4, "tuning": {"block_kernel": 1}})
+    _random_rollout_vs_oracle(backend, cfg, True, 6 if backend == "emu" else 256, 6 if backend == "emu" else 30, seed=4)
+    cfg = _abi.highway_default_config()
+    cfg.update({"vehicles_count": 30, "duration": 20, "tuning": {"block_kernel": 1}})
+    _random_rollout_vs_oracle(backend, cfg, False, 3 if backend == "emu" else 64, 2 if backend == "emu" else 8, seed=5)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -15,11 +15,11 @@ from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, GoldenIntersecti
                                ix_engine_state)
 
 
-def _hwy_config(g, E, host_traffic=True):
+def _hwy_config(g, E, host_traffic=True, tuning=None):
     cfg = dict(g.config)
     cfg["max_vehicles"] = g.N
     cfg["host_traffic"] = host_traffic
-    return _abi.make_config(cfg, E, scenario="intersection")
+    return _abi.make_config(cfg, E, scenario="intersection", tuning=tuning)
 
 
 def _sub(st, sel):
@@ -113,18 +113,17 @@ def test_policy_steps_vs_reference(backend, name):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", ["intersection_default", "intersection_dense"])
-def test_helper_lanes_are_bit_identical_to_the_serial_loops(backend, name, monkeypatch):
+def test_helper_lanes_are_bit_identical_to_the_serial_loops(backend, name):
     """N <= 32: threads 32..63 of the wavefront split the lane-table walk, the collision partners and the regulation
     samples / partners with the vehicle's own thread (hwy_ix.h, IxSharedT).  Same arithmetic, same tie rules: the state
-    after whole policy steps (device clear / spawn included) must equal the 32-thread build's (HWY_IX_HELPERS=0) BIT FOR BIT."""
+    after whole policy steps (device clear / spawn included) must equal the 32-thread build's (hwy_config.tune_ix_no_helpers) BIT FOR BIT."""
     g = GoldenIntersection(name)
     E = g.E
     rng = np.random.default_rng(3)
     acts = rng.integers(0, 3, size=(6, E, 1)).astype(np.int32)
     out = []
-    for helpers in ("1", "0"):
-        monkeypatch.setenv("HWY_IX_HELPERS", helpers)
-        cfg = _hwy_config(g, E, host_traffic=False)
+    for no_helpers in (0, 1):
+        cfg = _hwy_config(g, E, host_traffic=False, tuning={"ix_no_helpers": no_helpers})
         eng = make_engine(backend, cfg)
         eng.set_state(ix_engine_state(g, g.state("init"), cfg))
         rows = []

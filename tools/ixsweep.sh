@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/h1
 for h in 1 0; do for w in 2 3; do for e in 2048 4096; do
-  HWY_IX_HELPERS=$h HWY_STEP_WAVES_PER_EU=$w timeout 120 python bench.py --workload intersection --envs-per-gpu $e --steps 60 --warmup 40 --no-cpu-baseline > gpurun_out/h1/b_${h}_${w}_${e}.json 2> gpurun_out/h1/b_${h}_${w}_${e}.err
+  timeout 120 python bench.py --tune ix_no_helpers=$((1-h)) --tune waves_per_eu=$w --workload intersection --envs-per-gpu $e --steps 60 --warmup 40 --no-cpu-baseline > gpurun_out/h1/b_${h}_${w}_${e}.json 2> gpurun_out/h1/b_${h}_${w}_${e}.err
   python - <<PY
 import json
 try:
