@@ -217,30 +217,51 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
 // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
 //
-// The reference projects the 4+4 corners on the 8 edge normals.  The normals of a rectangle are +-its
-// two body axes (in the order -u, +w, +u, -w for the corner order of objects.py:169-181), a projection
-// interval is (centre . n) -+ (L/2 |u.n| + W/2 |w.n|), and everything the test computes is symmetric under
-// n -> -n, so four axes (u_a, w_a, u_b, w_b, in that order: the first minimum wins) give the same
-// flags and the same translation as the eight -- in ~100 flops and a dozen registers instead of a
-// 16-double corner table.  Differences to the literal corner arithmetic are at the 1e-16 level.
+// The reference projects the 4+4 corners on the 8 edge normals.  The normals of a rectangle are +-its two body
+// axes, in the order -u, +w, +u, -w for the corner order of objects.py:169-181, and a projection interval is
+// (centre . n) -+ (L/2 |u.n| + W/2 |w.n|): four axis DIRECTIONS are evaluated, in ~100 flops and a dozen registers
+// instead of a 16-double corner table (differences to the literal corner arithmetic: 1e-16).  The two flags are
+// symmetric under n -> -n, but interval_distance (utils.py:188-193) is NOT when the swept interval of `a` CONTAINS
+// b's: with a = [a0, a1], b = [b0, b1] it returns b0 - a1 if a0 < b0 else a0 - b1, and for -n the test becomes
+// a1 > b1, which picks the OTHER candidate exactly in the containment case (two cars nose to tail on one lane centre,
+// lateral axis: found by tests/test_collision_steps.py against the reference's traces).  So every direction yields
+// both signed distances and the minimum is folded in the reference's own order of the 8 normals (first minimum wins).
 struct SatAcc {
   bool intersecting, will;
   double min_distance, axx, axy;
 };
-__device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
-                                double vp, double cdx, double cdy) {
+struct SatAxis {
+  double nx, ny, dot;  // direction, and (centre_a - centre_b) . n
+  double dn, dm;       // interval distance for the normal +n and for the normal -n
+};
+__device__ inline SatAxis sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
+                                   double vp, double cdx, double cdy) {
   double min_a = ca_ - ra, max_a = ca_ + ra;
   const double min_b = cb_ - rb, max_b = cb_ + rb;
   if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) acc.intersecting = false;
   if (vp < 0) min_a += vp; else max_a += vp;
-  const double distance = min_a < min_b ? min_b - max_a : min_a - max_b;
-  if (distance > 0) acc.will = false;
-  if (fabs(distance) < acc.min_distance) {
-    acc.min_distance = fabs(distance);
-    const bool pos = cdx * nx + cdy * ny > 0;  // translation_axis = normal if d.dot(normal) > 0 else -normal
-    acc.axx = pos ? nx : -nx;
-    acc.axy = pos ? ny : -ny;
+  const double g1 = min_b - max_a, g2 = min_a - max_b;
+  const double dn = min_a < min_b ? g1 : g2;  // normal +n
+  const double dm = max_a > max_b ? g2 : g1;  // normal -n: the intervals are the exact negations, [-max, -min]
+  if (dn > 0) acc.will = false;                // (disjoint intervals: dn == dm)
+  return SatAxis{nx, ny, cdx * nx + cdy * ny, dn, dm};
+}
+// one normal: keep the first minimum; translation_axis = normal if d.dot(normal) > 0 else -normal (utils.py:232-236)
+__device__ inline void sat_take(SatAcc &acc, const SatAxis &ax, bool minus) {
+  const double d = minus ? ax.dm : ax.dn;
+  if (fabs(d) < acc.min_distance) {
+    acc.min_distance = fabs(d);
+    const bool pos = minus ? !(ax.dot < 0) : (ax.dot > 0);  // in units of +n
+    acc.axx = pos ? ax.nx : -ax.nx;
+    acc.axy = pos ? ax.ny : -ax.ny;
   }
+}
+// the four edge normals of one rectangle in the reference's order: -u, +w, +u, -w
+__device__ inline void sat_polygon(SatAcc &acc, const SatAxis &u, const SatAxis &w) {
+  sat_take(acc, u, true);
+  sat_take(acc, w, false);
+  sat_take(acc, u, false);
+  sat_take(acc, w, true);
 }
 __device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
@@ -255,13 +276,14 @@ __device__ inline int pair_collide(const Body &A, const Body &B, double dt, doub
   const double cdx = A.x - B.x, cdy = A.y - B.y;  // centre difference (mean of the corners)
   const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);  // |cos|, |sin| of (h_b - h_a)
   SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0};
-  // u_a = (cos h_a, sin h_a)
-  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
-  // w_a = (-sin h_a, cos h_a)
-  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
+  // u_a = (cos h_a, sin h_a), w_a = (-sin h_a, cos h_a)
+  const SatAxis ua = sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
+  const SatAxis wa = sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
+  sat_polygon(acc, ua, wa);
   // u_b, w_b
-  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy);
-  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  const SatAxis ub = sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy);
+  const SatAxis wb = sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  sat_polygon(acc, ub, wb);
   if (acc.will) {
     *tx = acc.min_distance * acc.axx;
     *ty = acc.min_distance * acc.axy;
@@ -1024,8 +1046,11 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       // distance (collision radius + the most two vehicles can move relative to each other in one frame);
       // the partner with the highest index is the last writer of `impact` in the reference's (i, j>i) loop.
       // sh.x/y/v/c/s now hold the post-integration bodies by index, sh.aux0 the frame-start x by index.
+      // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
+      // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the scan is the literal all-pairs loop
+      const bool wide = __syncthreads_or(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
       if (active) {
-        const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+        const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
         int best = -1;
         for (int dir = -1; dir <= 1; dir += 2) {
           for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {

@@ -185,10 +185,12 @@ __device__ inline int net_pair_collide(const NetBody &A, const NetBody &B, doubl
   const double cdx = A.x - B.x, cdy = A.y - B.y;
   const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);
   SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0};
-  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, A.hl, B.x * A.c + B.y * A.s, B.hl * cr + B.hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
-  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, A.hw, B.y * A.c - B.x * A.s, B.hl * sr + B.hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
-  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, A.hl * cr + A.hw * sr, B.x * B.c + B.y * B.s, B.hl, B.c * ddx + B.s * ddy, cdx, cdy);
-  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, A.hl * sr + A.hw * cr, B.y * B.c - B.x * B.s, B.hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  const SatAxis ua = sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, A.hl, B.x * A.c + B.y * A.s, B.hl * cr + B.hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
+  const SatAxis wa = sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, A.hw, B.y * A.c - B.x * A.s, B.hl * sr + B.hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
+  sat_polygon(acc, ua, wa);  // the reference's order of the 8 normals (hwy_device.h: sat_polygon)
+  const SatAxis ub = sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, A.hl * cr + A.hw * sr, B.x * B.c + B.y * B.s, B.hl, B.c * ddx + B.s * ddy, cdx, cdy);
+  const SatAxis wb = sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, A.hl * sr + A.hw * cr, B.y * B.c - B.x * B.s, B.hw, B.c * ddy - B.s * ddx, cdx, cdy);
+  sat_polygon(acc, ub, wb);
   if (acc.will) {
     *tx = acc.min_distance * acc.axx;
     *ty = acc.min_distance * acc.axy;
@@ -775,10 +777,15 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       // frame-start distance: lim of the sphere pre-check below + what two bodies can move towards each other in
       // one frame (speed * dt each, + a pending impact each).  Speeds stay below 36 m/s in practice; the bound falls
       // back to 50 m/s if any body is faster.  Close pairs are only COLLECTED here (bit r2 of `cand`, rank space).
-      const bool calm = __ballot(present && !(fabs(me.v) <= 36.0 && fabs(v_old) <= 36.0)) == 0;
-      const bool pending = __ballot(present && (flags_old & HWY_F_HAS_IMPACT)) != 0;
+      // Both tiers are checked on the ACTUAL values of this frame (`moved` = what the integration, pending impact
+      // included, did to x; the speed afterwards for the radius term): nothing clamps speeds in the reference
+      // (kinematics.py:155-168 only pulls them back) and an Obstacle hands the vehicle the whole translation, so a body
+      // outside both tiers turns the walk into the literal all-pairs loop.
+      const double moved = fabs(me.x - x_old);
+      const bool calm = __ballot(present && !(fabs(me.v) <= 36.0 && moved <= 36.0 * p.dt)) == 0;
+      const bool wide = !calm && __ballot(present && !(fabs(me.v) <= 50.0 && moved <= 50.0 * p.dt + 3.0)) != 0;
       const double vb = (calm ? 36.0 : 50.0) * p.dt;
-      const double reach = (5.5 + vb) + 2.0 * (vb + (pending ? 3.0 : 0.0));
+      const double reach = wide ? __builtin_inf() : (5.5 + vb) + 2.0 * (vb + (calm ? 0.0 : 3.0));
       u64 cand = 0;
       bool go_a = present, go_b = present;
       for (int k = 1; k < n_present; ++k) {

@@ -494,9 +494,14 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       // have moved relative to each other within one frame.  Everything within reach is visited, so the
       // result equals the full loop; "last pair in loop order wins" == the partner with the highest index.
       sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
+      const bool wide = __ballot(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
       __syncthreads();
       if (active) {
-        const double reach = (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);  // radius + relative motion (speed <= 50, impact <= 3 m)
+        // radius + relative motion, for bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and
+        // are not faster than 50 m/s afterwards (the radius term).  Both are checked on the actual values (`wide`,
+        // wave-uniform): the reference does not clamp speeds (clip_actions only pulls them back, kinematics.py:155-168)
+        // and hwy_set_state accepts any, so a faster body or a larger push turns the scan into the literal all-pairs loop.
+        const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
         int best = -1;
         for (int dir = -1; dir <= 1; dir += 2) {
           for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {

@@ -92,3 +92,21 @@ def step(cfg: _abi.HwyConfig, st: dict, actions) -> tuple:
         raise KeyError("invalid meta-action")
     assert rc == 0, rc
     return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+
+
+class impact_margins:
+    """Context manager (test diagnostics): while active, every ``frames`` / ``step`` call of the straight-road oracle
+    fills ``self.margin`` [E, N] with the smallest ``|d . normal|`` (utils.py:232-236) among the impacts assigned to each
+    vehicle during that call (+inf where none was).  A margin at rounding-noise level marks a collision whose push
+    direction is decided by the last bit of the libm in use (two cars on one lane centre, lateral axis)."""
+
+    def __init__(self, cfg: _abi.HwyConfig):
+        self.margin = np.full((cfg.num_envs, cfg.num_vehicles), np.inf)
+
+    def __enter__(self):
+        lib().orc_set_margin_buffer(self.margin.ctypes.data_as(C.POINTER(C.c_double)))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_margin_buffer(None)
+        return False

@@ -84,6 +84,17 @@ inline unsigned long long __ballot(int pred) {
   if (lane == 0) acc = 0;  // reused two ballots later, with >= 1 rendezvous in between
   return v;
 }
+inline int __syncthreads_or(int pred) {  // barrier + OR of the predicate over the whole workgroup
+  unsigned long long any = __ballot(pred);  // per-wave OR (two rendezvous) ...
+  __shared__ unsigned long long acc[2];
+  const unsigned ph = emu::cur->ballot_phase & 1;  // (advanced once per call by the __ballot above, uniformly)
+  if (any) acc[ph] = 1;
+  emu::barrier();
+  const int v = acc[ph] != 0;
+  emu::barrier();
+  if (threadIdx.x == 0) acc[ph] = 0;
+  return v;
+}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }

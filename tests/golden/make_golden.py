@@ -80,13 +80,23 @@ SCENARIOS = [
     dict(name="v0_default", cls=HighwayEnv, config={}, seeds=[0, 1], steps=6,
          action_seed=99, frames_for=1),
     # per-env workload of BASELINE config 3: N=101
-    dict(name="cfg3_v0_n100", cls=HighwayEnv, config={"vehicles_count": 100}, seeds=[0],
-         steps=3, action_seed=7, frames_for=1),
+    dict(name="cfg3_v0_n100", cls=HighwayEnv, config={"vehicles_count": 100}, seeds=[0, 1, 2],
+         steps=3, action_seed=7, frames_for=3),
     # crash-rich: dense traffic, full collisions, ego keeps accelerating / weaving
     dict(name="dense_crash", cls=HighwayEnv,
          config={"vehicles_count": 30, "vehicles_density": 2.5, "lanes_count": 3,
                  "ego_spacing": 1.0, "duration": 20},
          seeds=[3, 5, 11], steps=14, action_seed=5, frames_for=3,
+         action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
+    # many first crashes (what a user sees WITH terminated=True): ego-only collisions, 5 Hz ...
+    dict(name="crash_many_fast", cls=HighwayEnvFast,
+         config={"vehicles_count": 30, "vehicles_density": 2.0, "lanes_count": 3, "ego_spacing": 1.0, "duration": 20},
+         seeds=list(range(100, 140)), steps=10, action_seed=21, frames_for=0,
+         action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
+    # ... and full pairwise collisions at 15 Hz, with per-frame states for the first envs
+    dict(name="crash_many_v0", cls=HighwayEnv,
+         config={"vehicles_count": 30, "vehicles_density": 2.5, "lanes_count": 3, "ego_spacing": 1.0, "duration": 20},
+         seeds=list(range(200, 224)), steps=8, action_seed=22, frames_for=6,
          action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
     # all-IDLE free run (no agent interference): long horizon, many MOBIL decisions
     dict(name="fast_idle_long", cls=HighwayEnvFast,

@@ -54,9 +54,10 @@ def test_full_size_determinism_independence_oracle_and_invariants():
         np.testing.assert_array_equal(s_obs, obs[pick], err_msg=f"batch independence, step {t}")
         np.testing.assert_array_equal(s_rew, reward[pick])
         np.testing.assert_array_equal(s_term, term[pick])
-        o2, r2, te2, tr2, _ = oracle.step(sub_cfg, ref, acts[pick])
+        with oracle.impact_margins(sub_cfg) as mg:
+            o2, r2, te2, tr2, _ = oracle.step(sub_cfg, ref, acts[pick])
         wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
-        ok = live & ~wreck
+        ok = live & (~wreck | (mg.margin.min(1) >= 1e-9))  # collision steps too, unless on the knife edge
         np.testing.assert_array_equal(s_term[live], te2[live])
         np.testing.assert_allclose(s_obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=f"oracle, step {t}")
         np.testing.assert_allclose(s_rew[ok], r2[ok], rtol=0, atol=1e-9)
@@ -94,6 +95,99 @@ def test_full_size_autoreset_keeps_every_env_alive():
     assert (resets >= 2).all()  # 70 steps, 30-step episodes: every env restarted at least twice
     st = eng.get_state()
     assert (st["time"] <= 30).all()
+    eng.close()
+
+
+# ---- BASELINE config 3, the per-GPU shard at full size: highway-v0, 1024 envs x 101 vehicles (two wavefronts per env),
+#      15 frames per step, FULL pairwise collisions (5050 pairs per env-frame in the reference) ---------------------------
+def make_cfg3(E_):
+    from highwayenv_amd.engine import Engine
+    cfg_d = _abi.highway_default_config()
+    cfg_d.update({"vehicles_count": 100})
+    cfg = _abi.make_config(cfg_d, E_, fast=False)
+    return cfg_d, cfg, Engine(cfg)
+
+
+def test_full_size_cfg3_determinism_independence_oracle_and_invariants():
+    E3, STEPS3 = 1024, 24
+    cfg_d, cfg, eng = make_cfg3(E3)
+    _, _, eng2 = make_cfg3(E3)
+    assert cfg.num_vehicles == 101 and cfg.frames_per_step == 15 and not (cfg.flags & _abi.C_EGO_ONLY_COLLISIONS)
+    seeds = np.arange(E3, dtype=np.uint64) + 777
+    for e_ in (eng, eng2):
+        e_.reset(seeds=seeds, ego_spacing=2.0, vehicles_density=1.0)
+    pick = np.sort(np.random.default_rng(6).choice(E3, 24, replace=False))
+    sub_cfg = _abi.make_config(cfg_d, len(pick), fast=False)
+    from highwayenv_amd.engine import Engine
+    sub = Engine(sub_cfg)
+    st0 = eng.get_state()
+    assert ((st0["flags"] & _abi.F_CHECK_COLLISIONS) != 0).all()  # highway-v0: every vehicle checks collisions
+    sub.set_state({k: np.ascontiguousarray(v[pick]) for k, v in st0.items()})
+    ref = {k: np.ascontiguousarray(v[pick]).copy() for k, v in st0.items()}
+    live = np.ones(len(pick), bool)
+    rng = np.random.default_rng(7)
+    prev = st0
+    n_oracle = 0
+    for t in range(STEPS3):
+        acts = rng.integers(0, 5, size=(E3, 1)).astype(np.int32)
+        out1 = eng.step(acts)
+        out2 = eng2.step(acts)
+        for a, b in zip(out1[:4], out2[:4]):
+            np.testing.assert_array_equal(a, b, err_msg=f"determinism, step {t}")
+        obs, reward, term, trunc, info = out1
+        s_obs, s_rew, s_term, s_trunc, _ = sub.step(acts[pick])
+        np.testing.assert_array_equal(s_obs, obs[pick], err_msg=f"batch independence, step {t}")
+        np.testing.assert_array_equal(s_rew, reward[pick])
+        np.testing.assert_array_equal(s_term, term[pick])
+        with oracle.impact_margins(sub_cfg) as mg:
+            o2, r2, te2, tr2, _ = oracle.step(sub_cfg, ref, acts[pick])
+        wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
+        ok = live & (~wreck | (mg.margin.min(1) >= 1e-9))
+        n_oracle += int(ok.sum())
+        np.testing.assert_array_equal(s_term[live], te2[live])
+        np.testing.assert_allclose(s_obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=f"oracle, step {t}")
+        np.testing.assert_allclose(s_rew[ok], r2[ok], rtol=0, atol=1e-9)
+        got = sub.get_state()
+        for k in ("lane", "target_lane", "flags"):
+            np.testing.assert_array_equal(got[k][ok], ref[k][ok], err_msg=f"oracle, step {t}: {k}")
+        for k in ("x", "y", "heading", "speed"):
+            np.testing.assert_allclose(got[k][ok], ref[k][ok], rtol=0, atol=1e-7, err_msg=f"oracle, step {t}: {k}")
+        live &= ~wreck & ~tr2
+        # invariants over the whole batch
+        st = eng.get_state()
+        assert obs.shape == (E3, 1, 5, 5) and np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()
+        assert ((reward >= 0) & (reward <= 1 + 1e-12)).all()
+        assert ((st["lane"] >= 0) & (st["lane"] < 4) & (st["target_lane"] >= 0) & (st["target_lane"] < 4)).all()
+        assert (np.abs(st["x"] - prev["x"]) <= 41.5 * 1.0 + 15.0).all()
+        np.testing.assert_array_equal(st["time"], t + 1.0)
+        assert (trunc == (t + 1 >= 40)).all()
+        # pile-ups are symmetric: a crashed vehicle has a crashed partner within reach of its body
+        crashed = (st["flags"] & _abi.F_CRASHED) != 0
+        assert (crashed.sum(1) != 1).all()
+        prev = st
+    assert n_oracle > 24 * 8
+    assert ((prev["flags"] & _abi.F_CRASHED) != 0).any(1).sum() > 10  # crashes did happen somewhere in the batch
+    for e_ in (eng, eng2, sub):
+        e_.close()
+
+
+def test_full_size_cfg3_autoreset_keeps_every_env_alive():
+    E3 = 1024
+    cfg_d, cfg, eng = make_cfg3(E3)
+    eng.reset(base_seed=5, ego_spacing=2.0, vehicles_density=1.0)
+    eng.set_autoreset(True, base_seed=6, ego_spacing=2.0, vehicles_density=1.0)
+    rng = np.random.default_rng(8)
+    done_prev = np.zeros(E3, bool)
+    resets = np.zeros(E3, int)
+    for t in range(45):
+        obs, reward, term, trunc, info = eng.step(rng.integers(0, 5, size=(E3, 1)))
+        assert (reward[done_prev] == 0).all() and not term[done_prev].any() and not trunc[done_prev].any()
+        assert not info["crashed"][done_prev].any()
+        resets += done_prev
+        done_prev = term | trunc
+    assert (resets >= 1).all()  # 45 steps, 40-step episodes
+    st = eng.get_state()
+    assert (st["time"] <= 40).all() and np.isfinite(st["x"]).all()
     eng.close()
 
 
