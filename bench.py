@@ -13,6 +13,16 @@ hwy_step_kernel (5 simulation frames + observe + reward + done).  Weak scaling: 
 4096 envs; with N>1 ranks the (obs, reward, terminated, truncated) blocks of every rank are gathered
 to rank 0 over RCCL, --gather-every (16) steps per collective, overlapped with the following steps.
 
+Timing protocol: W untimed warm-up steps, then --repeats (5) timed regions of EXACTLY K = --steps
+(1000) steps each, every region bracketed by barrier + synchronize on both sides and reduced with MAX over ranks;
+`ms_per_step` / `value` are the MEDIAN region (all regions are listed in `ms_per_step_repeats`).
+
+CPU leg: when the reference package is present (build container: /root/reference or $HWY_REFERENCE_ROOT) the
+UNMODIFIED reference is timed on the host cores (`cpu_baseline.kind == "reference"`, oracle/ref_bench.py); on a box
+without it (the GPU box) the C port of the oracle is timed instead and the committed build-container measurement of the
+reference (profiles/reference_cpu_baseline.json) is quoted next to it, labelled as coming from another box.
+`python bench.py --cpu-baseline-only [--save-cpu-baseline PATH]` runs just that leg (no GPU needed).
+
 Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs, inputs resident in HBM.
 """
 from __future__ import annotations
@@ -41,51 +51,81 @@ def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int, obs_floats: int
     return 72 * n_vehicles + (4 * obs_floats + 10) * agents
 
 
-def valu_view(envs_per_gpu: int, avg_kernel_s: float):
-    """The compute-side view of the headline kernel (it is VALU-issue bound, not HBM bound: DESIGN.md section 5): f64
-    flops per launch from the committed SQ instruction counts (profiles/r01_pmc_sq.json: add / mul = 1 flop, fma = 2,
-    x 64 lanes x one wave per environment) over the launch duration measured in THIS run, against the 78.6 TFLOP/s
-    f64 vector peak of MI355X, and the measured VALU issue utilisation."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sq.json")
+def _kernel_build_id():
+    """Identity of the kernel build being timed: sha256 over every kernel source + the hipcc flags
+    (highwayenv_amd.build.kernel_source_hash), valid only if the shared library is not older than its sources."""
+    from highwayenv_amd import build
+    return None if build.is_stale() else build.kernel_source_hash()
+
+
+def _load_counters(name: str, workload: str):
+    """A committed rocprofv3 PMC summary (profiles/<name>) -- returned ONLY if it was recorded for the kernel build
+    being timed (its `kernel_source_sha16` equals this build's) and for this workload: counters of another build
+    say nothing about this one, and PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
-        c = json.load(open(path))["per_wave_per_step"]
+        d = json.load(open(path))
     except Exception:
         return None
+    d = d.get(workload, d) if isinstance(d.get(workload), dict) else d
+    if d.get("kernel_source_sha16") is None or d.get("kernel_source_sha16") != _kernel_build_id():
+        return None
+    return d
+
+
+def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
+    """The compute-side view of the step kernel (it is VALU-issue bound, not HBM bound: DESIGN.md section 5): f64
+    flops per launch from the committed SQ instruction counts (tools/pmc_sq.sh: add / mul = 1 flop, fma = 2, x 64 lanes x
+    one wave per environment) over the launch duration measured in THIS run, against the 78.6 TFLOP/s f64 vector peak of
+    MI355X, and the measured VALU issue utilisation.  None unless the counters belong to this kernel build."""
+    d = _load_counters("r02_pmc_sq.json", workload)
+    if d is None or d.get("envs") != envs_per_gpu:
+        return None
+    c = d["per_wave_per_step"]
     flop = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"]) * 64 * envs_per_gpu
     achieved = flop / avg_kernel_s / 1e12
-    waves_per_simd = min(4.0, envs_per_gpu / 1024.0)
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
-            "valu_instructions_per_env_step": c["SQ_INSTS_VALU"],
-            "valu_issue_utilisation": c["SQ_ACTIVE_INST_VALU"] * waves_per_simd / c["SQ_WAVE_CYCLES"],
-            "source": "profiles/r01_pmc_sq.json (SQ counters of the same kernel and config)"}
+            "valu_instructions_per_env_step": c["SQ_INSTS_VALU"], "salu_instructions_per_env_step": c["SQ_INSTS_SALU"],
+            "valu_issue_utilisation_while_resident": c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"],
+            "source": "profiles/r02_pmc_sq.json (SQ counters of this kernel build and config)"}
 
 
-def measured_traffic_other(workload: str, envs_per_gpu: int):
-    """The same for the merge / intersection workloads (profiles/traffic_r01_other.json)."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01_other.json")
+def measured_traffic(workload: str, envs_per_gpu: int):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
+    tools/traffic_report.py -> profiles/traffic_r02.json).  None if absent, recorded for another kernel build, or for
+    another batch size."""
+    d = _load_counters("traffic_r02.json", workload)
+    if d is None or d.get("envs") != envs_per_gpu:
+        return None
+    return d["traffic_bytes_per_launch_calibrated"]
+
+
+def cpu_baseline(workload: str, cfg_dict, fast: bool, scenario: str, have_gpu: bool = True):
+    """The CPU leg.  With the reference package on this box: the unmodified reference, timed here (kind "reference"),
+    plus the C port for comparison.  Without it: the C port (kind "port") plus the committed reference measurement of
+    the build container, labelled as another box's."""
+    from oracle import ref_bench
+    port = None
+    if have_gpu or scenario != "intersection":  # (the intersection port takes its start states from the engine)
+        port = cpu_baseline_port(cfg_dict, fast, scenario=scenario)
+    if ref_bench.available():
+        out = ref_bench.measure(workload)
+        if port is not None:
+            out["port"] = port
+        return out
+    out = port
     try:
-        d = json.load(open(path))[workload]
-        return d["traffic_bytes_per_launch_calibrated"] if d["envs"] == envs_per_gpu else None
+        rec = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu_baseline.json")))[workload]
+        rec["note"] = ("NOT THE SAME BOX: the unmodified reference timed in the build container (the reference package does "
+                       "not exist on this box); committed by `python bench.py --cpu-baseline-only --save-cpu-baseline`")
+        out["reference_elsewhere"] = rec
     except Exception:
-        return None
+        out["reference_elsewhere"] = None
+    return out
 
 
-def measured_traffic(envs_per_gpu: int, fast: bool = True):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    separate passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
-    tools/traffic_report.py -> profiles/traffic_r01.json).  PMC counters cannot be read from inside this
-    process, so the number is the one measured for the same kernel and config; None if absent or if the
-    run uses another batch size."""
-    path = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if not os.path.exists(path) or envs_per_gpu != ENVS_PER_GPU or not fast:  # (fast is False for every non-headline workload)
-        return None
-    try:
-        return json.load(open(path))["traffic_bytes_per_launch_calibrated"]
-    except Exception:
-        return None
-
-
-def cpu_baseline(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: str = "highway"):
+def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: str = "highway"):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
     from highwayenv_amd import _abi, merge, spawn
@@ -184,13 +224,50 @@ def cpu_baseline_intersection(cfg_dict, budget_s: float = 12.0):
             "vehicle_slots": cfg.num_vehicles}
 
 
+def workload_config(workload: str):
+    """(cfg_dict, fast, scenario) of a --workload, in the reference's config vocabulary."""
+    from highwayenv_amd import _abi
+    fast = workload == "fast"
+    scenario = "highway"
+    if fast:
+        cfg_dict = _abi.highway_fast_default_config()
+        cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
+    elif workload in ("merge", "merge_ma4"):
+        from highwayenv_amd import merge
+        if workload == "merge":
+            scenario, cfg_dict = "merge", merge.merge_default_config()
+        else:
+            scenario, cfg_dict = "merge-generic", merge.merge_generic_default_config()
+            cfg_dict.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
+                             "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
+                             "observation": {"type": "MultiAgentObservation",
+                                             "observation_config": {"type": "Kinematics"}}})
+    elif workload in ("intersection", "intersection_kin"):
+        from highwayenv_amd import intersection as hix
+        scenario, cfg_dict = "intersection", hix.intersection_default_config()
+        cfg_dict.update({"max_vehicles": 30})
+        if workload == "intersection":  # BASELINE config 4: IntersectionEnv({"observation": {"type": "OccupancyGrid"}})
+            cfg_dict["observation"] = {"type": "OccupancyGrid"}
+    else:
+        cfg_dict = _abi.highway_default_config()
+        if workload == "v0_n100":
+            cfg_dict.update({"vehicles_count": 100})
+    return cfg_dict, fast, scenario
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps PER REGION (SURVEY 8d: >= 1000)")
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="run only the CPU leg (needs no GPU): the unmodified reference where it is installed, else the C port")
+    ap.add_argument("--save-cpu-baseline", metavar="PATH", default=None,
+                    help="with --cpu-baseline-only: merge the result into this JSON file under the workload's name "
+                         "(profiles/reference_cpu_baseline.json is what a box without the reference quotes)")
     ap.add_argument("--gather-every", type=int, default=16,
                     help="N > 1: the (obs, reward, done) blocks of this many consecutive steps travel to rank 0 in one RCCL "
                          "gather (every step's outputs still reach rank 0 inside the timed region); 1 = one gather per step")
@@ -205,6 +282,19 @@ def main() -> None:
                     help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds); repeatable")
     args = ap.parse_args()
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
+    cfg_dict, fast, scenario = workload_config(args.workload)
+
+    if args.cpu_baseline_only:
+        out = cpu_baseline(args.workload, cfg_dict, fast, scenario, have_gpu=False)
+        print(json.dumps({"workload": args.workload, "cpu_baseline": out}), flush=True)
+        if args.save_cpu_baseline and out.get("kind") == "reference":
+            try:
+                allw = json.load(open(args.save_cpu_baseline))
+            except Exception:
+                allw = {}
+            allw[args.workload] = out
+            json.dump(allw, open(args.save_cpu_baseline, "w"), indent=1)
+        return
 
     import torch
     import torch.distributed as dist
@@ -230,31 +320,6 @@ def main() -> None:
     from highwayenv_amd.engine import Engine
     from highwayenv_amd.dist import PackedStepOutputs
 
-    fast = args.workload == "fast"
-    scenario = "highway"
-    if fast:
-        cfg_dict = _abi.highway_fast_default_config()
-        cfg_dict.update({"vehicles_count": VEHICLES_COUNT, "lanes_count": LANES})
-    elif args.workload in ("merge", "merge_ma4"):
-        from highwayenv_amd import merge
-        if args.workload == "merge":
-            scenario, cfg_dict = "merge", merge.merge_default_config()
-        else:
-            scenario, cfg_dict = "merge-generic", merge.merge_generic_default_config()
-            cfg_dict.update({"lanes_count": 4, "vehicles_count": 40, "controlled_vehicles": 4,
-                             "action": {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}},
-                             "observation": {"type": "MultiAgentObservation",
-                                             "observation_config": {"type": "Kinematics"}}})
-    elif args.workload in ("intersection", "intersection_kin"):
-        from highwayenv_amd import intersection as hix
-        scenario, cfg_dict = "intersection", hix.intersection_default_config()
-        cfg_dict.update({"max_vehicles": 30})
-        if args.workload == "intersection":  # BASELINE config 4: IntersectionEnv({"observation": {"type": "OccupancyGrid"}})
-            cfg_dict["observation"] = {"type": "OccupancyGrid"}
-    else:
-        cfg_dict = _abi.highway_default_config()
-        if args.workload == "v0_n100":
-            cfg_dict.update({"vehicles_count": 100})
     E = args.envs_per_gpu
     cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario, tuning=tuning)
     N, A = cfg.num_vehicles, cfg.num_agents
@@ -266,7 +331,8 @@ def main() -> None:
     eng.reset(base_seed=1_000_003 * (rank + 1), **spawn_kw)
     eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), **spawn_kw)
 
-    total = args.warmup + args.steps
+    R = max(1, args.repeats)
+    total = args.warmup + R * args.steps
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     n_actions = 3 if scenario == "intersection" else 5
@@ -308,14 +374,22 @@ def main() -> None:
     for t in range(args.warmup):
         one_step(t)
     fence()
-    # HIP events on the launch stream around every 8th launch of the timed region (an event pair costs ~8 us of
+    # HIP events on the launch stream around every 8th launch of the timed regions (an event pair costs ~8 us of
     # stream time, 12 % of a launch: timing every launch would slow down the very loop being measured)
     eng.profile_enable(0 if os.environ.get("HWY_BENCH_NO_EVENTS") == "1" else EVENT_EVERY)
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total):
-        one_step(t)
-    fence()
-    elapsed = time.perf_counter() - t0
+    region_s = []
+    for r in range(R):
+        t_first = args.warmup + r * args.steps
+        t0 = time.perf_counter()
+        for t in range(t_first, t_first + args.steps):
+            one_step(t)
+        fence()
+        dt_r = time.perf_counter() - t0
+        el = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        region_s.append(el.item())
+    elapsed = float(np.median(region_s))
     kernel_ms, launches = eng.profile_read()
     eng.profile_enable(0)
 
@@ -333,10 +407,6 @@ def main() -> None:
 
     # statistics of the run (sanity: the workload really stepped and reset)
     term = outs[((total - 1) // K) & 1].terminated((total - 1) % K).sum().item()
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = el.item()
 
     if rank == 0:
         env_steps = args.steps * E * world
@@ -352,7 +422,10 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "repeats": R,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_repeats": [x / args.steps * 1e3 for x in region_s],
+            "timing": f"median of {R} regions of {args.steps} steps (barrier + synchronize on both sides, max over ranks)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -381,18 +454,19 @@ def main() -> None:
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(E, fast) if scenario == "highway" else measured_traffic_other(args.workload, E),
+                         "traffic": measured_traffic(args.workload, E),
+                         "kernel_source_sha16": _kernel_build_id(),
                          "kernel": ("hwy_ix_step_kernel  (one 64-wide wavefront per env)" if scenario == "intersection" else
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "algorithmic_bytes_per_launch": b_env * E,
-                         "valu": valu_view(E, avg_kernel_s) if fast else None},
+                         "valu": valu_view(E, avg_kernel_s, args.workload)},
             "terminated_in_last_step": int(term),
             "host_path_env_steps_per_s": host_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg_dict, fast, scenario=scenario)
+            line["cpu_baseline"] = cpu_baseline(args.workload, cfg_dict, fast, scenario)
         print(json.dumps(line), flush=True)
     eng.close()
     if use_dist:

@@ -36,6 +36,19 @@ def is_stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) over every source the engine library is built from + the hipcc flags: the identity
+    of a kernel build.  rocprofv3 counter summaries under profiles/ record it, and bench.py only quotes counters whose
+    hash equals the running build's."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_engine(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH

@@ -432,11 +432,15 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
         const int ci = ctz64(cm);
         cm &= cm - 1;
         const int Tc = wave_bcast_i(tgt_old, ci);
+        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+        // only ANOTHER vehicle moving into the same lane can block (behavior.py:233-237); usually there is none and the
+        // link costs three compares and a ballot instead of eight readlanes and a desired gap
+        const bool rival = active && i != ci && me.lane != Tc && my_tgt_seen == Tc;
+        if (__ballot(rival) == 0) continue;
         const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
         const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
-        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
         bool blk = false;
-        if (active && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+        if (rival) {
           const double d = me.x - xc;
           const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
           blk = (0 < d) && (d < d_star);

@@ -84,6 +84,10 @@ def test_impact_sign_agreement_rate(backend):
         K = g.steps * T
         for with_actions in (True, False):
             ks = [k for k in range(K) if (k % T == 0) == with_actions]
+            if backend == "emu":  # the CPU emulation only replays the frames in which the reference recorded a hit
+                ks = [k for k in ks if (g.state("frame", k)["flags"] & _abi.F_HAS_IMPACT).any()]
+            if not ks:
+                continue
             start = {f: np.concatenate([(g.state("init", envs=slice(0, Ef)) if k == 0 else g.state("frame", k - 1))[f]
                                         for k in ks]) for f in _abi.STATE_F64 + _abi.STATE_I32 + ["time"]}
             want = {f: np.concatenate([g.state("frame", k)[f] for k in ks]) for f in start}

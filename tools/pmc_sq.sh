@@ -11,7 +11,7 @@ P2="SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL
 P3="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE"
 k=0
 for P in "$P1" "$P2" "$P3"; do k=$((k+1))
-timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_$W/p$k -o run -- python $R/bench.py --workload $W --envs-per-gpu $E --no-cpu-baseline --steps 30 --warmup 40 > /dev/null 2> $R/gpurun_out/pmc_$W/p$k.err
+timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_$W/p$k -o run -- python $R/bench.py --workload $W --envs-per-gpu $E --no-cpu-baseline --steps 30 --warmup 40 --repeats 1 > /dev/null 2> $R/gpurun_out/pmc_$W/p$k.err
 done
 cd $R
 python - "$W" "$E" "$K" <<'PY'
@@ -24,6 +24,9 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{W}/p*/")):
             if K in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: sum(v[-30:]) / len(v[-30:]) / E for k, v in acc.items()}
-json.dump({"workload": W, "envs": E, "kernel": K, "per_wave_per_step": out}, open(f"gpurun_out/pmc_sq_{W}.json", "w"), indent=1)
+sys.path.insert(0, ".")
+from highwayenv_amd import build
+json.dump({"workload": W, "envs": E, "kernel": K, "kernel_source_sha16": build.kernel_source_hash(),
+           "waves_per_simd": min(4.0, E / 1024.0), "per_wave_per_step": out}, open(f"gpurun_out/pmc_sq_{W}.json", "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -27,4 +27,9 @@ for name, d, key in (("FETCH_SIZE", fetch_dir, "frames0_read_bytes"), ("WRITE_SI
 out["traffic_bytes_per_launch_calibrated"] = out["FETCH_SIZE"]["step_bytes_calibrated"] + out["WRITE_SIZE"]["step_bytes_calibrated"]
 out["traffic_bytes_per_launch_raw"] = out["FETCH_SIZE"]["step_bytes_raw"] + out["WRITE_SIZE"]["step_bytes_raw"]
 out["algorithmic_bytes_per_launch"] = known["algorithmic_bytes_per_step"]
+out["envs"], out["workload"] = known["E"], "fast"
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from highwayenv_amd import build  # noqa: E402
+out["kernel_source_sha16"] = build.kernel_source_hash()  # bench.py quotes these counters only for this kernel build
 print(json.dumps(out, indent=1))
