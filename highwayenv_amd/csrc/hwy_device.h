@@ -115,6 +115,11 @@ struct StepParams {
   double dt, policy_dt, duration, lane_width, road_length, speed_limit;
   double collision_reward, right_lane_reward, high_speed_reward, rs0, rs1, perception;
   double rx0, rx1, ry0, ry1, rvx0, rvx1, rvy0, rvy1;
+  // reciprocals of the constant denominators of utils.lmap (utils.py:31-33), computed once on the host in f64: the
+  // one-wavefront kernel multiplies by them instead of running an IEEE f64 division (~30 instructions) per observed
+  // feature and per reward term -- at most 1 ulp (f64) away from the quotient, far below the f32 observation's own
+  // rounding and the 1e-9 reward tolerance
+  double inv_rx, inv_ry, inv_rvx, inv_rvy, inv_rs, inv_reward_span, inv_lanes;
   // OccupancyGridObservation (obs_type == HWY_OBS_OCCUPANCY_GRID)
   int32_t obs_type, gW, gH, g_nwp;  // grid shape; waypoints per lane of the on-road layer
   double gmin_x, gmin_y, gstep_x, gstep_y, g_spacing;
@@ -124,6 +129,7 @@ struct StepParams {
   int32_t n_frames;       // frames to simulate (T for a policy step)
   int32_t full_step;      // 1: advance time, observe, reward, done flags; 0: frames only
   int32_t autoreset;      // 1: envs with done[e] are re-spawned instead of stepped
+  int32_t prio_shift;     // > 0: issue-priority rotation among the wavefronts of a SIMD (hwy_wave.h: WaveTurn); 0: off
   const int32_t *actions;  // [E][A] or nullptr
   float *obs;              // [E][A][V][F] or nullptr
   double *reward;          // [E][A]
@@ -148,6 +154,10 @@ __device__ inline double clipd(double a, double lo, double hi) { return fmin(fma
 // utils.py:31-33
 __device__ inline double lmap(double v, double x0, double x1, double y0, double y1) {
   return y0 + (v - x0) * (y1 - y0) / (x1 - x0);
+}
+// the same with the host-computed reciprocal of (x1 - x0) (StepParams::inv_*)
+__device__ inline double lmap_inv(double v, double x0, double inv_dx, double y0, double y1) {
+  return y0 + ((v - x0) * (y1 - y0)) * inv_dx;
 }
 
 // ---- counter-based RNG for the device-side reset: Philox-4x32-10 --------------------------
@@ -229,13 +239,14 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 struct SatAcc {
   bool intersecting, will;
   double min_distance, axx, axy;
+  int order;  // position of the winning normal in the reference's loop over the 8 normals
 };
-struct SatAxis {
-  double nx, ny, dot;  // direction, and (centre_a - centre_b) . n
-  double dn, dm;       // interval distance for the normal +n and for the normal -n
-};
-__device__ inline SatAxis sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
-                                   double vp, double cdx, double cdy) {
+// One axis DIRECTION n of polygon `poly` (0 = a, 1 = b): both of its normals (+n and -n) are folded into the running
+// minimum at once.  `first_minus`: the reference meets -n first (the body axis u: order -u .. +u) or +n first (w: +w .. -w);
+// k0 / k1 = positions of the two normals in the reference's loop, so "first minimum wins" becomes "smaller |d|, then
+// smaller position" and no per-axis result has to stay live until its turn.
+__device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
+                                double vp, double cdx, double cdy, int k_plus, int k_minus) {
   double min_a = ca_ - ra, max_a = ca_ + ra;
   const double min_b = cb_ - rb, max_b = cb_ + rb;
   if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) acc.intersecting = false;
@@ -244,24 +255,20 @@ __device__ inline SatAxis sat_axis(SatAcc &acc, double nx, double ny, double ca_
   const double dn = min_a < min_b ? g1 : g2;  // normal +n
   const double dm = max_a > max_b ? g2 : g1;  // normal -n: the intervals are the exact negations, [-max, -min]
   if (dn > 0) acc.will = false;                // (disjoint intervals: dn == dm)
-  return SatAxis{nx, ny, cdx * nx + cdy * ny, dn, dm};
-}
-// one normal: keep the first minimum; translation_axis = normal if d.dot(normal) > 0 else -normal (utils.py:232-236)
-__device__ inline void sat_take(SatAcc &acc, const SatAxis &ax, bool minus) {
-  const double d = minus ? ax.dm : ax.dn;
-  if (fabs(d) < acc.min_distance) {
-    acc.min_distance = fabs(d);
-    const bool pos = minus ? !(ax.dot < 0) : (ax.dot > 0);  // in units of +n
-    acc.axx = pos ? ax.nx : -ax.nx;
-    acc.axy = pos ? ax.ny : -ax.ny;
+  // the better of the two normals of this direction (ties: the one the reference meets first)
+  const double an = fabs(dn), am = fabs(dm);
+  const bool take_minus = am < an || (am == an && k_minus < k_plus);
+  const double d = take_minus ? am : an;
+  const int k = take_minus ? k_minus : k_plus;
+  if (d < acc.min_distance || (d == acc.min_distance && k < acc.order)) {
+    acc.min_distance = d;
+    acc.order = k;
+    // translation_axis = normal if d.dot(normal) > 0 else -normal (utils.py:232-236), in units of +n
+    const double dot = cdx * nx + cdy * ny;
+    const bool pos = take_minus ? !(dot < 0) : (dot > 0);
+    acc.axx = pos ? nx : -nx;
+    acc.axy = pos ? ny : -ny;
   }
-}
-// the four edge normals of one rectangle in the reference's order: -u, +w, +u, -w
-__device__ inline void sat_polygon(SatAcc &acc, const SatAxis &u, const SatAxis &w) {
-  sat_take(acc, u, true);
-  sat_take(acc, w, false);
-  sat_take(acc, u, false);
-  sat_take(acc, w, true);
 }
 __device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
@@ -275,15 +282,14 @@ __device__ inline int pair_collide(const Body &A, const Body &B, double dt, doub
   const double ddx = A.v * A.c * dt - B.v * B.c * dt, ddy = A.v * A.s * dt - B.v * B.s * dt;
   const double cdx = A.x - B.x, cdy = A.y - B.y;  // centre difference (mean of the corners)
   const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);  // |cos|, |sin| of (h_b - h_a)
-  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0};
+  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0, 8};
+  // the reference's order of the 8 normals: -u_a, +w_a, +u_a, -w_a, -u_b, +w_b, +u_b, -w_b  (positions 0..7)
   // u_a = (cos h_a, sin h_a), w_a = (-sin h_a, cos h_a)
-  const SatAxis ua = sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy);
-  const SatAxis wa = sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy);
-  sat_polygon(acc, ua, wa);
+  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy, 2, 0);
+  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy, 1, 3);
   // u_b, w_b
-  const SatAxis ub = sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy);
-  const SatAxis wb = sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy);
-  sat_polygon(acc, ub, wb);
+  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy, 6, 4);
+  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy, 5, 7);
   if (acc.will) {
     *tx = acc.min_distance * acc.axx;
     *ty = acc.min_distance * acc.axy;

@@ -3,6 +3,7 @@
 // (hwy_engine.cpp).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#define HWY_HAVE_SETPRIO 1  // s_setprio / s_memtime / s_getreg exist on the device (not in the CPU emulation of tests/emu)
 #include "hwy_device.h"
 #include "hwy_wave.h"
 #include "hwy_net.h"

@@ -6,6 +6,10 @@
 
 #include "hwy_device.h"
 
+#ifndef HWY_DEFAULT_PRIO_SHIFT
+#define HWY_DEFAULT_PRIO_SHIFT 14  // 16 k clock ticks (~7 us) per turn: measured best at 4096 envs (profiles/r02_history.md)
+#endif
+
 namespace hwy {
 
 inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
@@ -23,6 +27,12 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.perception = c.perception_distance;
   p.rx0 = c.obs_range_x[0]; p.rx1 = c.obs_range_x[1]; p.ry0 = c.obs_range_y[0]; p.ry1 = c.obs_range_y[1];
   p.rvx0 = c.obs_range_vx[0]; p.rvx1 = c.obs_range_vx[1]; p.rvy0 = c.obs_range_vy[0]; p.rvy1 = c.obs_range_vy[1];
+  p.inv_rx = 1.0 / (p.rx1 - p.rx0); p.inv_ry = 1.0 / (p.ry1 - p.ry0);
+  p.inv_rvx = 1.0 / (p.rvx1 - p.rvx0); p.inv_rvy = 1.0 / (p.rvy1 - p.rvy0);
+  p.inv_rs = 1.0 / (p.rs1 - p.rs0);
+  p.inv_reward_span = 1.0 / ((p.high_speed_reward + p.right_lane_reward) - p.collision_reward);
+  p.inv_lanes = 1.0 / (double)(p.L - 1 > 1 ? p.L - 1 : 1);
+  p.prio_shift = c.tune_prio_shift < 0 ? 0 : (c.tune_prio_shift > 0 ? c.tune_prio_shift : HWY_DEFAULT_PRIO_SHIFT);
   p.obs_type = c.obs_type;
   if (c.obs_type == HWY_OBS_OCCUPANCY_GRID) {
     p.gW = c.grid_shape[0]; p.gH = c.grid_shape[1];

@@ -42,6 +42,50 @@ __device__ inline int wave_send_i(int v, int dst) { return __builtin_amdgcn_ds_p
   const StepParams &q = *(const StepParams *)kernarg_
 #endif
 
+// ---- taking turns at the SIMD's issue port ------------------------------------------------------------------------------
+// The hardware arbiter issues from the OLDEST ready wavefront first.  With exactly four environments per SIMD (4096 envs)
+// that lets the first wavefront run as if it were alone (latency-bound: ~30 % of the VALU issue slots), the next two fill
+// the gaps, the fourth gets the leftovers and then finishes ALONE at the same 30 %: measured end times of the four
+// wavefronts of a SIMD 24 / 31 / 37 / 43 us (tools/wave_timeline2.py).  Equal shares would end all four together, sooner.
+// So every wavefront sets its own priority (s_setprio, 0..3) to (hardware wave slot + clock >> shift) & 3: at any time the
+// four wavefronts of a SIMD hold four different priorities and the top one changes every 2^shift clock ticks.  The clock
+// is read with s_memtime one turn ahead (the value requested at the previous checkpoint is used), so no checkpoint waits
+// for it.  Scheduling only: no result depends on it.
+struct WaveTurn {
+  unsigned long long t;
+  int slot, shift;
+};
+__device__ inline void wave_turn_init(WaveTurn &w, int shift) {
+#ifdef HWY_HAVE_SETPRIO
+  w.shift = shift;
+  w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4 /* HW_REG_HW_ID, WAVE_ID bits 3:0 */) & 3) : 0;
+  w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+  (void)w; (void)shift;
+#endif
+}
+__device__ inline void wave_turn(WaveTurn &w) {
+#ifdef HWY_HAVE_SETPRIO
+  if (w.shift > 0) {  // wave-uniform (SGPR)
+    const int prio = (w.slot + (int)(w.t >> w.shift)) & 3;
+    w.t = __builtin_amdgcn_s_memtime();
+    if (prio == 0) __builtin_amdgcn_s_setprio(0);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
+#else
+  (void)w;
+#endif
+}
+
+// One wavefront == one workgroup: LDS instructions of a wavefront execute in order, so a ds_read issued after a ds_write
+// of the same wavefront sees it without any wait or s_barrier.  Only the COMPILER must keep the order (and the CPU
+// emulation of tests/emu, whose 64 threads are separate fibers, needs a real rendezvous).
+#ifndef HWY_WAVE_LDS_FENCE
+#define HWY_WAVE_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#endif
+
 struct WaveShared {
   // frame snapshot in RANK order (slot r == r-th vehicle along the road)
   double x[64], v[64], c[64], s[64], lr[64];  // lr = log(v/v0), see EnvBlock::idm_log_ratio
@@ -203,9 +247,9 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
           }
           if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
             const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
-            const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+            const double ir = fid == HWY_FEAT_X ? p.inv_rx : fid == HWY_FEAT_Y ? p.inv_ry : fid == HWY_FEAT_VX ? p.inv_rvx : p.inv_rvy;
             if (r0 > -__builtin_inf()) {
-              val = lmap(val, r0, r1, -1.0, 1.0);
+              val = lmap_inv(val, r0, ir, -1.0, 1.0);
               if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
             }
           }
@@ -220,15 +264,14 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
       const bool on_road = fabs(me.y - me.lane * p.lane_width) <= p.lane_width / 2 + 0.0 && -5.0 <= me.x &&
                            me.x < p.road_length + 5.0;
       const double forward_speed = me.v * me.ch;
-      const double scaled_speed = lmap(forward_speed, p.rs0, p.rs1, 0.0, 1.0);
-      const int nl = p.L - 1 > 1 ? p.L - 1 : 1;
+      const double scaled_speed = lmap_inv(forward_speed, p.rs0, p.inv_rs, 0.0, 1.0);
       double reward = 0.0;
       reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
-      reward = reward + p.right_lane_reward * ((double)me.tgt / (double)nl);
+      reward = reward + p.right_lane_reward * ((double)me.tgt * p.inv_lanes);
       reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
       reward = reward + 0.0 * (on_road ? 1.0 : 0.0);
       if (p.flags & HWY_C_NORMALIZE_REWARD)
-        reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
+        reward = lmap_inv(reward, p.collision_reward, p.inv_reward_span, 0.0, 1.0);
       reward *= (on_road ? 1.0 : 0.0);
       p.reward[(size_t)e * p.A + a] = reward;
       if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
@@ -283,14 +326,19 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     return;
   }
 
+  WaveTurn turn;
+  wave_turn_init(turn, p.prio_shift);
+  // the meta-actions are requested BEFORE the state (lane a fetches agent a's): one HBM round trip instead of two
+  const int act_lane = (p.actions && i < p.A) ? p.actions[(size_t)e * p.A + i] : HWY_IDLE;
   Veh me;
   load_vehicle<1>(p, e, me);
   const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
   const bool idm = active && !controlled;
-  int agent = 0;
-  if (controlled)
-    for (int a = 0; a < p.A; ++a)
-      if (p.agent_index[a] == i) agent = a;
+  int agent = 0, act0 = HWY_IDLE;
+  for (int a = 0; a < p.A; ++a) {  // wave-uniform
+    const int act_a = wave_bcast_i(act_lane, a);
+    if (controlled && p.agent_index[a] == i) { agent = a; act0 = act_a; }
+  }
   sh.timer[i] = me.timer; sh.ts[i] = me.ts; sh.delta[i] = me.delta; sh.impx[i] = me.impx; sh.impy[i] = me.impy;
   const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;
   const u64 chk = __ballot(active && i_check);
@@ -301,9 +349,10 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   int rank = active ? me.rank : i;
   bool has_tie = false;  // two vehicles share the same x (=> literal neighbour scans)
   for (int fr = 0; fr < p.n_frames; ++fr) {
+    wave_turn(turn);
     // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315) ------------------------------
     if (fr == 0 && p.actions && controlled) {
-      const int act = p.actions[(size_t)e * p.A + agent];
+      const int act = act0;
       if (act == HWY_FASTER || act == HWY_SLOWER) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
         int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
@@ -335,16 +384,17 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     }
     // frame-start snapshot, stored in rank order (with each vehicle's IDM log speed ratio)
     const double log_ratio = active ? B::idm_log_ratio(p, me.v, sh.ts[i]) : 0.0;  // egos and wrecks can be followers too
-    __syncthreads();  // previous frame's gathers are complete (single wave: an s_barrier no-op + waitcnt)
+    HWY_WAVE_LDS_FENCE();  // previous frame's gathers are complete
     if (active) {
       sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
       sh.idx[rank] = i;
     }
     if (i < p.L + 2) sh.lane_mask[i] = m_pub;
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     const u64 m_own = sh.lane_mask[me.lane + 1], m_left = sh.lane_mask[me.lane], m_right = sh.lane_mask[me.lane + 2];
     const u64 m_tgt = sh.lane_mask[me.tgt + 1];
 
+    wave_turn(turn);
     // ---- D. Road.act: lane-change policy (behavior.py:219-263) ----------------------------------------
     const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
     const bool drives = idm && !crashed0;
@@ -449,6 +499,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       }
     }
 
+    wave_turn(turn);
     // ---- E. Road.act: low-level control ----------------------------------------------------------------
     const double inv_v = fast_rcp(not_zero(me.v));
     double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);
@@ -488,6 +539,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       sincos_bounded(me.h, &me.sh, &me.ch);
     }
 
+    wave_turn(turn);
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
     const Body mine{me.x, me.y, me.v, me.ch, me.sh};
     if (all_check) {
@@ -499,7 +551,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       // result equals the full loop; "last pair in loop order wins" == the partner with the highest index.
       sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
       const bool wide = __ballot(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
-      __syncthreads();
+      HWY_WAVE_LDS_FENCE();
       if (active) {
         // radius + relative motion, for bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and
         // are not faster than 50 m/s afterwards (the radius term).  Both are checked on the actual values (`wide`,

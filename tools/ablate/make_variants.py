@@ -120,7 +120,7 @@ def net_ticks(text):
 def wave_reload(text):
     """Frame loop of the one-wavefront kernel reads its parameters through a per-iteration view of the kernarg segment
     (short-lived SGPRs instead of values kept -- and spilled -- across the loop)."""
-    a = text.index("  for (int fr = 0; fr < p.n_frames; ++fr) {\n    // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315)")
+    a = text.index("  for (int fr = 0; fr < p.n_frames; ++fr) {\n    wave_turn(turn);")
     b = text.index("  }  // frames", a)
     body = text[a:b]
     head, rest = body.split("{\n", 1)
@@ -160,8 +160,27 @@ VARIANTS = {
                           "    __builtin_amdgcn_s_waitcnt(0);\n"
                           "    const unsigned long long tl_t1 = wall_clock64();\n"
                           "    unsigned *o = (unsigned *)(q.obs + (size_t)e * q.A * q.V * q.F);\n"
-                          "    o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc;\n"
-                          "  }\n}"))],
+                          "    o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u;\n"
+                          "  }\n}")),
+                  # event counters (LDS atomics): SAT trips, near pairs, chain links (all / with a rival), follower-test trips, recounts
+                  (W, sub("struct WaveShared {", "struct WaveShared {\n  int cnt[8];")),
+                  (W, sub("  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift);",
+                          "  if (i < 8) sh.cnt[i] = 0;\n  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift);")),
+                  (W, sub("              r = pair_collide(A, Bb, p.dt, &tx, &ty);", "              atomicAdd(&sh.cnt[0], 1); r = pair_collide(A, Bb, p.dt, &tx, &ty);")),
+                  (W, sub("            if (!surely_apart(A, Bb, p.dt)) {", "            atomicAdd(&sh.cnt[1], 1);\n            if (!surely_apart(A, Bb, p.dt)) {")),
+                  (W, sub("        if (__ballot(rival) == 0) continue;", "        if (i == 0) atomicAdd(&sh.cnt[2], 1);\n        if (__ballot(rival) == 0) continue;\n        if (i == 0) atomicAdd(&sh.cnt[3], 1);")),
+                  (W, sub("        if (pend_l || pend_r) {", "        if (i == 0) atomicAdd(&sh.cnt[4], 1);\n        if (pend_l || pend_r) {")),
+                  (W, sub("o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u;",
+                          "o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u; for (int k = 0; k < 5; ++k) o[5 + k] = (unsigned)sh.cnt[k];")),
+                  (W, sub("      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n    return;",
+                          "      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n"
+                          "    if (p.obs && i == 0) {\n"
+                          "      __builtin_amdgcn_s_waitcnt(0);\n"
+                          "      const unsigned long long tl_t1 = wall_clock64();\n"
+                          "      unsigned *o = (unsigned *)(p.obs + (size_t)e * p.A * p.V * p.F);\n"
+                          "      o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 1u;\n"
+                          "    }\n"
+                          "    return;"))],
     # intersection kernel (hwy_ix.h): sections removed (timing only)
     "ixbase": [],
     "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Developer tool: register / LDS / scratch table of every kernel in the gfx950 code object (from the assembly that
+tools/asm_loop_stats.py leaves in tools/ablate/_build/asm_base, or a fresh -save-temps compile)."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tools", "ablate", "_build", "asm_base")
+ASM = os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+if "--fresh" in sys.argv or not os.path.exists(ASM):
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-gline-tables-only",
+                    "-c", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip"), "-o", os.path.join(OUT, "k.o"),
+                    "-save-temps=obj"], check=True, capture_output=True, cwd=OUT)
+s = open(ASM).read()
+meta = s[s.index("amdhsa.kernels:"):]
+print(f"{'kernel':58s} {'vgpr':>5s} {'spill':>5s} {'sgpr':>5s} {'s-spill':>7s} {'LDS B':>6s} {'priv B':>6s} {'scratch ops':>11s} {'waves/SIMD':>10s}")
+for blk in meta.split("  - .agpr_count:")[1:]:
+    def g(k):
+        m = re.search(r"\.%s:\s+(\S+)" % k, blk)
+        return m.group(1) if m else "?"
+    name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip().replace("hwy::", "")
+    name = re.sub(r"\(.*\)$", "", name).replace("void ", "")
+    v = int(g("vgpr_count"))
+    sym = g("name")
+    a = s.index("\n" + sym + ":")
+    body = s[a:s.index(".Lfunc_end", a)]
+    n_scratch = len(re.findall(r"^\s+(scratch_|buffer_)(load|store)", body, flags=re.M))
+    occ = min(8, 512 // max(v, 1)) if v else 8
+    print(f"{name:58s} {v:5d} {g('vgpr_spill_count'):>5s} {g('sgpr_count'):>5s} {g('sgpr_spill_count'):>7s} "
+          f"{g('group_segment_fixed_size'):>6s} {g('private_segment_fixed_size'):>6s} {n_scratch:11d} {occ:10d}")
