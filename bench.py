@@ -283,10 +283,20 @@ def main() -> None:
     args = ap.parse_args()
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
     cfg_dict, fast, scenario = workload_config(args.workload)
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner through C
+    # stdio when a communicator is created), so everything else is sent to stderr: fd 1 is pointed at fd 2 for the whole
+    # run and the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj) -> None:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     if args.cpu_baseline_only:
         out = cpu_baseline(args.workload, cfg_dict, fast, scenario, have_gpu=False)
-        print(json.dumps({"workload": args.workload, "cpu_baseline": out}), flush=True)
+        emit({"workload": args.workload, "cpu_baseline": out})
         if args.save_cpu_baseline and out.get("kind") == "reference":
             try:
                 allw = json.load(open(args.save_cpu_baseline))
@@ -340,36 +350,41 @@ def main() -> None:
     # two alternating output buffers of K step blocks each: the RCCL gather of one buffer (async, on RCCL's stream)
     # overlaps the step kernels that fill the other one.  K = --gather-every (1 without a collective).
     K = max(1, args.gather_every) if use_dist else 1
-    outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist, depth=K) for _ in range(2)]
-    works = [None, None]
-    pending = [False, False]
-    out = outs[0]
 
-    def one_step(t: int) -> None:
-        k, slot = (t // K) & 1, t % K
-        if slot == 0 and works[k] is not None:
-            works[k].wait()  # stream-level: buffer k was gathered, the engine may overwrite it
-            works[k] = None
-        eng.step_device(actions[t].data_ptr(), *outs[k].pointers(slot))
-        pending[k] = True
-        if use_dist and slot == K - 1:
-            works[k] = outs[k].gather_async()
-            pending[k] = False
+    def make_stepper(K):
+        outs = [PackedStepOutputs(cfg, dev, world, rank, force_collective=use_dist, depth=K) for _ in range(2)]
+        works = [None, None]
+        pending = [False, False]
 
-    def drain() -> None:
-        for k in (0, 1):
-            if use_dist and pending[k]:  # a partly filled buffer at the end of a region still travels
+        def one_step(t: int) -> None:
+            k, slot = (t // K) & 1, t % K
+            if slot == 0 and works[k] is not None:
+                works[k].wait()  # stream-level: buffer k was gathered, the engine may overwrite it
+                works[k] = None
+            eng.step_device(actions[t].data_ptr(), *outs[k].pointers(slot))
+            pending[k] = True
+            if use_dist and slot == K - 1:
                 works[k] = outs[k].gather_async()
                 pending[k] = False
-            if works[k] is not None:
-                works[k].wait()
-                works[k] = None
 
-    def fence() -> None:
-        drain()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def drain() -> None:
+            for k in (0, 1):
+                if use_dist and pending[k]:  # a partly filled buffer at the end of a region still travels
+                    works[k] = outs[k].gather_async()
+                    pending[k] = False
+                if works[k] is not None:
+                    works[k].wait()
+                    works[k] = None
+
+        def fence() -> None:
+            drain()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        return one_step, fence, outs
+
+    one_step, fence, outs = make_stepper(K)
 
     for t in range(args.warmup):
         one_step(t)
@@ -392,6 +407,31 @@ def main() -> None:
     elapsed = float(np.median(region_s))
     kernel_ms, launches = eng.profile_read()
     eng.profile_enable(0)
+    # what an event pair alone measures on this stream (no kernel in between): the sampled launches carry about this much
+    # on top of the kernel itself, which is why avg_kernel_us can exceed ms_per_step
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a_, b_ in ev:
+        a_.record(stream)
+        b_.record(stream)
+    torch.cuda.synchronize(dev)
+    event_pair_us = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]) * 1e3)
+    # N > 1: the same loop with ONE gather per step (what a policy that needs every step's outputs on rank 0 before it can
+    # act would see), reported next to the batched number
+    per_step_gather = None
+    if use_dist and K != 1:
+        one_step1, fence1, _ = make_stepper(1)
+        n1 = min(args.steps, 300)
+        for t in range(args.warmup, args.warmup + 20):
+            one_step1(t)
+        fence1()
+        t0 = time.perf_counter()
+        for t in range(args.warmup, args.warmup + n1):
+            one_step1(t)
+        fence1()
+        el1 = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(el1, op=dist.ReduceOp.MAX)
+        per_step_gather = {"steps": n1, "ms_per_step": el1.item() / n1 * 1e3, "value": n1 * E * world / el1.item(),
+                           "unit": "env-steps/s", "gather": "one RCCL gather per step"}
 
     # PCIe-inclusive rate of the host-pointer entry point (hwy_step: H2D actions, kernel, D2H results, sync);
     # reported for DESIGN.md, never as `value`
@@ -449,7 +489,9 @@ def main() -> None:
                                     "pairwise collisions, random actions, Kinematics 5x5 obs, device spawn + auto-reset"),
                        "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}",
                        "gather": (f"one RCCL gather of every rank's (obs, reward, done) blocks to rank 0 per {K} steps"
-                                  if use_dist else "none (single rank)")},
+                                  if use_dist else "none (single rank)"),
+                       "world_size_reported_by_the_process_group": dist.get_world_size() if use_dist else 1},
+            "gather_every_1": per_step_gather,
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -460,14 +502,16 @@ def main() -> None:
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
+                         "empty_event_pair_us": event_pair_us,
                          "algorithmic_bytes_per_launch": b_env * E,
                          "valu": valu_view(E, avg_kernel_s, args.workload)},
             "terminated_in_last_step": int(term),
+            "ix_spawn_counters": (lambda c: dict(c, drop_rate=c["ix_spawns_dropped"] / max(1, c["ix_spawns"] + c["ix_spawns_dropped"])))(eng.counters()) if scenario == "intersection" else None,
             "host_path_env_steps_per_s": host_rate,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, cfg_dict, fast, scenario)
-        print(json.dumps(line), flush=True)
+        emit(line)
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -18,7 +18,8 @@ EXPORTS = [
     "hwy_abi_version", "hwy_config_size", "hwy_device_count", "hwy_status_string", "hwy_create",
     "hwy_destroy", "hwy_last_error", "hwy_set_state", "hwy_get_state", "hwy_reset", "hwy_step",
     "hwy_step_device", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
-    "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math",
+    "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math", "hwy_get_counters",
+    "hwy_comm_unique_id", "hwy_comm_init", "hwy_gather", "hwy_comm_destroy",
 ]
 
 
@@ -56,12 +57,18 @@ def load() -> C.CDLL:
     lib.hwy_set_autoreset.argtypes = [vp, i32, C.c_uint64, f64, f64, i32]
     lib.hwy_sync.argtypes = [vp]
     lib.hwy_debug_math.argtypes = [vp, i32, vp, vp, C.c_int64]
+    lib.hwy_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), i32, i32]
+    lib.hwy_get_counters.restype = C.c_int
+    lib.hwy_comm_unique_id.argtypes = [vp]
+    lib.hwy_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.hwy_gather.argtypes = [vp, vp, vp, C.c_size_t, i32]
+    lib.hwy_comm_destroy.argtypes = [vp]
     lib.hwy_profile_enable.argtypes = [vp, i32]
     lib.hwy_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name.startswith(("hwy_create", "hwy_destroy", "hwy_set", "hwy_get", "hwy_reset",
-                                                      "hwy_step", "hwy_observe", "hwy_sync", "hwy_profile", "hwy_debug")):
+                                                      "hwy_step", "hwy_observe", "hwy_sync", "hwy_profile", "hwy_debug", "hwy_comm", "hwy_gather")):
             if name not in ("hwy_status_string", "hwy_last_error", "hwy_config_size"):
                 fn.restype = C.c_int
     if lib.hwy_abi_version() != _abi.HWY_ABI_VERSION:

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libhwy_engine.so")
-SOURCES = ["hwy_kernels.hip", "hwy_engine.hip"]
+SOURCES = ["hwy_kernels.hip", "hwy_engine.hip", "hwy_comm.hip"]
 import glob
 
 # every header the two translation units can include: csrc/*.h (hwy_device.h, hwy_wave.h, hwy_net.h, hwy_ix.h, ...)
@@ -61,7 +61,7 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/hwy_engine.h"
+#include "hwy_comm.h"
 #include "hwy_launch.h"
 #include "hwy_params.h"
 
@@ -36,6 +37,7 @@ struct hwy_engine {
   hwy_glane *d_gnet = nullptr;      // intersection scenario: lane table
   double *d_shadow_f64 = nullptr;   // intersection scenario, pre-warming of next episodes: second copy of the planes
   int32_t *d_shadow_packed = nullptr, *d_shadow_route = nullptr, *d_shadow_meta = nullptr;
+  unsigned long long *d_counters = nullptr;  // [HWY_CTR_COUNT] (hwy_get_counters)
   double *d_time = nullptr;
   uint8_t *d_done = nullptr;
   uint32_t *d_episode = nullptr;
@@ -64,6 +66,7 @@ struct hwy_engine {
   size_t events_used = 0;
   double prof_ms = 0.0;
   int64_t prof_launches = 0;
+  hwy::Comm *comm = nullptr;  // hwy_comm_init
   std::string err;
 };
 
@@ -185,6 +188,7 @@ static void fill_ix(const hwy_engine *eng, const StepParams &p, hwy::IxParams &i
   hwy::ix_params_from_config(eng->cfg, p, ip);
   ip.lanes = eng->d_gnet;
   ip.route = eng->d_route;
+  ip.counters = eng->d_counters;
   ip.road_steps = eng->d_road_steps;
   if (eng->d_shadow_meta) {
     hwy::bind_planes(eng->d_shadow_f64, (size_t)eng->cfg.num_envs * eng->pitch, ip.shadow);
@@ -306,6 +310,8 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
       if ((e = hipMemsetAsync(eng->d_shadow_meta, 0xff, E * 4 * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     }
   }
+  ALLOC(eng->d_counters, HWY_CTR_COUNT * sizeof(unsigned long long));
+  if ((e = hipMemsetAsync(eng->d_counters, 0, HWY_CTR_COUNT * sizeof(unsigned long long), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   ALLOC(eng->d_time, E * sizeof(double));
   ALLOC(eng->d_done, E);
   ALLOC(eng->d_episode, E * sizeof(uint32_t));
@@ -359,10 +365,11 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   if (!eng) return HWY_OK;
   (void)hipSetDevice(eng->device);
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
+  if (eng->comm) { hwy::comm_destroy(eng->comm); eng->comm = nullptr; }
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out,
                   eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet,
-                  eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta};
+                  eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta, eng->d_counters};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -695,6 +702,52 @@ extern "C" int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, dou
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   if (e != hipSuccess) return fail(eng, HWY_ERR_HIP, std::string("hwy_debug_math: ") + hipGetErrorString(e));
+  return HWY_OK;
+}
+
+extern "C" int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32_t reset) {
+  if (!eng || !out || n < 0) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  unsigned long long host[HWY_CTR_COUNT];
+  HWY_HIP(eng, hipMemcpyAsync(host, eng->d_counters, sizeof host, hipMemcpyDeviceToHost, eng->stream));
+  if (reset) HWY_HIP(eng, hipMemsetAsync(eng->d_counters, 0, sizeof host, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  for (int k = 0; k < n && k < HWY_CTR_COUNT; ++k) out[k] = host[k];
+  return HWY_OK;
+}
+
+extern "C" int hwy_comm_unique_id(uint8_t *id) {
+  if (!id) return fail(nullptr, HWY_ERR_INVALID_ARG, "id is NULL");
+  std::string err;
+  const int rc = hwy::comm_unique_id(id, err);
+  return rc ? fail(nullptr, rc, err) : HWY_OK;
+}
+extern "C" int hwy_comm_init(hwy_engine *eng, const uint8_t *id, int32_t rank, int32_t world) {
+  if (!eng || !id || world < 1 || rank < 0 || rank >= world) return HWY_ERR_INVALID_ARG;
+  if (eng->comm) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_comm_init: this engine already has a communicator");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  std::string err;
+  const int rc = hwy::comm_init(&eng->comm, id, rank, world, err);
+  return rc ? fail(eng, rc, err) : HWY_OK;
+}
+extern "C" int hwy_gather(hwy_engine *eng, const void *d_send, void *d_recv, size_t bytes, int32_t root) {
+  if (!eng || !d_send) return HWY_ERR_INVALID_ARG;
+  if (!eng->comm) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_gather: call hwy_comm_init first");
+  if (root < 0 || root >= hwy::comm_world(eng->comm)) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_gather: root out of range");
+  if (hwy::comm_rank(eng->comm) == root && !d_recv) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_gather: d_recv is NULL on the root");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  std::string err;
+  const int rc = hwy::comm_gather(eng->comm, d_send, d_recv, bytes, root, eng->stream, err);
+  return rc ? fail(eng, rc, err) : HWY_OK;
+}
+extern "C" int hwy_comm_destroy(hwy_engine *eng) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (eng->comm) {
+    (void)hipSetDevice(eng->device);
+    (void)hipStreamSynchronize(eng->stream);
+    hwy::comm_destroy(eng->comm);
+    eng->comm = nullptr;
+  }
   return HWY_OK;
 }
 

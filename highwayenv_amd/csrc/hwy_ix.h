@@ -43,6 +43,7 @@ struct IxParams {
   DevState shadow;
   int32_t *shadow_route;
   int32_t *shadow_meta;    // [E][4]
+  unsigned long long *counters;  // [HWY_CTR_COUNT] event counters of the engine (hwy_get_counters), nullptr = not counted
 };
 
 // packed per-vehicle word of this scenario: lane[0:4] | target_lane[5:9] | speed_index[10:12] | flags[13:19]
@@ -943,6 +944,9 @@ __device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double lo
   if (__ballot(present && sqrt(dx * dx + dy * dy) < 15) != 0) return;  // too close to somebody
   const u64 pm = __ballot(present);
   const int slot = __popcll(pm);  // the list is compact
+  // every spawn the reference would perform is counted, and so is every one dropped because all max_vehicles slots are
+  // taken (the reference's list is unbounded, intersection_env.py:324-352): hwy_get_counters reports the rate
+  if (ip.counters && i == 0) atomicAdd(&ip.counters[slot >= p.N ? HWY_CTR_IX_SPAWNS_DROPPED : HWY_CTR_IX_SPAWNS], 1ull);
   if (slot >= p.N) return;        // capacity reached: no spawn (documented deviation; size num_vehicles accordingly)
   const int best = ix_closest_lane_uniform(ip, sh, nx, ny, nh);  // lane index: get_closest_lane_index(position, heading)
   if (i == slot) {

@@ -139,6 +139,37 @@ class Engine:
         return out.reshape(np.shape(x))
 
     # -- misc ---------------------------------------------------------------------------------
+    COUNTERS = ("ix_spawns", "ix_spawns_dropped")
+
+    def counters(self, reset: bool = False) -> dict:
+        """Event counters (hwy_get_counters): intersection scenario, device traffic -- spawns performed, and spawns
+        DROPPED because all ``max_vehicles`` slots were taken (the reference's vehicle list is unbounded)."""
+        out = (C.c_uint64 * 8)()
+        self._check(self._lib.hwy_get_counters(self._h, out, 8, int(bool(reset))))
+        return {k: int(out[i]) for i, k in enumerate(self.COUNTERS)}
+
+    # -- multi-GPU: RCCL gather behind the ABI (one process per GPU) -----------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128-byte RCCL id every rank passes to ``comm_init`` (ship it by any means)."""
+        lib = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.hwy_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(f"hwy_comm_unique_id: {lib.hwy_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.hwy_comm_init(self._h, buf, int(rank), int(world)))
+
+    def gather(self, d_send: int, d_recv: int, nbytes: int, root: int = 0):
+        """Enqueue ncclGather of ``nbytes`` bytes per rank (device pointers) on the engine's stream."""
+        self._check(self._lib.hwy_gather(self._h, C.c_void_p(d_send), C.c_void_p(d_recv or None), C.c_size_t(nbytes), int(root)))
+
+    def comm_destroy(self):
+        self._check(self._lib.hwy_comm_destroy(self._h))
+
     def sync(self):
         self._check(self._lib.hwy_sync(self._h))
 

@@ -340,6 +340,17 @@ int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base_seed, doub
 int hwy_sync(hwy_engine *eng); /* hipStreamSynchronize on the engine stream */
 
 /*
+ * Event counters of an engine since creation (or since the last call with reset != 0); synchronises the stream.
+ * HWY_SCENARIO_INTERSECTION, device traffic mode: IntersectionEnv._spawn_vehicle (intersection_env.py:324-352) appends to
+ * an unbounded list; the engine has hwy_config.num_vehicles slots per environment and DROPS a spawn that finds them all
+ * taken.  HWY_CTR_IX_SPAWNS counts the spawns performed, HWY_CTR_IX_SPAWNS_DROPPED the ones dropped (initial traffic,
+ * the per-step spawn and the pre-warmed next episodes alike), so a caller can size max_vehicles until the second is 0.
+ * `out` receives min(n, HWY_CTR_COUNT) values.
+ */
+enum { HWY_CTR_IX_SPAWNS = 0, HWY_CTR_IX_SPAWNS_DROPPED = 1, HWY_CTR_COUNT = 8 };
+int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32_t reset);
+
+/*
  * Self-test hook: evaluate one of the step kernel's own math routines (csrc/hwy_math.h -- bounded-domain
  * log / exp / sincos / asin, Newton-refined v_rcp_f64 / v_rsq_f64, floor-mod angle wrap) on n doubles on
  * the device.  Host pointers.  op: 0 log_pos, 1 exp_bounded, 2 sin, 3 cos, 4 asin_bounded, 5 fast_rcp, 8 atan_fd,
@@ -357,6 +368,24 @@ int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, i
  */
 int hwy_profile_enable(hwy_engine *eng, int32_t enabled);
 int hwy_profile_read(hwy_engine *eng, double *total_ms, int64_t *launches);
+
+/*
+ * Multi-GPU, one process (and one engine) per GPU.  The reference's only vectorisation is gymnasium's process-level
+ * vector env (tests/envs/test_gym.py:158-165); here the environments are block-partitioned over the engines of a node,
+ * nothing is exchanged while stepping, and the per-step (obs | reward | done) blocks of every rank are gathered to a root
+ * rank with ONE RCCL collective over xGMI (ncclGather, rccl.h:745), enqueued on the engine's stream.
+ *   hwy_comm_unique_id  rank 0 only; the caller ships the HWY_COMM_ID_BYTES bytes to every other rank (MPI, a TCP store, ...)
+ *   hwy_comm_init       collective over all `world` ranks; librccl is loaded on first use (HWY_ERR_UNSUPPORTED if absent)
+ *   hwy_gather          `bytes` bytes from device pointer d_send of every rank -> d_recv[rank * bytes ...] on `root`
+ *                       (d_recv is ignored on the other ranks); asynchronous: hwy_sync or stream order makes it visible
+ * A caller that keeps its buffers in a framework (PyTorch) may use that framework's collectives instead
+ * (highwayenv_amd/dist.py does, bench.py --comm abi uses these entry points).
+ */
+#define HWY_COMM_ID_BYTES 128
+int hwy_comm_unique_id(uint8_t *id);
+int hwy_comm_init(hwy_engine *eng, const uint8_t *id, int32_t rank, int32_t world);
+int hwy_gather(hwy_engine *eng, const void *d_send, void *d_recv, size_t bytes, int32_t root);
+int hwy_comm_destroy(hwy_engine *eng);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,7 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt(x))
 #define __builtin_amdgcn_ds_permute(addr, v) emu::ds_permute((addr), (v))
 // agent-scope atomics (fibers run on one OS thread: plain accesses)
+template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = *p; *p = old + (T)v; return old; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_store(ptr, v, order, scope) (*(ptr) = (v))
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))

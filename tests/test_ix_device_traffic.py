@@ -183,3 +183,31 @@ def test_autoreset_next_step_semantics(backend):
         done_prev = term | trunc
     assert n_resets >= E  # duration 4: every env was truncated (or terminated) and re-spawned
     eng.close()
+
+
+@pytest.mark.gpu
+def test_spawn_counters_report_what_the_slot_cap_drops():
+    """The reference's vehicle list is unbounded (intersection_env.py:324-352); the engine has ``max_vehicles`` slots and
+    drops a spawn that finds them all taken.  hwy_get_counters makes that deviation measurable: with 6 slots drops
+    happen, with BASELINE config 4's 30 slots the printed rate is what DESIGN.md quotes; spawns + drops = attempts."""
+    from highwayenv_amd.engine import Engine
+    rates = {}
+    for cap in (6, 30, 48):
+        cfg_d, cfg = _config(512, max_vehicles=cap, observation={"type": "OccupancyGrid"})
+        eng = Engine(cfg)
+        eng.reset(base_seed=3)
+        eng.set_autoreset(True, base_seed=4)
+        c0 = eng.counters(reset=True)
+        assert c0["ix_spawns"] > 0  # the initial traffic of 512 episodes
+        rng = np.random.default_rng(0)
+        present_before = ((eng.get_state()["flags"] & _abi.F_ABSENT) == 0).sum()
+        for t in range(40):
+            eng.step(rng.integers(0, 3, size=(512, 1)))
+        c = eng.counters()
+        assert eng.counters(reset=True) == c and eng.counters() == {"ix_spawns": 0, "ix_spawns_dropped": 0}
+        attempts = c["ix_spawns"] + c["ix_spawns_dropped"]
+        assert attempts > 512  # spawn_probability 0.6 per env-step, minus the ones too close to somebody
+        rates[cap] = c["ix_spawns_dropped"] / attempts
+        eng.close()
+    print(f"\nintersection-v0 spawn drop rate by slot capacity: " + ", ".join(f"{k} slots: {100 * v:.3f} %" for k, v in rates.items()))
+    assert rates[6] > 0.05 and rates[48] == 0.0 and rates[30] <= rates[6]

@@ -21,8 +21,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "highwayenv_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_device.h", "hwy_math.h",
-         "hwy_net.h", "hwy_ix.h")
+FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_comm.hip", "hwy_comm.h", "hwy_launch.h", "hwy_params.h", "hwy_wave.h",
+         "hwy_device.h", "hwy_math.h", "hwy_net.h", "hwy_ix.h")
 W, D, NET, IX = "hwy_wave.h", "hwy_device.h", "hwy_net.h", "hwy_ix.h"
 
 
@@ -231,7 +231,7 @@ def build(name):
     lib = os.path.join(OUT, f"libhwy_engine_{name}.so")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + FLAG_VARIANTS.get(name, [])
     r = subprocess.run(["hipcc", *flags, "-shared", "-o", lib, os.path.join(d, "hwy_kernels.hip"),
-                        os.path.join(d, "hwy_engine.hip")], capture_output=True, text=True)
+                        os.path.join(d, "hwy_engine.hip"), os.path.join(d, "hwy_comm.hip"), "-ldl"], capture_output=True, text=True)
     shutil.rmtree(d)
     return lib if r.returncode == 0 else f"[fail] {name}: {r.stderr[-400:]}"
 
