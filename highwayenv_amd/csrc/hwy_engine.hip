@@ -29,6 +29,7 @@ struct hwy_engine {
   int pitch = 0;
   bool force_block_kernel = false;  // hwy_config.tune_block_kernel: use the generic workgroup kernel even for N <= 64
   int waves_per_eu = 3;  // register-allocation variant of the step kernel (hwy_config.tune_waves_per_eu)
+  int prio_shift = 0;    // issue-priority turns of the one-wavefront kernels (hwy_config.tune_prio_shift; 0 = off)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -180,6 +181,7 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.autoreset = eng->autoreset;
   p.rp = eng->rp;
   p.grid_ws = eng->d_grid_ws;
+  p.prio_shift = eng->prio_shift;
 }
 
 static bool is_ix(const hwy_engine *eng) { return eng->cfg.scenario == HWY_SCENARIO_INTERSECTION; }
@@ -274,6 +276,14 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     eng->waves_per_eu = (cfg->num_envs > 2048 && !helpers) ? 3 : 2;
   }
   else if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
+  else if (!(cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) && cfg->num_vehicles <= 64) {
+    // full-pairwise build of the one-wavefront kernel: 137 VGPRs (3 waves/SIMD, no spills) or 128 with 6 spilled (4 waves/
+    // SIMD).  A batch that fits 3 waves/SIMD runs the spill-free build; beyond that the 4th resident wave wins by far
+    // (highway-v0 x 4096 envs: 188 -> 154 us per step, with the priority turns the all-resident grid allows)
+    hipDeviceProp_t prop;
+    const int simds = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * 4;
+    eng->waves_per_eu = cfg->num_envs > 3 * simds ? 4 : 3;
+  }
   if (cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4) eng->waves_per_eu = cfg->tune_waves_per_eu;
   auto bail = [&](hipError_t e, const char *what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -357,6 +367,16 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->rp.initial_lane_id = -1;
   eng->rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;  // HighwayEnvFast (highway_env.py:177-182)
   eng->rp.base_seed = 0;
+  // issue-priority turns: on by default only where the whole grid of the step kernel is resident at once
+  if (cfg->tune_prio_shift > 0) eng->prio_shift = cfg->tune_prio_shift;
+  else if (cfg->tune_prio_shift == 0) {
+    StepParams probe;
+    hwy::params_from_config(*cfg, eng->pitch, probe);
+    int resident = 0;
+    if (cfg->scenario == HWY_SCENARIO_HIGHWAY) resident = hwy::step_resident_blocks(probe, eng->waves_per_eu, eng->force_block_kernel, cfg->tune_extra_lds);
+    else if (cfg->scenario != HWY_SCENARIO_INTERSECTION) resident = hwy::net_step_resident_blocks(eng->waves_per_eu);
+    eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? HWY_DEFAULT_PRIO_SHIFT : 0;
+  }
   *out = eng;
   return HWY_OK;
 }

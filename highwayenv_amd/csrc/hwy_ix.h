@@ -190,13 +190,13 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double 
     const int t = threadIdx.x, o = t ^ SH::kCap;
     sh.xd[t] = bd; sh.xi[t] = best; sh.xb[t] = bits | (has_lat ? (1 << 30) : 0);
     if (lat_t) sh.xl[t] = *lat_t;
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     const double obd = sh.xd[o];
     const int ob = sh.xi[o], obits = sh.xb[o];
     bits |= obits & ~(1 << 30);
     if (obd < bd || (obd == bd && ob < best)) { bd = obd; best = ob; }
     if (lat_t && !has_lat && (obits & (1 << 30))) *lat_t = sh.xl[o];  // the other half walked my target lane
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
   }
 }
 
@@ -213,9 +213,9 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
   constexpr int NH = SH::kNH;
   const int t = threadIdx.x, vi = t & (SH::kCap - 1), half = NH > 1 ? t / SH::kCap : 0;
   if constexpr (NH > 1) {  // a helper works on the body of vehicle t & 31
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     if (half == 0) { sh.x[vi] = x; sh.y[vi] = y; sh.hd[vi] = h; sh.vw[vi] = tgt | (present ? 256 : 0); }
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     x = sh.x[vi]; y = sh.y[vi]; h = sh.hd[vi];
     const int w = sh.vw[vi];
     tgt = w & 255; present = (w & 256) != 0;
@@ -425,7 +425,10 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const int every = (int)(1 / p.dt / 2);  // int(1 / dt / REGULATION_FREQUENCY) (regulation.py:38)
+  WaveTurn turn;  // the wavefronts sharing a SIMD take turns at the top issue priority (hwy_wave.h)
+  wave_turn_init(turn, p.prio_shift);
   for (int fr = 0; fr < n_frames; ++fr) {
+    wave_turn(turn);
     const bool present = !(me.flags & HWY_F_ABSENT);
     const bool controlled = present && (me.flags & HWY_F_CONTROLLED);
     const u64 pm = __ballot(present);
@@ -441,7 +444,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       }
     }
     // ---- B. membership masks + snapshot ---------------------------------------------------------------------------
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     if constexpr (SH::kNH > 1) {  // helper lanes carry their vehicle's bits: one ballot yields the masks of two lanes
       const int HL = (ip.n_lanes + 1) >> 1, half = i / SH::kCap;
       for (int L = 0; L < HL; ++L) {
@@ -459,8 +462,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     }
     const double ch = me.ch, shh = me.sh;
     sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = ch; sh.s[i] = shh;
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
 
+    wave_turn(turn);
     // ---- C. Road.act (road.py:464-467) ---------------------------------------------------------------------------
     // steering -> slip angle -> bicycle model are folded like in hwy_net.h: tb = tan(beta) with beta = atan(tan(delta) / 2)
     // (controller.py:145-187 + kinematics.py:141-152; exact trigonometric identities, <= 2 ulp from the literal chain)
@@ -532,7 +536,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       if constexpr (NH > 1) {
         if (half == 0) { sh.xd[i] = s_me; sh.xi[i] = me.route; sh.xb[i] = me.lane | (veh ? 256 : 0); }
       }
-      __syncthreads();  // sl[][] is dead from here on: the trajectories share its storage
+      HWY_WAVE_LDS_FENCE();  // sl[][] is dead from here on: the trajectories share its storage
       if constexpr (NH > 1) {
         s_me = sh.xd[vi]; route_me = sh.xi[vi];
         lane_me = sh.xb[vi] & 255; veh_v = (sh.xb[vi] & 256) != 0;
@@ -547,7 +551,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
           sh.traj[k][0][vi] = px; sh.traj[k][1][vi] = py; sh.traj[k][2][vi] = hd;
         }
       }
-      if constexpr (NH > 1) __syncthreads();
+      if constexpr (NH > 1) HWY_WAVE_LDS_FENCE();
       // Two vehicles can only conflict if at some sample their predicted positions are within LENGTH of each other
       // (regulation.py:103): bound every vehicle's 11 positions by a circle (centre = the middle sample) and skip a
       // partner for the whole wave when no pair of circles comes within LENGTH (triangle inequality, 1e-6 of slack)
@@ -562,7 +566,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         my_rho = sqrt(my_rho);  // == the maximum of the 11 distances (sqrt is monotone)
       }
       if (half == 0) { sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho; }
-      __syncthreads();
+      HWY_WAVE_LDS_FENCE();
       bool yield = false;
       // partner trips: one slot per half (NH == 2: slots j0 and j0 + 1), skipped when nobody is there
       for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform
@@ -604,9 +608,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         }
       }
       if constexpr (NH > 1) {  // a vehicle yields iff one of its halves found a pair that names it
-        __syncthreads();
+        HWY_WAVE_LDS_FENCE();
         sh.xi[i] = yield ? 1 : 0;
-        __syncthreads();
+        HWY_WAVE_LDS_FENCE();
         yield = yield || sh.xi[i ^ SH::kCap] != 0;
       }
       if (present && yield && !controlled) {  // only a ControlledVehicle that is not the MDPVehicle is stopped
@@ -615,6 +619,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       }
     }
 
+    wave_turn(turn);
     // ---- E. Vehicle.step (kinematics.py:130-177, behavior.py:139-148) -------------------------------------------------
     if (present) {
       if (!controlled) me.timer += p.dt;
@@ -639,7 +644,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       me.v += accel * p.dt;
       sincos_bounded(me.h, &me.sh, &me.ch);
     }
-    __syncthreads();  // the trajectories (if any) are dead: sl[][] is written again
+    HWY_WAVE_LDS_FENCE();  // the trajectories (if any) are dead: sl[][] is written again
     {
       int cl_new, bits_new;  // on_state_update + the next frame's membership bits and s table
       ix_lane_pass(ip, sh, present, me.x, me.y, me.h, me.tgt, &bits_new, &cl_new, &lat_tgt);
@@ -652,9 +657,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       constexpr int NH = SH::kNH;
       const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
       const double c2 = me.ch, s2 = me.sh;
-      __syncthreads();
+      HWY_WAVE_LDS_FENCE();
       sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
-      __syncthreads();
+      HWY_WAVE_LDS_FENCE();
       // (helper lanes: thread t checks vehicle t & 31 against the partners of parity t >> 5)
       const Body mine = NH > 1 ? Body{sh.x[vi], sh.y[vi], sh.v[vi], sh.c[vi], sh.s[vi]} : Body{me.x, me.y, me.v, c2, s2};
       const bool present_v = NH > 1 ? ((pm >> vi) & 1) != 0 : present;
@@ -684,9 +689,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         }
       }
       if constexpr (NH > 1) {  // the other half's verdict: the impact of the higher partner slot stays
-        __syncthreads();
+        HWY_WAVE_LDS_FENCE();
         sh.xd[i] = imp_x; sh.bcx[i] = imp_y; sh.xi[i] = j_imp; sh.xb[i] = crash ? 1 : 0;
-        __syncthreads();
+        HWY_WAVE_LDS_FENCE();
         const int o = i ^ SH::kCap;
         if (sh.xi[o] > j_imp) { imp_x = sh.xd[o]; imp_y = sh.bcx[o]; j_imp = sh.xi[o]; }
         crash = crash || sh.xb[o] != 0;

@@ -63,6 +63,34 @@ hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, in
     default: return launch_step_wpe<4>(p, num_envs, stream);
   }
 }
+// How many workgroups of the step kernel a launch of this engine can hold at once (occupancy x compute units): the
+// issue-priority turns (hwy_wave.h: WaveTurn) only pay when the whole grid is resident.
+template <typename K>
+static int resident_blocks(K kernel, int block, int dyn_lds) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds) != hipSuccess) return 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return per_cu * prop.multiProcessorCount;
+}
+int step_resident_blocks(const StepParams &p, int waves_per_eu, bool force_block_kernel, int extra_lds) {
+  if (p.N > 64 || force_block_kernel) return 0;  // (the workgroup kernels keep the hardware order)
+  const bool fast = (p.flags & HWY_C_EGO_ONLY_COLLISIONS) != 0;
+  switch (waves_per_eu) {
+    case 1: return fast ? resident_blocks(hwy_step_wave_kernel<1, false>, 64, extra_lds) : resident_blocks(hwy_step_wave_kernel<1, true>, 64, extra_lds);
+    case 2: return fast ? resident_blocks(hwy_step_wave_kernel<2, false>, 64, extra_lds) : resident_blocks(hwy_step_wave_kernel<2, true>, 64, extra_lds);
+    case 3: return fast ? resident_blocks(hwy_step_wave_kernel<3, false>, 64, extra_lds) : resident_blocks(hwy_step_wave_kernel<3, true>, 64, extra_lds);
+    default: return fast ? resident_blocks(hwy_step_wave_kernel<4, false>, 64, extra_lds) : resident_blocks(hwy_step_wave_kernel<4, true>, 64, extra_lds);
+  }
+}
+int net_step_resident_blocks(int waves_per_eu) {
+  switch (waves_per_eu) {
+    case 1: return resident_blocks(hwy_net_step_kernel<1>, 64, 0);
+    case 2: return resident_blocks(hwy_net_step_kernel<2>, 64, 0);
+    case 3: return resident_blocks(hwy_net_step_kernel<3>, 64, 0);
+    default: return resident_blocks(hwy_net_step_kernel<4>, 64, 0);
+  }
+}
 hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
   switch (waves_per_eu) {
     case 1: hipLaunchKernelGGL((hwy_net_step_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;

@@ -9,6 +9,9 @@
 namespace hwy {
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds);
+// workgroups of the step kernel the device holds at once (0 = unknown / not applicable)
+int step_resident_blocks(const StepParams &p, int waves_per_eu, bool force_block_kernel, int extra_lds);
+int net_step_resident_blocks(int waves_per_eu);
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *in, double *out, long long n, hipStream_t stream);
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream);

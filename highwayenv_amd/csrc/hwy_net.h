@@ -546,6 +546,8 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     return;
   }
 
+  WaveTurn turn;  // the wavefronts sharing a SIMD take turns at the top issue priority (hwy_wave.h)
+  wave_turn_init(turn, p.prio_shift);
   Veh me;
   load_vehicle<1>(p, e, me);
   const bool present = i < N && !(me.flags & HWY_F_ABSENT);
@@ -561,7 +563,6 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       if (p.agent_index[a] == i) agent = a;
   const bool i_check = present && (me.flags & HWY_F_CHECK_COLLISIONS);
   const u64 chk = __ballot(i_check);
-  const double my_hl = obstacle ? 1.0 : HWY_VEH_LENGTH / 2, my_hw = obstacle ? 1.0 : HWY_VEH_WIDTH / 2;
   // lane membership bits of the current position: from the loaded state for the first frame, afterwards from the
   // same table pass that re-indexes the lane after the integration (on_state_update) -- the position does not
   // change between the end of a frame and the start of the next one
@@ -576,6 +577,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
   bool has_tie = false;
 
   for (int fr = 0; fr < p.n_frames; ++fr) {
+    wave_turn(turn);
     // ---- A. meta-actions of all agents (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315;
     //         ControlledVehicle.act starts with follow_road, :98) ---------------------------------------------
     if (fr == 0 && p.actions && controlled) {
@@ -610,7 +612,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       m_pub |= ((my_conn >> L) & 1) ? b : 0;
     }
     const double log_ratio = veh ? net_log_ratio(me.v, me.ts, sh.llimit[me.lane]) : 0.0;
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     if (present) {
       sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
       sh.ox[rank] = sh.lx0[me.lane];
@@ -618,8 +620,9 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       sh.kind[rank] = veh ? 1 : 0;
     }
     if (i < np.n_lanes) sh.lane_mask[i] = m_pub;
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
 
+    wave_turn(turn);
     // ---- C. Road.act -------------------------------------------------------------------------------------------
     const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
     const bool drives = idm && !crashed0;  // IDMVehicle.act returns early when crashed (behavior.py:102-103)
@@ -713,6 +716,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       }
     }
 
+    wave_turn(turn);
     // ---- D. low-level control: steering towards the target lane, IDM / speed control --------------------------
     const double inv_v = fast_rcp(not_zero(me.v));
     double tb;
@@ -734,8 +738,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     accel = controlled ? HWY_KP_A * (me.ts - me.v) : accel;
 
     // ---- E. Road.step: integrate (kinematics.py:130-177) ------------------------------------------------------
-    const double x_old = me.x, v_old = me.v;
-    const int flags_old = me.flags;
+    const double x_old = me.x;
     if (veh) {
       if (!(drives || controlled)) {  // a crashed IDM vehicle keeps its previous action, then clip_actions overrides it
         tb = 0.0;
@@ -765,12 +768,13 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       bits = present ? bits_new : 0;
     }
 
+    wave_turn(turn);
     // ---- F. Road.step: collisions (road.py:477-481, objects.py:92-138) ----------------------------------------
     // Outward scan in rank order bounded by the frame-start distance, like hwy_wave.h; "last pair in loop
     // order wins" == the partner with the highest slot (the obstacle, being last, beats every vehicle).
     // bodies after the integration, in the frame-start RANK order (same permutation as the snapshot above)
     if (present) { sh.nx[rank] = me.x; sh.ny[rank] = me.y; sh.nv[rank] = me.v; sh.nc[rank] = me.ch; sh.ns[rank] = me.sh; }
-    __syncthreads();
+    HWY_WAVE_LDS_FENCE();
     {
       // Phase 1, wave-uniform walk outwards in rank order (partners at rank - k and rank + k), bounded by the
       // frame-start distance: lim of the sphere pre-check below + what two bodies can move towards each other in
@@ -806,7 +810,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
         }
       }
       // Phase 2: every thread's collected partners, one per trip (a handful of trips for the whole wave)
-      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, my_hl, my_hw};
+      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, obstacle ? 1.0 : HWY_VEH_LENGTH / 2, obstacle ? 1.0 : HWY_VEH_WIDTH / 2};
       int best = -1;
       while (__ballot(cand != 0) != 0) {  // wave-uniform
         if (cand == 0) continue;

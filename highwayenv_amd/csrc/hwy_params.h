@@ -7,7 +7,9 @@
 #include "hwy_device.h"
 
 #ifndef HWY_DEFAULT_PRIO_SHIFT
-#define HWY_DEFAULT_PRIO_SHIFT 14  // 16 k clock ticks (~7 us) per turn: measured best at 4096 envs (profiles/r02_history.md)
+#define HWY_DEFAULT_PRIO_SHIFT 14  // 16 k clock ticks (~7 us) per turn: measured best (profiles/r02_history.md); used only when the
+                                   // whole grid is resident at once -- otherwise the hardware's oldest-first order lets queued
+                                   // workgroups start sooner (measured: highway-v0 at 3 waves/SIMD loses 10 % with turns)
 #endif
 
 namespace hwy {
@@ -32,7 +34,7 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.inv_rs = 1.0 / (p.rs1 - p.rs0);
   p.inv_reward_span = 1.0 / ((p.high_speed_reward + p.right_lane_reward) - p.collision_reward);
   p.inv_lanes = 1.0 / (double)(p.L - 1 > 1 ? p.L - 1 : 1);
-  p.prio_shift = c.tune_prio_shift < 0 ? 0 : (c.tune_prio_shift > 0 ? c.tune_prio_shift : HWY_DEFAULT_PRIO_SHIFT);
+  p.prio_shift = c.tune_prio_shift > 0 ? c.tune_prio_shift : 0;  // the engine turns the default on where it pays (hwy_create)
   p.obs_type = c.obs_type;
   if (c.obs_type == HWY_OBS_OCCUPANCY_GRID) {
     p.gW = c.grid_shape[0]; p.gH = c.grid_shape[1];

@@ -228,9 +228,11 @@ typedef struct hwy_config {
   int32_t tune_ix_no_prewarm;          /* 1: HWY_SCENARIO_INTERSECTION auto-resets run their warm-up frames inline */
   int32_t tune_extra_lds;              /* bytes of dynamic LDS per workgroup of the one-wavefront step kernel (<= 65536):
                                           fewer resident wavefronts per SIMD, the rest dispatched as wavefronts retire */
-  int32_t tune_prio_shift;             /* one-wavefront step kernel: wavefronts sharing a SIMD take turns at the top issue
-                                          priority (s_setprio), the turn lasting 2^shift clock ticks of s_memtime;
-                                          0 = the engine's default, -1 = off (hardware order: oldest wavefront first) */
+  int32_t tune_prio_shift;             /* one-wavefront step kernels: wavefronts sharing a SIMD take turns at the top issue
+                                          priority (s_setprio), a turn lasting 2^shift clock ticks of s_memtime;
+                                          -1 = off (hardware order: oldest wavefront first), 0 = the engine's default: 14
+                                          (~7 us) when the whole grid of the step kernel is resident at once (occupancy x
+                                          compute units >= num_envs), else off */
   int32_t tune_reserved[2];
 } hwy_config;
 
