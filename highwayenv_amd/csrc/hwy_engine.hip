@@ -488,6 +488,23 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
     if (h->road_steps) std::memcpy(h->road_steps, rs, sizeof(int32_t) * E);
     double *flds[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};
     for (int f = 0; f < 9; ++f) if (flds[f]) unpack_rows(eng, stage + f * plane, flds[f]);
+    // the step kernel maintains the impact pair only while its flag is set, and nothing but the flag word of an empty slot
+    for (int e = 0; e < E; ++e)
+      for (int i = 0; i < N; ++i) {
+        const int fl = hwy::ix_word_flags(pk[(size_t)e * P + i]);
+        const size_t k = (size_t)e * N + i;
+        if (fl & HWY_F_ABSENT) {
+          for (int f = 0; f < 9; ++f) if (flds[f]) flds[f][k] = 0.0;
+          if (h->lane) h->lane[k] = 0;
+          if (h->target_lane) h->target_lane[k] = 0;
+          if (h->speed_index) h->speed_index[k] = 0;
+          if (h->flags) h->flags[k] = HWY_F_ABSENT;
+          if (h->route) h->route[k] = 0;
+        } else if (!(fl & HWY_F_HAS_IMPACT)) {
+          if (h->impact_x) h->impact_x[k] = 0.0;
+          if (h->impact_y) h->impact_y[k] = 0.0;
+        }
+      }
     if (h->time) std::memcpy(h->time, tm, sizeof(double) * E);
     return HWY_OK;
   }

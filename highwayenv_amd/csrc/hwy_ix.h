@@ -66,6 +66,9 @@ struct IxVeh {
   double x, y, h, v, timer, ts, delta, impx, impy;
   double ch, sh;  // cos / sin of the heading, refreshed whenever the heading changes
   int lane, tgt, sidx, flags, route;
+  // HBM write-back bookkeeping (ix_store_vehicle): the route word as loaded, and whether this SLOT now holds another
+  // vehicle than the one it was loaded with (compaction, spawn, a state taken from the other set of planes)
+  int route0, dirty;
 };
 
 #define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
@@ -390,31 +393,47 @@ __device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o, bool
   o.flags = HWY_F_ABSENT;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
-    o.x = st.x[k]; o.y = st.y[k]; o.h = st.heading[k]; o.v = st.speed[k];
-    o.timer = st.timer[k]; o.ts = st.target_speed[k]; o.delta = st.delta[k];
     const int w = st.packed[k];
-    o.lane = ix_word_lane(w); o.tgt = ix_word_target(w); o.sidx = ix_word_speed_index(w); o.flags = ix_word_flags(w);
-    o.route = route[k];
-    if (o.flags & HWY_F_HAS_IMPACT) {
-      o.impx = st.impact_x[k];
-      o.impy = st.impact_y[k];
+    o.flags = ix_word_flags(w);
+    // an empty slot has nothing but its flag word: its other planes are neither read nor (ix_store_vehicle) written
+    if (!(o.flags & HWY_F_ABSENT)) {
+      o.x = st.x[k]; o.y = st.y[k]; o.h = st.heading[k]; o.v = st.speed[k];
+      o.timer = st.timer[k]; o.ts = st.target_speed[k]; o.delta = st.delta[k];
+      o.lane = ix_word_lane(w); o.tgt = ix_word_target(w); o.sidx = ix_word_speed_index(w);
+      o.route = o.route0 = route[k];
+      if (o.flags & HWY_F_HAS_IMPACT) {
+        o.impx = st.impact_x[k];
+        o.impy = st.impact_y[k];
+      }
     }
   }
   sincos_bounded(o.h, &o.sh, &o.ch);
 }
-__device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o, bool to_shadow = false) {
+// Write-back of what CHANGED.  Positions, speed, heading, timer, target speed and the packed word of a present slot always
+// do; the constant of a vehicle (DELTA) and its route word only when the slot holds another
+// vehicle than at load time (`dirty`) or the value moved; the impact pair only where the flag says it is valid; an empty
+// slot only its flag word.  `all` (a state loaded from the OTHER set of planes: the re-spawn of a pre-warmed episode)
+// writes every plane of every present slot.  The fields of an empty slot are unspecified (hwy_get_state).
+__device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o, bool to_shadow = false, bool all = false) {
   const StepParams &p = ip.s;
   const DevState &st = to_shadow ? ip.shadow : ip.s.st;
   int32_t *route = to_shadow ? ip.shadow_route : ip.route;
   const int i = threadIdx.x;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
-    st.x[k] = o.x; st.y[k] = o.y; st.heading[k] = o.h; st.speed[k] = o.v;
-    st.timer[k] = o.timer; st.target_speed[k] = o.ts; st.delta[k] = o.delta;
     st.packed[k] = ix_pack_word(o.lane, o.tgt, o.sidx, o.flags);
-    route[k] = o.route;
-    st.impact_x[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impx : 0.0;
-    st.impact_y[k] = (o.flags & HWY_F_HAS_IMPACT) ? o.impy : 0.0;
+    if (!(o.flags & HWY_F_ABSENT)) {
+      const bool fresh = all || o.dirty != 0;
+      st.x[k] = o.x; st.y[k] = o.y; st.heading[k] = o.h; st.speed[k] = o.v;
+      st.timer[k] = o.timer;
+      st.target_speed[k] = o.ts;  // (RegulatedRoad moves the target speed of yielding traffic too, regulation.py:60-68)
+      if (fresh) st.delta[k] = o.delta;
+      if (fresh || o.route != o.route0) route[k] = o.route;
+      if (o.flags & HWY_F_HAS_IMPACT) {
+        st.impact_x[k] = o.impx;
+        st.impact_y[k] = o.impy;
+      }
+    }
   }
 }
 
@@ -896,6 +915,7 @@ __device__ inline void ix_compact(IxVeh &me, bool keep) {
   MOVE_D(me.impx); MOVE_D(me.impy); MOVE_D(me.ch); MOVE_D(me.sh);
   MOVE_I(me.lane); MOVE_I(me.tgt); MOVE_I(me.sidx); MOVE_I(flags); MOVE_I(me.route);
   me.flags = flags;
+  me.dirty = 1;  // the list moved up: this slot may hold another vehicle now (write its constants back)
 #undef MOVE_I
 #undef MOVE_D
 }
@@ -956,6 +976,7 @@ __device__ inline void ix_spawn(const IxParams &ip, SH &sh, IxVeh &me, double lo
   const int best = ix_closest_lane_uniform(ip, sh, nx, ny, nh);  // lane index: get_closest_lane_index(position, heading)
   if (i == slot) {
     me = IxVeh{};
+    me.dirty = 1;
     me.x = nx; me.y = ny; me.h = nh; me.v = speed; me.ts = speed;
     me.lane = me.tgt = best;
     me.timer = py_mod_pos((nx + ny) * HWY_PI, HWY_LC_DELAY);
@@ -1037,6 +1058,7 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
   const int best = ix_closest_lane_uniform(ip, sh, ex, ey, eh);
   if (i == slot && slot < p.N) {
     me = IxVeh{};
+    me.dirty = 1;
     me.x = ex; me.y = ey; me.h = eh; me.v = sh.lim[access];
     me.lane = me.tgt = best;
     me.route = ix_plan_route(ip, sh, best, ip.destination);
@@ -1136,7 +1158,7 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
     ix_observe(ip, sh, e, me, role == STEP);
   }
   if (role == STEP && p.full_step && !ip.host_spawn) ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);
-  ix_store_vehicle(ip, e, me);
+  ix_store_vehicle(ip, e, me, false, role == RESPAWN);  // (a re-spawn moves the episode from the shadow planes to these)
   if (role == RESPAWN) {  // the step after terminated | truncated re-spawned the environment
     __threadfence();  // the shadow has been read before `done` is cleared (the pre-warming block starts over once it sees that)
     if (i == 0) {
@@ -1166,7 +1188,7 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_reset_kernel(const IxParams ip
   const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
   ix_spawn_env(ip, sh, e, seed, 0u, me, road_steps);
   ix_observe(ip, sh, e, me, false);
-  ix_store_vehicle(ip, e, me);
+  ix_store_vehicle(ip, e, me, false, true);
   if (i == 0) {
     p.st.time[e] = 0.0;
     p.st.done[e] = 0;

@@ -243,6 +243,8 @@ typedef struct hwy_config {
  * env.road.vehicles[i].{position,heading,speed,lane_index,target_lane_index,
  * crashed,impact,timer,DELTA,target_speed,speed_index}).  Any pointer may be
  * NULL in hwy_get_state (field skipped); all must be non-NULL in hwy_set_state.
+ * HWY_SCENARIO_INTERSECTION: for a slot whose flags hold HWY_F_ABSENT only `flags` is meaningful -- the step kernel
+ * neither reads nor writes the other planes of an empty slot.
  */
 typedef struct hwy_state {
   double *x, *y, *heading, *speed;      /* RoadObject.position/heading/speed     objects.py:42-45 */

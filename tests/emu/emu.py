@@ -79,7 +79,16 @@ class EmuEngine:
         self.done[:] = 0
 
     def get_state(self):
-        return _abi.copy_state(self.st)
+        st = _abi.copy_state(self.st)
+        if self.ix:  # like hwy_get_state: the planes of an empty slot (and an impact without its flag) are unspecified: zeros
+            absent = (st["flags"] & _abi.F_ABSENT) != 0
+            for k in _abi.STATE_F64 + ["lane", "target_lane", "speed_index", "route"]:
+                st[k][absent] = 0
+            st["flags"][absent] = _abi.F_ABSENT
+            no_impact = (st["flags"] & _abi.F_HAS_IMPACT) == 0
+            st["impact_x"][no_impact] = 0
+            st["impact_y"][no_impact] = 0
+        return st
 
     def set_autoreset(self, enabled, base_seed=0, ego_spacing=2.0, vehicles_density=1.0, initial_lane_id=-1):
         if self.ix and int(base_seed) != self.autoreset[1]:
