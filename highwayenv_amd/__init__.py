@@ -8,4 +8,24 @@ from ._abi import (highway_default_config, highway_fast_default_config, make_con
 
 __version__ = "0.1.0"
 
-__all__ = ["highway_default_config", "highway_fast_default_config", "make_config", "__version__"]
+__all__ = ["highway_default_config", "highway_fast_default_config", "make_config", "register_envs", "__version__"]
+
+
+def register_envs(namespace="highwayenv_amd"):
+    """gymnasium registration of the drop-in environments (highwayenv_amd.envs.register_envs); a no-op without gymnasium."""
+    from .envs import register_envs as _register
+    return _register(namespace)
+
+
+def _register_if_gymnasium_is_installed() -> None:
+    # the reference registers its ids on `import highway_env` (highway_env/__init__.py:190); same here, but only when
+    # gymnasium exists -- the package never needs it otherwise, and importing it must not load the native library
+    import importlib.util
+    try:
+        if importlib.util.find_spec("gymnasium") is not None:
+            register_envs()
+    except Exception:  # a broken / partial gymnasium must not make the engine unusable
+        pass
+
+
+_register_if_gymnasium_is_installed()

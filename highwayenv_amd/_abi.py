@@ -43,8 +43,15 @@ FEATURE_IDS = {name: i for i, name in enumerate(
     ["presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h", "cos_d", "sin_d",
      "long_off", "lat_off", "ang_off", "on_road"])}
 
-# DiscreteMetaAction.ACTIONS_ALL (envs/common/action.py:204)
+# DiscreteMetaAction.ACTIONS_ALL / ACTIONS_LONGI / ACTIONS_LAT (envs/common/action.py:204-210)
 ACTIONS_ALL = {0: "LANE_LEFT", 1: "IDLE", 2: "LANE_RIGHT", 3: "FASTER", 4: "SLOWER"}
+ACTIONS_LONGI = {0: "SLOWER", 1: "IDLE", 2: "FASTER"}
+ACTIONS_LAT = {0: "LANE_LEFT", 1: "IDLE", 2: "LANE_RIGHT"}
+ACTIONS_SET_ALL, ACTIONS_SET_LONGI, ACTIONS_SET_LAT = 0, 1, 2
+
+
+def num_actions(cfg: "HwyConfig") -> int:
+    return 5 if cfg.action_set == ACTIONS_SET_ALL else 3
 
 
 class HwyLane(C.Structure):
@@ -87,7 +94,7 @@ class HwyConfig(C.Structure):
         ("obs_features", C.c_int32),
         ("obs_feature_ids", C.c_int32 * HWY_MAX_FEATURES),
         ("num_target_speeds", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("action_set", C.c_int32),
         ("target_speeds", C.c_double * HWY_MAX_TARGET_SPEEDS),
         ("dt", C.c_double),
         ("policy_dt", C.c_double),
@@ -299,11 +306,12 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     if act["type"] != "DiscreteMetaAction":
         raise NotImplementedError(f"action type {act['type']} is outside the MI355X hot-path scope")
     ix = scenario == "intersection"
-    if ix:
-        if not act.get("longitudinal", True) or act.get("lateral", True):
-            raise NotImplementedError("the intersection scenario takes longitudinal-only meta-actions")
-    elif not (act.get("longitudinal", True) and act.get("lateral", True)):
-        raise NotImplementedError("DiscreteMetaAction with longitudinal/lateral disabled is out of scope")
+    longi, lat = bool(act.get("longitudinal", True)), bool(act.get("lateral", True))
+    if not (longi or lat):
+        raise ValueError("At least longitudinal or lateral actions must be included")  # action.py:246-249
+    if ix and (not longi or lat):
+        raise NotImplementedError("the intersection scenario takes longitudinal-only meta-actions")
+    action_set = ACTIONS_SET_ALL if (longi and lat) else (ACTIONS_SET_LONGI if longi else ACTIONS_SET_LAT)
     obs = cfg["observation"]
     if obs["type"] == "MultiAgentObservation":
         obs = obs["observation_config"]
@@ -367,6 +375,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     ts = np.linspace(20, 30, 3) if ts is None else np.asarray(ts, np.float64)  # controller.py:259
     if not (2 <= ts.size <= HWY_MAX_TARGET_SPEEDS):
         raise ValueError("target_speeds must hold 2..8 values")
+    c.action_set = action_set
     c.num_target_speeds = int(ts.size)
     for k, v in enumerate(ts):
         c.target_speeds[k] = float(v)

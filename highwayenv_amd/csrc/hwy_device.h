@@ -109,6 +109,7 @@ struct ResetParams {
 struct StepParams {
   // compact config (hwy_config subset)
   int32_t N, A, L, T, flags, V, F, n_ts, pitch;
+  int32_t action_set;  // hwy_config.action_set: the table the action ids index (HWY_ACTION_TO_ALL)
   int32_t agent_index[HWY_MAX_AGENTS];
   int32_t feat[HWY_MAX_FEATURES];
   double target_speeds[HWY_MAX_TARGET_SPEEDS];
@@ -873,7 +874,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     // ---- A. action_type.act (abstract.py:294-304) -> MDPVehicle.act(label) (controller.py:295-315):
     //         target updates only; the controllers run below with Road.act (same state => same command)
     if (fr == 0 && p.actions && controlled) {
-      const int act = p.actions[(size_t)e * p.A + agent];
+      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)e * p.A + agent]);
       if (act == HWY_FASTER || act == HWY_SLOWER) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
         int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);

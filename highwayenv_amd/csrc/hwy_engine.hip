@@ -101,7 +101,7 @@ extern "C" const char *hwy_status_string(int status) {
     case HWY_ERR_HIP: return "HIP runtime error";
     case HWY_ERR_UNSUPPORTED: return "unsupported configuration";
     case HWY_ERR_NO_DEVICE: return "no MI355X / HIP device available (there is no CPU fallback)";
-    case HWY_ERR_ACTION: return "meta-action outside [0,5)";
+    case HWY_ERR_ACTION: return "meta-action outside the configured action table";
     default: return "unknown status";
   }
 }
@@ -121,6 +121,7 @@ static int validate(const hwy_config *c, std::string &why) {
     if (c->agent_index[a] < 0 || c->agent_index[a] >= c->num_vehicles) BAD("agent_index[%d] out of range", a);
   if (c->lanes_count < 1 || c->lanes_count > HWY_MAX_LANES) BAD("lanes_count must be in [1,%d]", HWY_MAX_LANES);
   if (c->frames_per_step < 0) BAD("frames_per_step must be >= 0");
+  if (c->action_set < HWY_ACTIONS_ALL || c->action_set > HWY_ACTIONS_LAT) BAD("action_set must be HWY_ACTIONS_ALL / _LONGI / _LAT");
   if (c->tune_extra_lds < 0 || c->tune_extra_lds > 65536) BAD("tune_extra_lds must be in [0,65536]");
   if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
@@ -603,9 +604,9 @@ extern "C" int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, dou
   io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
   const size_t E = eng->cfg.num_envs;
   // the reference raises KeyError for an unknown meta-action before touching the simulation (action.py:260)
-  const int max_action = is_ix(eng) ? 2 : 4;  // IntersectionEnv.ACTIONS has 3 entries (intersection_env.py:14)
+  const int max_action = is_ix(eng) ? 2 : HWY_NUM_ACTIONS(eng->cfg.action_set) - 1;  // IntersectionEnv.ACTIONS has 3 entries (intersection_env.py:14)
   for (size_t k = 0; k < n_act; ++k)
-    if (actions[k] < 0 || actions[k] > max_action) return fail(eng, HWY_ERR_ACTION, is_ix(eng) ? "meta-action outside [0,3)" : "meta-action outside [0,5)");
+    if (actions[k] < 0 || actions[k] > max_action) return fail(eng, HWY_ERR_ACTION, max_action == 2 ? "meta-action outside [0,3)" : "meta-action outside [0,5)");
   HWY_HIP(eng, hipSetDevice(eng->device));
   // pinned layout: [mirror of the device output block][actions]
   char *h_out = (char *)eng->h_pinned;
@@ -638,7 +639,7 @@ extern "C" int hwy_step_frames(hwy_engine *eng, const int32_t *actions, int32_t 
   p.autoreset = 0;
   if (actions) {
     for (size_t k = 0; k < n_act; ++k)
-      if (actions[k] < 0 || actions[k] > (is_ix(eng) ? 2 : 4)) return fail(eng, HWY_ERR_ACTION, "meta-action out of range");
+      if (actions[k] < 0 || actions[k] > (is_ix(eng) ? 2 : HWY_NUM_ACTIONS(eng->cfg.action_set) - 1)) return fail(eng, HWY_ERR_ACTION, "meta-action out of range");
     std::memcpy(eng->h_pinned, actions, n_act * 4);
     HWY_HIP(eng, hipMemcpyAsync(eng->d_actions, eng->h_pinned, n_act * 4, hipMemcpyHostToDevice, eng->stream));
     p.actions = eng->d_actions;

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     // ---- A. meta-actions of all agents (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315;
     //         ControlledVehicle.act starts with follow_road, :98) ---------------------------------------------
     if (fr == 0 && p.actions && controlled) {
-      const int act = p.actions[(size_t)e * p.A + agent];
+      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)e * p.A + agent]);
       me.tgt = net_follow_road(sh, me.tgt, me.x, me.y);
       if (act == HWY_FASTER || act == HWY_SLOWER) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);

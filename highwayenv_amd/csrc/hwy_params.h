@@ -19,6 +19,7 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.N = c.num_vehicles; p.A = c.num_agents; p.L = c.lanes_count; p.T = c.frames_per_step;
   p.flags = c.flags; p.V = c.obs_vehicles; p.F = c.obs_features; p.n_ts = c.num_target_speeds;
   p.pitch = pitch;
+  p.action_set = c.action_set;
   for (int a = 0; a < HWY_MAX_AGENTS; ++a) p.agent_index[a] = a < c.num_agents ? c.agent_index[a] : -1;
   for (int f = 0; f < HWY_MAX_FEATURES; ++f) p.feat[f] = c.obs_feature_ids[f];
   for (int k = 0; k < HWY_MAX_TARGET_SPEEDS; ++k) p.target_speeds[k] = c.target_speeds[k];

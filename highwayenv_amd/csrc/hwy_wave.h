@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   int agent = 0, act0 = HWY_IDLE;
   for (int a = 0; a < p.A; ++a) {  // wave-uniform
     const int act_a = wave_bcast_i(act_lane, a);
-    if (controlled && p.agent_index[a] == i) { agent = a; act0 = act_a; }
+    if (controlled && p.agent_index[a] == i) { agent = a; act0 = HWY_ACTION_TO_ALL(p.action_set, act_a); }
   }
   sh.timer[i] = me.timer; sh.ts[i] = me.ts; sh.delta[i] = me.delta; sh.impx[i] = me.impx; sh.impy[i] = me.impy;
   const bool i_check = (me.flags & HWY_F_CHECK_COLLISIONS) != 0;

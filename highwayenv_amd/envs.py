@@ -122,10 +122,10 @@ class BatchedHighwayEnv:
         A = hc.num_agents
         self.single_observation_shape = _abi.obs_shape(hc) if A == 1 else (A, *_abi.obs_shape(hc))
         if _gym is not None:
-            self.single_action_space = _gym.spaces.Discrete(5)
+            self.single_action_space = _gym.spaces.Discrete(_abi.num_actions(hc))  # len(self.actions), action.py:252-253
             self.single_observation_space = _gym.spaces.Box(-np.inf, np.inf, self.single_observation_shape, np.float32)
         else:
-            self.single_action_space = _Discrete(5)
+            self.single_action_space = _Discrete(_abi.num_actions(hc))
             self.single_observation_space = _Box(self.single_observation_shape)
         self.action_space, self.observation_space = self.single_action_space, self.single_observation_space
 
@@ -402,6 +402,10 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
                 "on_road_reward": float(on_road)}
 
 
+# with gymnasium installed the single-environment drop-ins ARE gymnasium.Env's (gym.make / wrappers / checkers accept them)
+_GYM_BASES = (_gym.Env,) if _gym is not None else ()
+
+
 class _SingleEnvMixin:
     """E == 1 with the reference's unbatched signature."""
 
@@ -430,11 +434,11 @@ class _SingleEnvMixin:
         return [vs[self._hcfg.agent_index[a]] for a in range(self._hcfg.num_agents)]
 
 
-class HighwayEnv(_SingleEnvMixin, BatchedHighwayEnv):
+class HighwayEnv(_SingleEnvMixin, BatchedHighwayEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.highway_env.HighwayEnv`` (``highway-v0``)."""
 
 
-class HighwayEnvFast(_SingleEnvMixin, BatchedHighwayEnvFast):
+class HighwayEnvFast(_SingleEnvMixin, BatchedHighwayEnvFast, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.highway_env.HighwayEnvFast`` (``highway-fast-v0``)."""
 
 
@@ -457,7 +461,7 @@ class _SingleIntersectionMixin(_SingleEnvMixin):
         return [self.vehicle]
 
 
-class IntersectionEnv(_SingleIntersectionMixin, BatchedIntersectionEnv):
+class IntersectionEnv(_SingleIntersectionMixin, BatchedIntersectionEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.intersection_env.IntersectionEnv`` (``intersection-v0``)."""
 
 
@@ -465,23 +469,23 @@ class BatchedConnectedLaneIntersectionEnv(_ConnectedLaneNeighboursMixin, Batched
     """E parallel ``intersection-v2`` environments (ConnectedLaneIntersectionEnv, intersection_env.py:423)."""
 
 
-class ConnectedLaneIntersectionEnv(_SingleIntersectionMixin, BatchedConnectedLaneIntersectionEnv):
+class ConnectedLaneIntersectionEnv(_SingleIntersectionMixin, BatchedConnectedLaneIntersectionEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.intersection_env.ConnectedLaneIntersectionEnv`` (``intersection-v2``)."""
 
 
-class MergeEnv(_SingleMergeMixin, BatchedMergeEnv):
+class MergeEnv(_SingleMergeMixin, BatchedMergeEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.merge_env.MergeEnv`` (``merge-v0``)."""
 
 
-class MergeGenericEnv(_SingleMergeMixin, BatchedMergeGenericEnv):
+class MergeGenericEnv(_SingleMergeMixin, BatchedMergeGenericEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.merge_env.MergeGenericEnv`` (``merge-generic-v0``)."""
 
 
-class ConnectedLaneMergeEnv(_SingleMergeMixin, BatchedConnectedLaneMergeEnv):
+class ConnectedLaneMergeEnv(_SingleMergeMixin, BatchedConnectedLaneMergeEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.merge_env.ConnectedLaneMergeEnv`` (``merge-v1``)."""
 
 
-class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeGenericEnv):
+class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeGenericEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.merge_env.ConnectedLaneMergeGenericEnv`` (``merge-generic-v1``)."""
 
 
@@ -498,6 +502,28 @@ REGISTRY = {
     "intersection-v0": (IntersectionEnv, BatchedIntersectionEnv),
     "intersection-v2": (ConnectedLaneIntersectionEnv, BatchedConnectedLaneIntersectionEnv),
 }
+
+
+GYM_NAMESPACE = "highwayenv_amd"
+
+
+def register_envs(namespace: str | None = GYM_NAMESPACE) -> list:
+    """Register the single-environment drop-ins of REGISTRY with gymnasium, like ``highway_env/__init__.py:22-187`` does for
+    the reference at import time: ``gym.make("highwayenv_amd/highway-fast-v0", config={...})``.  The ids live in their own
+    namespace so that this package and ``highway_env`` can be installed side by side; ``namespace=None`` registers the
+    reference's bare ids (for a box without the reference).  Idempotent; returns the ids it registered; does nothing
+    (returns []) when gymnasium is not importable.  Importing ``highwayenv_amd`` calls it."""
+    if _gym is None:
+        return []
+    from gymnasium.envs.registration import register, registry
+    done = []
+    for env_id, (single, _batched) in REGISTRY.items():
+        full = f"{namespace}/{env_id}" if namespace else env_id
+        if full in registry:
+            continue
+        register(id=full, entry_point=f"{__name__}:{single.__name__}")
+        done.append(full)
+    return done
 
 
 def make(env_id: str, config: dict = None, **kwargs):

@@ -54,7 +54,7 @@ typedef enum hwy_status {
   HWY_ERR_HIP = -2,
   HWY_ERR_UNSUPPORTED = -3,
   HWY_ERR_NO_DEVICE = -4,
-  HWY_ERR_ACTION = -5 /* meta-action outside [0,5): the reference raises KeyError (action.py:260) */
+  HWY_ERR_ACTION = -5 /* meta-action outside the configured table: the reference raises KeyError (action.py:260) */
 } hwy_status;
 
 /* per-vehicle flag bits (hwy_state.flags) */
@@ -159,6 +159,11 @@ typedef struct hwy_lane {
 
 /* meta-actions: DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:204 */
 enum { HWY_LANE_LEFT = 0, HWY_IDLE = 1, HWY_LANE_RIGHT = 2, HWY_FASTER = 3, HWY_SLOWER = 4 };
+/* hwy_config.action_set: ACTIONS_ALL / ACTIONS_LONGI / ACTIONS_LAT (action.py:204-210) */
+enum { HWY_ACTIONS_ALL = 0, HWY_ACTIONS_LONGI = 1, HWY_ACTIONS_LAT = 2 };
+/* id in the configured table -> id in ACTIONS_ALL (what the kernels and the oracle act on) */
+#define HWY_ACTION_TO_ALL(set, a) ((set) == HWY_ACTIONS_LONGI ? ((a) == 0 ? HWY_SLOWER : ((a) == 2 ? HWY_FASTER : HWY_IDLE)) : (a))
+#define HWY_NUM_ACTIONS(set) ((set) == HWY_ACTIONS_ALL ? 5 : 3)
 
 /*
  * Flat POD derived from the reference's config dict
@@ -178,7 +183,10 @@ typedef struct hwy_config {
   int32_t obs_features;                /* F */
   int32_t obs_feature_ids[HWY_MAX_FEATURES];
   int32_t num_target_speeds;           /* MDPVehicle.target_speeds (controller.py:259,287-291) */
-  int32_t reserved0;
+  int32_t action_set;                  /* DiscreteMetaAction(longitudinal, lateral) (action.py:204-253): which table the action
+                                          ids index -- HWY_ACTIONS_ALL (5 ids), HWY_ACTIONS_LONGI {0 SLOWER, 1 IDLE, 2 FASTER},
+                                          HWY_ACTIONS_LAT {0 LANE_LEFT, 1 IDLE, 2 LANE_RIGHT}.  HWY_SCENARIO_INTERSECTION always
+                                          uses the longitudinal table (intersection_env.py:14) */
   double target_speeds[HWY_MAX_TARGET_SPEEDS];
   double dt;                           /* 1 / simulation_frequency  (abstract.py:307) */
   double policy_dt;                    /* 1 / policy_frequency      (abstract.py:274) */

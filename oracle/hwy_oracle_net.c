@@ -506,7 +506,8 @@ static void vehicle_step(const hwy_config *c, ent_t *v, double dt) { /* kinemati
 
 /* ---- road/road.py:464-481 -------------------------------------------------------------------------- */
 static void apply_meta_actions(net_t *r, const int *actions) { /* abstract.py:294-304, action.py:259-260,320-325 */
-  for (int a = 0; a < r->cfg->num_agents; a++) mdp_act(r->cfg, &r->v[r->cfg->agent_index[a]], actions[a]);
+  for (int a = 0; a < r->cfg->num_agents; a++) /* the id indexes ACTIONS_ALL / _LONGI / _LAT */
+    mdp_act(r->cfg, &r->v[r->cfg->agent_index[a]], HWY_ACTION_TO_ALL(r->cfg->action_set, actions[a]));
 }
 static void road_act(net_t *r) {
   for (int i = 0; i < r->n; i++) {
@@ -714,7 +715,7 @@ int orc_net_step(const hwy_config *c, hwy_state *st, const int32_t *actions, flo
   for (int e = 0; e < c->num_envs; e++) {
     for (int a = 0; a < A; a++) {
       acts[a] = actions[e * A + a];
-      if (acts[a] < 0 || acts[a] > 4) { free(v); return HWY_ERR_ACTION; }
+      if (acts[a] < 0 || acts[a] >= HWY_NUM_ACTIONS(c->action_set)) { free(v); return HWY_ERR_ACTION; }
     }
     load_env(c, st, e, v);
     net_t r = {c, v, N};

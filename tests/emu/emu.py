@@ -120,7 +120,7 @@ class EmuEngine:
 
     def step(self, actions):
         a = np.asarray(actions)
-        if ((a < 0) | (a > (2 if self.ix else 4))).any():
+        if ((a < 0) | (a > (2 if self.ix else _abi.num_actions(self.cfg) - 1))).any():
             raise KeyError("invalid meta-action")
         return self._run(1, self.cfg.frames_per_step, actions)
 

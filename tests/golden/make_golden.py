@@ -98,6 +98,15 @@ SCENARIOS = [
          config={"vehicles_count": 30, "vehicles_density": 2.5, "lanes_count": 3, "ego_spacing": 1.0, "duration": 20},
          seeds=list(range(200, 224)), steps=8, action_seed=22, frames_for=6,
          action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
+    # DiscreteMetaAction with one of the two action tables only (action.py:204-253): ids index ACTIONS_LAT / ACTIONS_LONGI
+    dict(name="fast_lateral_only", cls=HighwayEnvFast,
+         config={"vehicles_count": 25, "lanes_count": 4, "duration": 20,
+                 "action": {"type": "DiscreteMetaAction", "longitudinal": False}},
+         seeds=[31, 32, 33], steps=12, action_seed=31, frames_for=2, n_actions=3),
+    dict(name="v0_longitudinal_only", cls=HighwayEnv,
+         config={"vehicles_count": 20, "lanes_count": 3, "duration": 20, "simulation_frequency": 5,
+                 "action": {"type": "DiscreteMetaAction", "lateral": False, "target_speeds": [15, 20, 25, 30, 35]}},
+         seeds=[41, 42, 43], steps=12, action_seed=41, frames_for=2, n_actions=3),
     # all-IDLE free run (no agent interference): long horizon, many MOBIL decisions
     dict(name="fast_idle_long", cls=HighwayEnvFast,
          config={"vehicles_count": 30, "lanes_count": 4, "duration": 40}, seeds=[21, 22],
@@ -137,8 +146,9 @@ def run_scenario(sc: dict) -> dict:
     else:
         rng = np.random.default_rng(sc["action_seed"])
         p = sc.get("action_p")
-        actions = (rng.choice(5, size=(steps, E), p=p) if p is not None
-                   else rng.integers(0, 5, size=(steps, E))).astype(np.int32)
+        n_act = sc.get("n_actions", 5)
+        actions = (rng.choice(n_act, size=(steps, E), p=p) if p is not None
+                   else rng.integers(0, n_act, size=(steps, E))).astype(np.int32)
     out: dict = {"seeds": np.asarray(seeds, np.int64), "actions": actions}
     per_env = []
     frames_for = sc["frames_for"]
@@ -189,6 +199,7 @@ def run_scenario(sc: dict) -> dict:
     out["cfg_reward_speed_range"] = np.asarray(cfg["reward_speed_range"], np.float64)
     import json
     out["cfg_observation_json"] = np.asarray(json.dumps(cfg["observation"]))
+    out["cfg_action_json"] = np.asarray(json.dumps(cfg["action"]))
     out["obs0"] = np.stack([r["obs0"] for r in per_env])
     out["obs"] = np.stack([np.stack(r["obs"]) for r in per_env], axis=1)          # [steps,E,V,F]
     out["reward"] = np.asarray([r["reward"] for r in per_env], np.float64).T      # [steps,E]

@@ -12,8 +12,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 GRID = ["grid_default", "grid_aligned_fine", "grid_xy_range"]
 ALL = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
-       "fast_idle_long", "fast_offroad_terminal"]
-WITH_FRAMES = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash"]
+       "fast_idle_long", "fast_offroad_terminal", "fast_lateral_only", "v0_longitudinal_only"]
+WITH_FRAMES = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
+               "fast_lateral_only", "v0_longitudinal_only"]
 
 
 class Golden:
@@ -42,6 +43,9 @@ class Golden:
         if "cfg_observation_json" in z.files:
             import json
             self.config["observation"] = json.loads(str(z["cfg_observation_json"]))
+        if "cfg_action_json" in z.files:
+            import json
+            self.config["action"] = json.loads(str(z["cfg_action_json"]))
         self.seeds = z["seeds"]
         self.actions = z["actions"]  # [steps, E]
 
