@@ -36,6 +36,8 @@ C_EGO_ONLY_COLLISIONS = 64
 C_GRID_ALIGN = 128
 C_HOST_TRAFFIC = 256
 C_CONNECTED_LANES = 512
+C_OBS_UNSORTED = 1024
+C_OBS_VEHICLES_ONLY = 2048
 OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
 HWY_MAX_GRID_CELLS = 65536
 
@@ -332,8 +334,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     # (road.py:513-529: nothing leaves "1", nothing arrives at "0"), so the flag is accepted there and changes nothing
     if merge and grid:
         raise NotImplementedError("OccupancyGrid is not implemented for the merge networks")
-    if not grid and obs.get("order", "sorted") != "sorted":
-        raise NotImplementedError("KinematicObservation order='shuffled' is out of scope")
+    if not grid and obs.get("order", "sorted") not in ("sorted", "shuffled"):
+        raise ValueError("KinematicObservation order must be 'sorted' or 'shuffled'")
 
     c = HwyConfig()
     c.abi_version = HWY_ABI_VERSION
@@ -443,8 +445,10 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         flags |= C_OBS_SEE_BEHIND
     if (merge or ix) and cfg.get("neighbour_vehicles_connected_lanes", False):
         flags |= C_CONNECTED_LANES
-    if merge and not obs.get("include_obstacles", True):
-        raise NotImplementedError("KinematicObservation include_obstacles=False is out of scope")
+    if not grid and obs.get("order", "sorted") == "shuffled":
+        flags |= C_OBS_UNSORTED       # close_objects_to(sort=False); envs.py shuffles the rows on env.np_random
+    if not grid and not obs.get("include_obstacles", True):
+        flags |= C_OBS_VEHICLES_ONLY  # (only the merge scenarios have objects)
     if ix:
         for name in feats:
             if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h") + (("on_road",) if grid else ()):

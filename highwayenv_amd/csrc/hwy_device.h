@@ -653,7 +653,7 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
     const double d_lane = me.x - ex;  // lane_distance_to on the ego's (straight) lane
     const bool elig = active && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
                       ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
-    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();  // (sort=False: list order)
     __syncthreads();  // previous users of aux0 are done
     sh.aux0[i] = key;
     __syncthreads();

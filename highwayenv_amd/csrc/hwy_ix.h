@@ -832,7 +832,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
   const double d_lane = s_mine - wave_bcast(s_mine, ia);
   const bool elig = present && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
                     ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
-  const double key = elig ? fabs(d_lane) : __builtin_inf();
+  const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();  // (sort=False: list order)
   const int n_elig = __popcll(__ballot(elig));
   const int mrows = n_elig < V - 1 ? n_elig : V - 1;
   int pos = 0;  // stable sort position (ties keep list order)

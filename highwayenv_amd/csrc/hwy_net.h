@@ -346,9 +346,9 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
     const double dxe = me.x - ex, dye = me.y - ey;
     const double d_lane = (me.x - ox) - (ex - ox);  // observer.lane_distance_to(me)
     const bool near = dxe * dxe + dye * dye < p.perception * p.perception;
-    const bool elig = present && near && (obstacle ? (-2 * HWY_VEH_LENGTH < d_lane)
+    const bool elig = present && near && (obstacle ? (!(p.flags & HWY_C_OBS_VEHICLES_ONLY) && -2 * HWY_VEH_LENGTH < d_lane)
                                                    : (i != ia && ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane))));
-    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();  // (sort=False: list order)
     const int n_elig = __popcll(__ballot(elig));
     const int m = n_elig < V - 1 ? n_elig : V - 1;
     int pos = 0;  // stable sort position; obstacles sit after every vehicle slot, so slot order == list order

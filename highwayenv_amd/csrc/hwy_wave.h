@@ -204,12 +204,13 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
     // correctly rounded, so the compare can be done on the squares
     const bool elig = active && i != ia && (dxe * dxe + dye * dye < p.perception * p.perception) &&
                       ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
-    const double key = elig ? fabs(d_lane) : __builtin_inf();
+    // (sort=False, observation.py:245: every eligible object gets the same key, so the stable order is the list order)
+    const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();
     const int n_elig = __popcll(__ballot(elig));
     const int m = n_elig < V - 1 ? n_elig : V - 1;
     // stable sort position among the eligible (ties keep list order)
     int pos = 0;
-    if (BY_RANK && !(p.flags & HWY_C_OBS_SEE_BEHIND)) {  // wave-uniform
+    if (BY_RANK && !(p.flags & (HWY_C_OBS_SEE_BEHIND | HWY_C_OBS_UNSORTED))) {  // wave-uniform
       // Everything eligible BEHIND the observer is closer than 2*LENGTH, so the eligible split into `near`
       // (key < 2*LENGTH: a handful, ordered by explicit compares) and `far` (all in front by at least 2*LENGTH,
       // after every near one, and among themselves ordered like x, i.e. like their rank along the road).

@@ -153,11 +153,11 @@ class BatchedHighwayEnv:
             seeds = list(seed)
             if len(seeds) != E:
                 raise ValueError("one seed per env expected")
+        for e, s in enumerate(seeds):
+            if s is not None or self.np_random[e] is None:
+                # gymnasium.utils.seeding.np_random(seed): Generator(PCG64(SeedSequence(seed)))
+                self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
         if self.spawn_mode == "reference":
-            for e, s in enumerate(seeds):
-                if s is not None or self.np_random[e] is None:
-                    # gymnasium.utils.seeding.np_random(seed): Generator(PCG64(SeedSequence(seed)))
-                    self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
             eng.set_state(self._spawn_reference(self.np_random))
             obs = eng.observe()
         else:
@@ -222,6 +222,16 @@ class BatchedHighwayEnv:
         return self._shape_obs(obs), reward[:, 0], term, trunc, out_info
 
     def _shape_obs(self, obs):
+        # KinematicObservation(order="shuffled") (observation.py:273-274): `self.env.np_random.shuffle(obs[1:])` after every
+        # observe(), agent by agent -- the engine returned the rows in list order (HWY_C_OBS_UNSORTED), the shuffle draws
+        # from each environment's own generator like the reference's (same stream as its spawn in spawn_mode="reference")
+        if self._hcfg.flags & _abi.C_OBS_UNSORTED:
+            obs = np.array(obs, copy=True)
+            for e in range(self.num_envs):
+                if self.np_random[e] is None:
+                    self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
+                for a in range(self._hcfg.num_agents):
+                    self.np_random[e].shuffle(obs[e, a, 1:])
         return obs[:, 0] if self._hcfg.num_agents == 1 else obs
 
     # ---- inspection --------------------------------------------------------------------------------

@@ -86,6 +86,11 @@ enum {
   HWY_C_GRID_ALIGN = 128,     /* OccupancyGridObservation.align_to_vehicle_axes  observation.py:294,431-435 */
   HWY_C_CONNECTED_LANES = 512, /* Road.neighbour_vehicles_connected_lanes (road.py:483-547; merge-v1, merge-generic-v1): the
                                  leader / follower search on a lane also looks at hwy_lane.connected */
+  HWY_C_OBS_UNSORTED = 1024,  /* KinematicObservation(order="shuffled") (observation.py:245,273-274): close_objects_to(sort=False)
+                                 keeps the first vehicles_count - 1 eligible objects in LIST order; the shuffle of the rows
+                                 itself draws from env.np_random and is done by the host side of the binding */
+  HWY_C_OBS_VEHICLES_ONLY = 2048, /* KinematicObservation(include_obstacles=False) (observation.py:172,246): objects of
+                                 Road.objects (the merge scenarios' Obstacle) are not observed */
   HWY_C_HOST_TRAFFIC = 256    /* HWY_SCENARIO_INTERSECTION: the HOST clears / spawns vehicles between policy steps (the
                                  reference-stream mode of highwayenv_amd/intersection.py); otherwise the step kernel does
                                  it on Philox draws */

@@ -61,7 +61,8 @@ typedef struct {
   int32_t num_envs, n_slots, n_lanes, n_route, frames_per_step, num_target_speeds, obs_vehicles, obs_features;
   int32_t obs_feature_ids[IX_MAX_FEATURES];
   int32_t obs_absolute, obs_normalize, obs_clip, obs_see_behind, normalize_reward, offroad_terminal,
-      connected_lanes /* Road.neighbour_vehicles_connected_lanes (intersection-v2) */, pad1;
+      connected_lanes /* Road.neighbour_vehicles_connected_lanes (intersection-v2) */,
+      obs_unsorted /* order="shuffled": close_objects_to(sort=False) (observation.py:245) */;
   double dt, policy_dt, duration, perception_distance;
   double distance_wanted, time_wanted, comfort_acc_max, comfort_acc_min; /* IDMVehicle class attributes (:243-247) */
   double target_speeds[8];
@@ -701,7 +702,7 @@ static void observe_agent(const road_t *r, int ego_idx, float *obs) {
     close[m].idx = j;
     m++;
   }
-  for (int a = 1; a < m; a++) { /* sorted() is stable */
+  for (int a = 1; a < m && !c->obs_unsorted; a++) { /* sorted() is stable; sort=False: list order */
     close_t t = close[a];
     int b = a - 1;
     while (b >= 0 && close[b].key > t.key) { close[b + 1] = close[b]; b--; }

@@ -554,7 +554,8 @@ static void observe_agent(const net_t *r, int ego_idx, float *obs) {
   int see_behind = (c->flags & HWY_C_OBS_SEE_BEHIND) != 0;
   close_t *close = (close_t *)malloc(sizeof(close_t) * (size_t)r->n);
   int m = 0;
-  for (int pass = 0; pass < 2; pass++) { /* vehicles, then obstacles */
+  /* vehicles_only = not include_obstacles (observation.py:246, road.py:444) */
+  for (int pass = 0; pass < ((c->flags & HWY_C_OBS_VEHICLES_ONLY) ? 1 : 2); pass++) { /* vehicles, then obstacles */
     for (int j = 0; j < r->n; j++) {
       const ent_t *v = &r->v[j];
       if (!v->present || v->obstacle != pass) continue;
@@ -571,7 +572,7 @@ static void observe_agent(const net_t *r, int ego_idx, float *obs) {
       m++;
     }
   }
-  for (int a = 1; a < m; a++) { /* sorted() is stable */
+  for (int a = 1; a < m && !(c->flags & HWY_C_OBS_UNSORTED); a++) { /* sorted() is stable; sort=False: list order */
     close_t t = close[a];
     int b = a - 1;
     while (b >= 0 && close[b].key > t.key) { close[b + 1] = close[b]; b--; }

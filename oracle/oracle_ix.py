@@ -34,7 +34,7 @@ class IxConfig(C.Structure):
                                           "num_target_speeds", "obs_vehicles", "obs_features"]]
                 + [("obs_feature_ids", C.c_int32 * IX_MAX_FEATURES)]
                 + [(k, C.c_int32) for k in ["obs_absolute", "obs_normalize", "obs_clip", "obs_see_behind",
-                                            "normalize_reward", "offroad_terminal", "connected_lanes", "pad1"]]
+                                            "normalize_reward", "offroad_terminal", "connected_lanes", "obs_unsorted"]]
                 + [(k, C.c_double) for k in ["dt", "policy_dt", "duration", "perception_distance", "distance_wanted",
                                              "time_wanted", "comfort_acc_max", "comfort_acc_min"]]
                 + [("target_speeds", C.c_double * 8)]
@@ -104,6 +104,7 @@ def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots
         c.obs_feature_ids[k] = FEATURE_IDS[name]
     c.obs_absolute, c.obs_normalize = int(obs.get("absolute", False)), int(obs.get("normalize", True))
     c.obs_clip, c.obs_see_behind = int(obs.get("clip", True)), int(obs.get("see_behind", False))
+    c.obs_unsorted = int(obs.get("order", "sorted") == "shuffled")
     inf = float("inf")
     for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
         field[0], field[1] = (float(fr[name][0]), float(fr[name][1])) if name in fr else (-inf, inf)

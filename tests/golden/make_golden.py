@@ -107,6 +107,11 @@ SCENARIOS = [
          config={"vehicles_count": 20, "lanes_count": 3, "duration": 20, "simulation_frequency": 5,
                  "action": {"type": "DiscreteMetaAction", "lateral": False, "target_speeds": [15, 20, 25, 30, 35]}},
          seeds=[41, 42, 43], steps=12, action_seed=41, frames_for=2, n_actions=3),
+    # KinematicObservation(order="shuffled"): close_objects_to(sort=False) + np_random.shuffle(obs[1:]) (observation.py:245,273)
+    dict(name="fast_shuffled", cls=HighwayEnvFast,
+         config={"vehicles_count": 25, "lanes_count": 4, "duration": 20,
+                 "observation": {"type": "Kinematics", "order": "shuffled", "vehicles_count": 7}},
+         seeds=[51, 52, 53], steps=10, action_seed=51, frames_for=0),
     # all-IDLE free run (no agent interference): long horizon, many MOBIL decisions
     dict(name="fast_idle_long", cls=HighwayEnvFast,
          config={"vehicles_count": 30, "lanes_count": 4, "duration": 40}, seeds=[21, 22],

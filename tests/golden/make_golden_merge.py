@@ -181,6 +181,12 @@ SCENARIOS = [
     # merge-v1 / merge-generic-v1: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
     dict(name="merge_v1", cls=ConnectedLaneMergeEnv, config={}, seeds=list(range(8)), steps=14, action_seed=35,
          frames_for=3, n_slots=6),
+    # KinematicObservation(include_obstacles=False): the Obstacle at the end of the acceleration lane is not observed
+    # (observation.py:172,246 -> close_objects_to(vehicles_only=True)); a short ramp so that the ego gets close to it
+    dict(name="merge_no_obstacles", cls=MergeEnv,
+         config={"observation": {"type": "Kinematics", "include_obstacles": False, "vehicles_count": 6}},
+         seeds=list(range(20, 26)), steps=12, action_seed=37, frames_for=1, n_slots=6,
+         action_p=[0.05, 0.2, 0.45, 0.25, 0.05]),
     dict(name="merge_generic_v1", cls=ConnectedLaneMergeGenericEnv, config={"lanes_count": 3, "vehicles_count": 20},
          seeds=list(range(5)), steps=13, action_seed=36, frames_for=2, n_slots=23,
          action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),

@@ -361,3 +361,27 @@ def test_action_tables_longitudinal_or_lateral_only():
     with pytest.raises(ValueError, match="At least longitudinal or lateral"):
         envs.BatchedHighwayEnv({"action": {"type": "DiscreteMetaAction", "longitudinal": False, "lateral": False}})
     assert _abi.make_config(dict(_abi.highway_default_config(), action={"type": "DiscreteMetaAction", "lateral": False}), 1).action_set == _abi.ACTIONS_SET_LONGI
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+def test_shuffled_observation_order_replays_the_reference_stream(real):
+    """KinematicObservation(order="shuffled"): the kernel returns the first vehicles_count - 1 eligible vehicles in LIST
+    order (close_objects_to(sort=False)), the host shuffles rows 1.. on each environment's own generator -- the same
+    stream the reference's reset(seed=s) spawned the traffic from, so the observations are the reference's row for row."""
+    g = Golden("fast_shuffled")
+    assert g.config["observation"]["order"] == "shuffled"
+    cls = envs.BatchedHighwayEnvFast if real else EmuFast
+    env = cls(g.config, num_envs=g.E)
+    assert env._hcfg.flags & _abi.C_OBS_UNSORTED
+    obs, _ = env.reset(seed=[int(s) for s in g.seeds])
+    np.testing.assert_allclose(obs, g.z["obs0"], rtol=0, atol=1e-6)
+    live = np.ones(g.E, bool)
+    for t in range(g.steps):
+        obs, reward, term, trunc, info = env.step(g.actions[t])
+        np.testing.assert_allclose(obs[live], g.z["obs"][t][live], rtol=0, atol=1e-6, err_msg=f"step {t}")
+        np.testing.assert_allclose(reward[live], g.z["reward"][t][live], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(term[live], g.z["terminated"][t].astype(bool)[live])
+        live &= ~(term | trunc)
+        if not live.any():
+            break
+    env.close()
