@@ -142,7 +142,7 @@ static int validate(const hwy_config *c, std::string &why) {
     if (c->num_agents != 1) BAD("the intersection scenario has one controlled vehicle");
     if (c->num_vehicles < 4 || c->num_vehicles > 64) BAD("the intersection scenario needs 4..64 slots (one wavefront per environment)");
     if (c->gnet_lanes < 1 || c->gnet_lanes > HWY_MAX_GLANES) BAD("gnet_lanes must be in [1,%d]", HWY_MAX_GLANES);
-    if (c->destination < 0 || c->destination > 3) BAD("destination must be the k of \"o\" + k, 0..3");
+    if (c->destination < -1 || c->destination > 3) BAD("destination must be the k of \"o\" + k, 0..3, or -1 for a random one");
     if (c->initial_vehicle_count < 1) BAD("initial_vehicle_count must be positive");
     for (int k = 0; k < 4; ++k)
       if (c->access_lane[k] < 0 || c->access_lane[k] >= c->gnet_lanes || c->exit_of[k] < 0 || c->exit_of[k] >= c->gnet_lanes)

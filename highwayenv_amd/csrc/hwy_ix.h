@@ -1046,6 +1046,14 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
   // the ego on ("o0", "ir0", 0) at 60 + 5 * normal(1.0), speed = speed_limit, route to config["destination"]
   double u0, u1;
   philox_uniform2(seed, 501u, episode, 0u, &u0, &u1);
+  // destination = config["destination"] or "o" + str(np_random.integers(1, 4)) (:295-297): uniform over {1, 2, 3}
+  int destination = ip.destination;
+  if (destination < 0) {
+    double ud, unused;
+    philox_uniform2(seed, 501u, episode, 1u, &ud, &unused);
+    const int k = (int)(ud * 3);
+    destination = 1 + (k > 2 ? 2 : k);
+  }
   const int access = ip.access_lane[0];
   double ex, ey;
   ix_position(sh, access, 60.0 + 5.0 * (1.0 + ix_normal(u0, u1)), &ex, &ey);
@@ -1061,7 +1069,7 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
     me.dirty = 1;
     me.x = ex; me.y = ey; me.h = eh; me.v = sh.lim[access];
     me.lane = me.tgt = best;
-    me.route = ix_plan_route(ip, sh, best, ip.destination);
+    me.route = ix_plan_route(ip, sh, best, destination);
     const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
     me.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
     me.ts = p.target_speeds[me.sidx];

@@ -120,8 +120,9 @@ def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
     if int(cfg.get("controlled_vehicles", 1)) != 1:
         raise NotImplementedError("MultiAgentIntersectionEnv (controlled_vehicles > 1) is out of scope")
     dest = cfg.get("destination")
-    if not (isinstance(dest, str) and dest in ("o0", "o1", "o2", "o3")):
-        raise NotImplementedError("destination must be one of 'o0'..'o3' (a random destination is out of scope)")
+    # config["destination"] or "o" + str(np_random.integers(1, 4)) (intersection_env.py:295-297): None / "" = a random exit
+    if dest and not (isinstance(dest, str) and dest in ("o0", "o1", "o2", "o3")):
+        raise ValueError("destination must be one of 'o0'..'o3', or None for a random one")
     c.scenario = _abi.SCENARIO_INTERSECTION
     c.num_vehicles = int(cfg.get("max_vehicles", 32))  # slots per environment (the list grows while an episode runs)
     if not (4 <= c.num_vehicles <= 64):
@@ -141,7 +142,7 @@ def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
     for q in range(4):
         c.access_lane[q] = lane_index_of(tab, f"o{q}", f"ir{q}")
         c.exit_of[q] = lane_index_of(tab, f"il{q}", f"o{q}")
-    c.destination = int(dest[1])
+    c.destination = int(dest[1]) if dest else -1  # -1: drawn per episode (1..3)
     c.initial_vehicle_count = int(cfg["initial_vehicle_count"])
     c.spawn_probability = float(cfg["spawn_probability"])
     c.arrived_reward = float(cfg["arrived_reward"])
@@ -296,6 +297,8 @@ def make_vehicles_after_warmup(c, cfg, tab, st, e, rng) -> None:
     spawn_vehicle(c, tab, st, e, rng, 60, spawn_probability=1.0, go_straight=True, position_deviation=0.1,
                   speed_deviation=0.0)
     access = lane_index_of(tab, "o0", "ir0")
+    # destination = config["destination"] or "o" + str(np_random.integers(1, 4)): drawn BEFORE the position (:295-300)
+    destination = c.destination if c.destination >= 0 else int(rng.integers(1, 4))
     pos = lane_position(tab, access, 60.0 + 5.0 * rng.normal(1.0))
     heading = lane_heading_at(tab, access, 60.0)
     speed = float(tab["speed_limit"][access])
@@ -312,7 +315,7 @@ def make_vehicles_after_warmup(c, cfg, tab, st, e, rng) -> None:
     st["target_speed"][e, i] = ts[sidx]
     st["timer"][e, i] = st["delta"][e, i] = st["impact_x"][e, i] = st["impact_y"][e, i] = 0.0
     st["flags"][e, i] = _abi.F_CONTROLLED | _abi.F_CHECK_COLLISIONS
-    st["route"][e, i] = route_pack(plan_route(tab, lane, c.destination))
+    st["route"][e, i] = route_pack(plan_route(tab, lane, destination))
     present = (st["flags"][e] & _abi.F_ABSENT) == 0
     keep = present.copy()
     for j in np.nonzero(present)[0]:

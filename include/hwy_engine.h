@@ -223,7 +223,9 @@ typedef struct hwy_config {
   /* HWY_SCENARIO_INTERSECTION (ABI v4) */
   int32_t gnet_lanes;                  /* entries used in gnet[] */
   int32_t initial_vehicle_count;       /* config["initial_vehicle_count"] (device reset, intersection_env.py:232-290) */
-  int32_t destination;                 /* k of config["destination"] == "o" + k (the ego's route, intersection_env.py:262-275) */
+  int32_t destination;                 /* k of config["destination"] == "o" + k (the ego's route, intersection_env.py:262-275);
+                                          -1: config["destination"] is None -- "o" + str(np_random.integers(1, 4)) per episode
+                                          (:295-297), drawn by the device reset on its own counter-based stream */
   int32_t reserved3;
   int32_t access_lane[4];              /* table index of ("o" + k, "ir" + k, 0): where _spawn_vehicle puts new traffic */
   int32_t exit_of[4];                  /* table index of ("il" + k, "o" + k, 0): the last road of a route to "o" + k */

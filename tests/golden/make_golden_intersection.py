@@ -160,6 +160,9 @@ SCENARIOS = [
                                  "grid_step": [4, 4], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
                                  "features_range": {"x": [-40, 40], "y": [-40, 40], "vx": [-20, 20], "vy": [-20, 20]}}},
          seeds=[31, 32], steps=12, action_seed=44, frames_for=0, n_slots=24),
+    # config["destination"] = None: "o" + str(np_random.integers(1, 4)) per episode (intersection_env.py:295-297)
+    dict(name="intersection_random_destination", config={"destination": None}, seeds=list(range(51, 59)), steps=8,
+         action_seed=46, frames_for=0, n_slots=24),
     # intersection-v2: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
     dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
          config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},

@@ -261,8 +261,9 @@ def test_single_intersection_env_dropin_matches_reference_episode(real, e, v2):
 def test_intersection_config_errors():
     with pytest.raises(NotImplementedError):
         EmuBatchedIntersection({"controlled_vehicles": 2}, num_envs=1)
-    with pytest.raises(NotImplementedError):
-        EmuBatchedIntersection({"destination": None}, num_envs=1)
+    assert EmuBatchedIntersection({"destination": None}, num_envs=1)._hcfg.destination == -1  # random exit per episode
+    with pytest.raises(ValueError):
+        EmuBatchedIntersection({"destination": "o7"}, num_envs=1)
     with pytest.raises(NotImplementedError):
         EmuBatchedIntersection({"observation": {"type": "OccupancyGrid", "features": ["presence", "lat_off"]}}, num_envs=1)
     assert EmuBatchedIntersection({"observation": {"type": "OccupancyGrid"}}, num_envs=1).single_observation_shape == (4, 11, 11)
@@ -385,3 +386,38 @@ def test_shuffled_observation_order_replays_the_reference_stream(real):
         if not live.any():
             break
     env.close()
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+def test_random_destination_replays_the_reference_stream(real):
+    """config["destination"] = None: the reference draws "o" + str(np_random.integers(1, 4)) for the ego BEFORE its position
+    (intersection_env.py:295-300).  reset(seed=s) must give the reference's ego route, first observation and episode."""
+    from highwayenv_amd import intersection as hix
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection("intersection_random_destination")
+    assert g.config["destination"] is None
+    dests = set()
+    for e in range(g.E):
+        env = (envs.IntersectionEnv if real else EmuIntersection)({"destination": None})
+        obs, info = env.reset(seed=int(g.z["seeds"][e]))
+        np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)
+        st = env.get_state()
+        ego = int(np.argmax((st["flags"][0] & _abi.F_CONTROLLED) != 0))
+        route = hix.route_unpack(int(st["route"][0, ego]))
+        tab = hix.table_from_config(env._hcfg)
+        init = g.state("init")
+        want = [(int(init["route_from"][e, ego, q]), int(init["route_to"][e, ego, q])) for q in range(int(init["route_len"][e, ego]))]
+        assert [(int(tab["from_node"][l]), int(tab["to_node"][l])) for l in route] == want
+        dests.add(want[-1][1])
+        for t in range(3):
+            wst = g.state("step", t)
+            pres = wst["present"][e] != 0
+            if ((wst["crashed"][e] != 0) | (wst["has_impact"][e] != 0))[pres].any() or (np.abs(wst["speed"][e][pres]) < 0.5).any():
+                break
+            obs, r, te, tr, info = env.step(int(g.actions[t, e, 0]))
+            np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=f"env {e} step {t}")
+            assert abs(r - g.z["reward"][t, e]) < 1e-9
+            if te or tr:
+                break
+        env.close()
+    assert len(dests) >= 2  # the draw really varies over the seeds

@@ -82,6 +82,10 @@ def _host_reset(backend, cfg, c, seeds, episode):
                 a, b = philox_uniform2(int(_sd), 501, int(episode), 0)
                 return loc + np.sqrt(-2.0 * np.log(1.0 - a)) * np.cos(2 * np.pi * b)
 
+            def integers(self, lo, hi, _sd=sd):  # destination = "o" + str(np_random.integers(1, 4))
+                k = min(int(philox_uniform2(int(_sd), 501, int(episode), 1)[0] * 3), 2)
+                return lo + k
+
             def uniform(self, *a, **k):  # the challenger already took its draws
                 raise AssertionError
         # second half of make_vehicles_after_warmup without its own challenger spawn: replay it with a generator whose
@@ -95,9 +99,10 @@ def _host_reset(backend, cfg, c, seeds, episode):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-def test_device_reset_follows_the_reference_rule(backend):
+@pytest.mark.parametrize("destination", ["o1", None])
+def test_device_reset_follows_the_reference_rule(backend, destination):
     E = 6
-    cfg, c = _config(E, max_vehicles=24)
+    cfg, c = _config(E, max_vehicles=24, destination=destination)
     seeds = np.array([3, 2**40 + 17, 99, 12345678901234567, 0, 7], np.uint64)
     eng = make_engine(backend, c)
     obs = eng.reset(seeds=seeds)
