@@ -332,8 +332,6 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         raise ValueError(f"unknown scenario {scenario!r}")
     # neighbour_vehicles_connected_lanes on the single road 0->1 of highway-v0 adds no lane to the search list
     # (road.py:513-529: nothing leaves "1", nothing arrives at "0"), so the flag is accepted there and changes nothing
-    if merge and grid:
-        raise NotImplementedError("OccupancyGrid is not implemented for the merge networks")
     if not grid and obs.get("order", "sorted") not in ("sorted", "shuffled"):
         raise ValueError("KinematicObservation order must be 'sorted' or 'shuffled'")
 
@@ -461,7 +459,7 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         # the Obstacle's to_dict (vehicle/objects.py:141-160) has no heading / lane-offset keys: the reference
         # would put NaN in those columns whenever the obstacle is observed
         for name in feats:
-            if name not in ("presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "cos_d", "sin_d"):
+            if name not in ("presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "cos_d", "sin_d") + (("on_road",) if grid else ()):
                 raise NotImplementedError(f"feature {name!r} is undefined for the Obstacle of the merge scenarios")
     if grid and obs.get("align_to_vehicle_axes", False):
         flags |= C_GRID_ALIGN

@@ -323,6 +323,80 @@ __device__ inline void net_neighbours_scan(const NetShared &sh, u64 pm, int bits
   *rear = b;
 }
 
+// ---- OccupancyGridObservation (observation.py:354-413) on a road network, for one observer: like observe_grid of
+//      hwy_device.h (atomic-min cell ownership: the lowest slot wins like the reference's reverse iteration, owners write
+//      their features), but only Road.vehicles are rasterised (not the Obstacle of Road.objects, :366-368) and the on-road
+//      layer walks the waypoints of EVERY lane of the table -- lane.position(wp, 0) = (x0 + wp, y0 [+ amplitude * sin(
+//      pulsation * wp + phase)]), SineLane included (:454-484). ---------------------------------------------------------
+__device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh, int e, int a, const Veh &me, bool veh,
+                                        double ex, double ey, double ev, double ec, double es) {
+  const StepParams &p = np.s;
+  const int i = threadIdx.x, NT = 64;
+  const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
+  int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
+  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  for (int t = i; t < WH; t += NT) {
+    grid_ws_store(own + t, 0x7fffffff);
+    grid_ws_store(road + t, 0);
+  }
+  __syncthreads();
+  int my_ci = -1, my_cj = -1;
+  if (veh) {
+    double x = me.x - ex, y = me.y - ey;
+    if (p.rx0 > -__builtin_inf()) x = lmap(lmap(x, p.rx0, p.rx1, -1.0, 1.0), -1.0, 1.0, p.rx0, p.rx1);
+    if (p.ry0 > -__builtin_inf()) y = lmap(lmap(y, p.ry0, p.ry1, -1.0, 1.0), -1.0, 1.0, p.ry0, p.ry1);
+    int ci, cj;
+    grid_cell(p, x, y, ec, es, &ci, &cj);
+    if (0 <= ci && ci < W && 0 <= cj && cj < H) {
+      my_ci = ci;
+      my_cj = cj;
+      grid_ws_min(own + ci * H + cj, i);
+    }
+  }
+  bool has_road = false;
+  for (int f = 0; f < F; ++f) has_road |= (p.feat[f] == HWY_FEAT_ON_ROAD);
+  if (has_road) {
+    for (int t = i; t < np.n_lanes * p.g_nwp; t += NT) {
+      const int k = t / p.g_nwp, j = t - k * p.g_nwp;
+      const double origin = ex - sh.lx0[k];  // lane.local_coordinates(observer)[0]: every lane of these networks runs along +x
+      const double wp = clipd((origin - 100.0) + j * p.g_spacing, 0.0, sh.llen[k]);
+      double py = sh.ly0[k];
+      if (sh.lamp[k] != 0.0) {
+        double sn, cs;
+        sincos_bounded(sh.lpuls[k] * wp + sh.lphase[k], &sn, &cs);
+        py = sh.ly0[k] + (0.0 + sh.lamp[k] * sn);
+      }
+      int ci, cj;
+      grid_cell(p, (sh.lx0[k] + wp) - ex, py - ey, ec, es, &ci, &cj);
+      if (0 <= ci && ci < W && 0 <= cj && cj < H) grid_ws_store(road + ci * H + cj, 1);
+    }
+  }
+  __syncthreads();
+  const bool clip = (p.flags & HWY_C_OBS_CLIP) != 0;
+  if (my_ci >= 0 && grid_ws_load(own + my_ci * H + my_cj) == i) {
+    for (int f = 0; f < F; ++f) {
+      const int fid = p.feat[f];
+      if (fid == HWY_FEAT_ON_ROAD) continue;
+      double val = EnvBlock<1>::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
+      const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
+      if (rel) {
+        val -= fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ec : ev * es;
+        const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
+        const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+        if (r0 > -__builtin_inf()) val = lmap(val, r0, r1, -1.0, 1.0);
+      }
+      if (clip) val = clipd(val, -1.0, 1.0);
+      out[(f * W + my_ci) * H + my_cj] = (float)val;
+    }
+  }
+  for (int t = i; t < F * WH; t += NT) {
+    const int f = t / WH, c = t - f * WH;
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
+    else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;
+  }
+  __syncthreads();
+}
+
 // ---- KinematicObservation (observation.py:234-276) with obstacles (road.py:421-450), MergeEnv reward and
 //      termination (merge_env.py:40-82).  All cross-lane reads through readlane. -------------------------------------
 __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, const Veh &me, bool write_reward) {
@@ -357,7 +431,8 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
       const double kk = wave_bcast(key, k);
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
-    if (p.obs) {
+    if (p.obs && p.obs_type != HWY_OBS_KINEMATICS) net_observe_grid(np, sh, e, a, me, veh, ex, ey, ev, ec, es);
+    if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
       float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (present && row >= 0) {

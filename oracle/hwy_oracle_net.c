@@ -604,6 +604,80 @@ static void observe_agent(const net_t *r, int ego_idx, float *obs) {
   free(close);
 }
 
+/* ---- OccupancyGridObservation.observe (observation.py:354-413) on a road network: only Road.vehicles are rasterised
+ *      (the Obstacle of Road.objects is not, :366-368), the on-road layer walks every lane of the network (:454-484) -- */
+static void grid_pos_to_index(const hwy_config *c, const ent_t *ego, double px, double py, int relative, int *ci, int *cj) {
+  if (!relative) { px -= ego->x; py -= ego->y; } /* observation.py:415-435 */
+  if (c->flags & HWY_C_GRID_ALIGN) {
+    double cs = cos(ego->heading), sn = sin(ego->heading);
+    double qx = cs * px + sn * py, qy = -sn * px + cs * py;
+    px = qx; py = qy;
+  }
+  *ci = (int)floor((px - c->grid_min[0]) / c->grid_step[0]);
+  *cj = (int)floor((py - c->grid_min[1]) / c->grid_step[1]);
+}
+static const double *grid_range(const hwy_config *c, int fid) {
+  const double *rg = fid == HWY_FEAT_X ? c->obs_range_x : fid == HWY_FEAT_Y ? c->obs_range_y
+                   : fid == HWY_FEAT_VX ? c->obs_range_vx : fid == HWY_FEAT_VY ? c->obs_range_vy : NULL;
+  return (rg && isfinite(rg[0])) ? rg : NULL;
+}
+static void observe_grid_agent(const net_t *r, int ego_idx, float *obs) {
+  const hwy_config *c = r->cfg;
+  const ent_t *ego = &r->v[ego_idx];
+  int F = c->obs_features, W = c->grid_shape[0], H = c->grid_shape[1];
+  double *grid = (double *)malloc(sizeof(double) * (size_t)F * W * H);
+  for (int k = 0; k < F * W * H; k++) grid[k] = NAN;
+  for (int layer = 0; layer < F; layer++) {
+    int fid = c->obs_feature_ids[layer];
+    if (fid != HWY_FEAT_ON_ROAD) {
+      for (int i = r->n - 1; i >= 0; i--) { /* df[::-1].iterrows() over Road.vehicles: the lower index wins a cell */
+        const ent_t *v = &r->v[i];
+        if (!is_veh(v)) continue;
+        double x = v->x - ego->x, y = v->y - ego->y;
+        const double *rx = grid_range(c, HWY_FEAT_X), *ry = grid_range(c, HWY_FEAT_Y);
+        if (rx) { x = lmap(x, rx[0], rx[1], -1, 1); x = lmap(x, -1, 1, rx[0], rx[1]); }
+        if (ry) { y = lmap(y, ry[0], ry[1], -1, 1); y = lmap(y, -1, 1, ry[0], ry[1]); }
+        int ci, cj;
+        grid_pos_to_index(c, ego, x, y, 1, &ci, &cj);
+        if (0 <= ci && ci < W && 0 <= cj && cj < H) {
+          double val = feature_of(v, fid);
+          if (fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY) val -= feature_of(ego, fid);
+          const double *rg = grid_range(c, fid);
+          if (rg) val = lmap(val, rg[0], rg[1], -1, 1);
+          grid[((size_t)layer * W + ci) * H + cj] = val;
+        }
+      }
+    } else {
+      double spacing = fmin(c->grid_step[0], c->grid_step[1]);
+      for (int k = 0; k < c->net_lanes; k++) { /* every lane of the network, StraightLane and SineLane alike */
+        const hwy_lane *l = &c->net[k];
+        double origin, lat;
+        lane_local(l, ego->x, ego->y, &origin, &lat);
+        double start = origin - 100.0, stop = origin + 100.0;
+        int n = (int)ceil((stop - start) / spacing); /* len(np.arange(start, stop, step)) */
+        for (int j = 0; j < n; j++) {
+          double wp = clipd(start + j * spacing, 0, l->length);
+          double px, py;
+          lane_position(l, wp, 0.0, &px, &py);
+          int ci, cj;
+          grid_pos_to_index(c, ego, px, py, 0, &ci, &cj);
+          if (0 <= ci && ci < W && 0 <= cj && cj < H) grid[((size_t)layer * W + ci) * H + cj] = 1;
+        }
+      }
+    }
+  }
+  for (int k = 0; k < F * W * H; k++) {
+    double v = grid[k];
+    if (c->flags & HWY_C_OBS_CLIP) v = isnan(v) ? v : clipd(v, -1, 1);
+    obs[k] = isnan(v) ? 0.0f : (float)v;
+  }
+  free(grid);
+}
+static void observe_any(const net_t *r, int ego_idx, float *obs) {
+  if (r->cfg->obs_type == HWY_OBS_OCCUPANCY_GRID) observe_grid_agent(r, ego_idx, obs);
+  else observe_agent(r, ego_idx, obs);
+}
+
 /* ---- MergeEnv._reward / _rewards (merge_env.py:40-75); `action` is the agent's own meta-action ---------- */
 static double reward_of(const net_t *r, const ent_t *ego, int action) {
   const hwy_config *c = r->cfg;
@@ -695,12 +769,13 @@ int orc_net_neighbours(const hwy_config *c, const hwy_state *st, int32_t e, int3
 
 int orc_net_observe(const hwy_config *c, const hwy_state *st, float *obs) {
   int N = c->num_vehicles, A = c->num_agents;
-  size_t VF = (size_t)c->obs_vehicles * c->obs_features;
+  size_t VF = c->obs_type == HWY_OBS_OCCUPANCY_GRID ? (size_t)c->obs_features * c->grid_shape[0] * c->grid_shape[1]
+                                                    : (size_t)c->obs_vehicles * c->obs_features;
   ent_t *v = (ent_t *)malloc(sizeof(ent_t) * (size_t)N);
   for (int e = 0; e < c->num_envs; e++) {
     load_env(c, st, e, v);
     net_t r = {c, v, N};
-    for (int a = 0; a < A; a++) observe_agent(&r, c->agent_index[a], obs + ((size_t)e * A + a) * VF);
+    for (int a = 0; a < A; a++) observe_any(&r, c->agent_index[a], obs + ((size_t)e * A + a) * VF);
   }
   free(v);
   return 0;
@@ -710,7 +785,8 @@ int orc_net_observe(const hwy_config *c, const hwy_state *st, float *obs) {
 int orc_net_step(const hwy_config *c, hwy_state *st, const int32_t *actions, float *obs, double *reward,
                  uint8_t *terminated, uint8_t *truncated, double *info_speed, uint8_t *info_crashed) {
   int N = c->num_vehicles, A = c->num_agents;
-  size_t VF = (size_t)c->obs_vehicles * c->obs_features;
+  size_t VF = c->obs_type == HWY_OBS_OCCUPANCY_GRID ? (size_t)c->obs_features * c->grid_shape[0] * c->grid_shape[1]
+                                                    : (size_t)c->obs_vehicles * c->obs_features;
   ent_t *v = (ent_t *)malloc(sizeof(ent_t) * (size_t)N);
   int acts[HWY_MAX_AGENTS];
   for (int e = 0; e < c->num_envs; e++) {
@@ -728,7 +804,7 @@ int orc_net_step(const hwy_config *c, hwy_state *st, const int32_t *actions, flo
     }
     for (int a = 0; a < A; a++) {
       const ent_t *ego = &v[c->agent_index[a]];
-      observe_agent(&r, c->agent_index[a], obs + ((size_t)e * A + a) * VF);
+      observe_any(&r, c->agent_index[a], obs + ((size_t)e * A + a) * VF);
       reward[e * A + a] = reward_of(&r, ego, acts[a]);
       if (info_speed) info_speed[e * A + a] = ego->speed;
       if (info_crashed) info_crashed[e * A + a] = (uint8_t)ego->crashed;

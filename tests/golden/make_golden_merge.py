@@ -187,6 +187,16 @@ SCENARIOS = [
          config={"observation": {"type": "Kinematics", "include_obstacles": False, "vehicles_count": 6}},
          seeds=list(range(20, 26)), steps=12, action_seed=37, frames_for=1, n_slots=6,
          action_p=[0.05, 0.2, 0.45, 0.25, 0.05]),
+    # OccupancyGridObservation on the merge network: vehicles only (no Obstacle), on-road layer over StraightLane and
+    # SineLane waypoints (observation.py:454-484); world-aligned default grid and a vehicle-aligned finer one
+    dict(name="merge_grid", cls=MergeEnv, config={"observation": {"type": "OccupancyGrid"}},
+         seeds=list(range(30, 34)), steps=10, action_seed=38, frames_for=0, n_slots=6),
+    dict(name="merge_generic_grid_aligned", cls=MergeGenericEnv,
+         config={"lanes_count": 3, "vehicles_count": 15,
+                 "observation": {"type": "OccupancyGrid", "align_to_vehicle_axes": True, "grid_size": [[-24, 48], [-12, 12]],
+                                 "grid_step": [3, 3], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "on_road"],
+                                 "features_range": {"x": [-60, 60], "y": [-20, 20], "vx": [-20, 20], "vy": [-10, 10]}}},
+         seeds=[40, 41, 42], steps=9, action_seed=39, frames_for=0, n_slots=18, action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),
     dict(name="merge_generic_v1", cls=ConnectedLaneMergeGenericEnv, config={"lanes_count": 3, "vehicles_count": 20},
          seeds=list(range(5)), steps=13, action_seed=36, frames_for=2, n_slots=23,
          action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),
@@ -245,9 +255,12 @@ def run_scenario(sc: dict) -> dict:
     out["end_position"] = np.float64(per_env[0]["end_position"])
     for k in LANE_F64 + LANE_I32:
         out["lane_" + k] = tab0[k]
-    out["obs0"] = np.stack([r["obs0"] for r in per_env]).reshape(E, A, *per_env[0]["obs0"].shape[-2:])
-    obs = np.stack([np.stack(r["obs"]) for r in per_env], axis=1)                  # [steps,E,(A,)V,F]
-    out["obs"] = obs.reshape(steps, E, A, *obs.shape[-2:])
+    # per-agent observation shape: (V, F) Kinematics or (F, W, H) OccupancyGrid; a single agent has no agent axis
+    one = np.asarray(per_env[0]["obs0"])
+    oshape = one.shape[1:] if A > 1 else one.shape
+    out["obs0"] = np.stack([r["obs0"] for r in per_env]).reshape(E, A, *oshape)
+    obs = np.stack([np.stack(r["obs"]) for r in per_env], axis=1)                  # [steps,E,(A,)...]
+    out["obs"] = obs.reshape(steps, E, A, *oshape)
     out["reward"] = np.asarray([r["reward"] for r in per_env], np.float64).T      # [steps,E]
     out["terminated"] = np.asarray([r["terminated"] for r in per_env], np.int8).T
     out["truncated"] = np.asarray([r["truncated"] for r in per_env], np.int8).T

@@ -98,6 +98,7 @@ def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
 # --------------------------------------------------------------------------- merge scenarios
 MERGE = ["merge_default", "merge_generic_l3", "merge_generic_sections", "merge_ma4", "merge_v1", "merge_generic_v1",
          "merge_no_obstacles"]
+MERGE_GRID = ["merge_grid", "merge_generic_grid_aligned"]  # per-step fixtures with the OccupancyGrid observation
 
 
 class GoldenMerge:

@@ -12,7 +12,7 @@ import pytest
 from highwayenv_amd import _abi, merge
 from oracle import oracle
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import MERGE, GoldenMerge, assert_net_state_close
+from tests.golden_util import MERGE, MERGE_GRID, GoldenMerge, assert_net_state_close
 
 
 def _sub(st, sel):
@@ -48,7 +48,7 @@ def test_teacher_forced_frames_vs_reference(backend, name):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", MERGE)
+@pytest.mark.parametrize("name", MERGE + MERGE_GRID)
 def test_free_running_episodes_vs_reference(backend, name):
     """reset state -> whole episodes: obs / reward / terminated / info / state at every step while the episode
     is live and collision-free (flags, termination and reward also on the step of the first crash).  An env leaves

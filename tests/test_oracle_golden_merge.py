@@ -10,7 +10,7 @@ import pytest
 
 from highwayenv_amd import _abi, merge
 from oracle import oracle
-from tests.golden_util import MERGE, GoldenMerge, assert_net_state_close
+from tests.golden_util import MERGE, MERGE_GRID, GoldenMerge, assert_net_state_close
 
 
 @pytest.mark.parametrize("name", MERGE)
@@ -58,7 +58,7 @@ def test_oracle_teacher_forced_frames(name):
             assert_net_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}")
 
 
-@pytest.mark.parametrize("name", MERGE)
+@pytest.mark.parametrize("name", MERGE + MERGE_GRID)
 def test_oracle_free_running_steps(name):
     """Whole episodes from the reset state, compared while the episode is live (up to and including the
     terminal step; see DESIGN.md section 4 on post-termination wrecks)."""
