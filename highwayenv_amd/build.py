@@ -37,12 +37,13 @@ def is_stale() -> bool:
 
 
 def kernel_source_hash() -> str:
-    """sha256 (first 16 hex digits) over every source the engine library is built from + the hipcc flags: the identity
-    of a kernel build.  rocprofv3 counter summaries under profiles/ record it, and bench.py only quotes counters whose
-    hash equals the running build's."""
+    """sha256 (first 16 hex digits) over every source the DEVICE code is built from (hwy_kernels.hip and the csrc headers
+    it includes) + the hipcc flags: the identity of a kernel build.  rocprofv3 counter summaries under profiles/ record it,
+    and bench.py only quotes counters whose hash equals the running build's.  (The host side of the library --
+    hwy_engine.hip, hwy_comm.hip -- is not part of it: it picks a kernel variant, whose name the summaries record too.)"""
     import hashlib
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(["hwy_kernels.hip"] + [x for x in HEADERS if not x.startswith("..")]):
         h.update(os.path.basename(f).encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())

@@ -156,7 +156,6 @@ static int validate(const hwy_config *c, std::string &why) {
     }
   } else if (c->scenario != HWY_SCENARIO_HIGHWAY) {
     if (c->scenario != HWY_SCENARIO_MERGE && c->scenario != HWY_SCENARIO_MERGE_GENERIC) BAD("unknown scenario %d", c->scenario);
-    if (c->obs_type != HWY_OBS_KINEMATICS) BAD("road-network scenarios support the Kinematics observation only");
     if (c->num_vehicles < 3 || c->num_vehicles > 64) BAD("road-network scenarios need 3..64 slots (one wavefront per environment)");
     if (c->net_lanes < 1 || c->net_lanes > HWY_MAX_LANES) BAD("net_lanes must be in [1,%d]", HWY_MAX_LANES);
     if (c->merge_lane >= c->net_lanes) BAD("merge_lane out of range");

@@ -92,6 +92,10 @@ int net_step_resident_blocks(int waves_per_eu) {
   }
 }
 hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) {  // the OccupancyGrid build (its own instantiation: hwy_net.h, net_observe<GRID>)
+    hipLaunchKernelGGL((hwy_net_step_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
+    return hipGetLastError();
+  }
   switch (waves_per_eu) {
     case 1: hipLaunchKernelGGL((hwy_net_step_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
     case 2: hipLaunchKernelGGL((hwy_net_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
@@ -101,11 +105,13 @@ hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream
   return hipGetLastError();
 }
 hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_net_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) hipLaunchKernelGGL((hwy_net_reset_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
+  else hipLaunchKernelGGL((hwy_net_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
   return hipGetLastError();
 }
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream) {
-  hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) hipLaunchKernelGGL((hwy_net_observe_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
+  else hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
   return hipGetLastError();
 }
 template <int WPE>

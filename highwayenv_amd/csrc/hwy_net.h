@@ -398,7 +398,10 @@ __device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh
 }
 
 // ---- KinematicObservation (observation.py:234-276) with obstacles (road.py:421-450), MergeEnv reward and
-//      termination (merge_env.py:40-82).  All cross-lane reads through readlane. -------------------------------------
+//      termination (merge_env.py:40-82).  All cross-lane reads through readlane.  GRID: the build for the OccupancyGrid
+//      observation -- a compile-time switch, so that the Kinematics kernels (the measured configs) carry none of the grid
+//      code in their register / scalar allocation. ---------------------------------------------------------------------
+template <bool GRID>
 __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, const Veh &me, bool write_reward) {
   const StepParams &p = np.s;
   const int i = threadIdx.x;
@@ -431,8 +434,10 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
       const double kk = wave_bcast(key, k);
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
-    if (p.obs && p.obs_type != HWY_OBS_KINEMATICS) net_observe_grid(np, sh, e, a, me, veh, ex, ey, ev, ec, es);
-    if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
+    if constexpr (GRID) {
+      if (p.obs) net_observe_grid(np, sh, e, a, me, veh, ex, ey, ev, ec, es);
+    }
+    if (!GRID && p.obs) {
       float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (present && row >= 0) {
@@ -591,7 +596,7 @@ __device__ inline void net_spawn_env(const NetParams &np, NetShared &sh, uint64_
 }
 
 // =============================================================================================================
-template <int WPE>
+template <int WPE, bool GRID = false>
 __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams np) {
   const StepParams &p = np.s;
   __shared__ NetShared sh;
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     Veh me;
     const uint32_t episode = p.st.episode[e] + 1u;
     net_spawn_env(np, sh, p.rp.base_seed + (uint64_t)e, episode, me);
-    net_observe(np, sh, e, me, false);
+    net_observe<GRID>(np, sh, e, me, false);
     store_vehicle<1>(p, e, me);
     if (i < p.A) {  // agent a == slot a
       p.reward[(size_t)e * p.A + i] = 0.0;
@@ -918,7 +923,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
   }  // frames
 
   // ---- G. observe / reward / done ------------------------------------------------------------------------------
-  if (p.full_step) net_observe(np, sh, e, me, true);
+  if (p.full_step) net_observe<GRID>(np, sh, e, me, true);
   {
     // rank hint for the next step is not used by this kernel; keep the slot index
     me.rank = i & 0xff;
@@ -927,7 +932,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
 }
 
 // Reset kernel: AbstractEnv.reset for the masked environments + first observation.
-template <int WPE>
+template <int WPE, bool GRID = false>
 __global__ void __launch_bounds__(64, WPE) hwy_net_reset_kernel(const NetParams np) {
   const StepParams &p = np.s;
   __shared__ NetShared sh;
@@ -937,7 +942,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_reset_kernel(const NetParams 
   Veh me;
   const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
   net_spawn_env(np, sh, seed, 0u, me);
-  net_observe(np, sh, e, me, false);
+  net_observe<GRID>(np, sh, e, me, false);
   store_vehicle<1>(p, e, me);
   if (i == 0) {
     p.st.time[e] = 0.0;
@@ -947,13 +952,13 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_reset_kernel(const NetParams 
 }
 
 // Observation-only kernel (hwy_observe).
-template <int WPE>
+template <int WPE, bool GRID = false>
 __global__ void __launch_bounds__(64, WPE) hwy_net_observe_kernel(const NetParams np) {
   __shared__ NetShared sh;
   net_load_table(np, sh);
   Veh me;
   load_vehicle<1>(np.s, blockIdx.x, me);
-  net_observe(np, sh, blockIdx.x, me, false);
+  net_observe<GRID>(np, sh, blockIdx.x, me, false);
 }
 
 }  // namespace hwy

@@ -111,10 +111,18 @@ void dispatch(Which which, const StepParams &p, int E) {
   if (g_cfg && g_cfg->scenario != HWY_SCENARIO_HIGHWAY) {  // same dispatch rule as hwy_engine.hip
     hwy::NetParams np;
     hwy::net_params_from_config(*g_cfg, p, np);
+    const bool grid = p.obs_type != HWY_OBS_KINEMATICS;
     switch (which) {
-      case STEP: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1>(q); }, E, 64, np); break;
-      case RESET: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_reset_kernel<1>(q); }, E, 64, np); break;
-      case OBSERVE: emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_observe_kernel<1>(q); }, E, 64, np); break;
+      // same dispatch rule as hwy_kernels.hip: the OccupancyGrid observation has its own instantiation
+      case STEP: if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1, true>(q); }, E, 64, np);
+                 else emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1>(q); }, E, 64, np);
+                 break;
+      case RESET: if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_reset_kernel<1, true>(q); }, E, 64, np);
+                  else emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_reset_kernel<1>(q); }, E, 64, np);
+                  break;
+      case OBSERVE: if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_observe_kernel<1, true>(q); }, E, 64, np);
+                    else emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_observe_kernel<1>(q); }, E, 64, np);
+                    break;
     }
     return;
   }

@@ -193,8 +193,9 @@ def test_batched_merge_generic_multi_agent_shapes_and_errors():
     env.close()
     with pytest.raises(AssertionError):  # the reference's own assert (merge_env.py:241-244)
         EmuBatchedMergeGeneric({"after_merge_length": 50}, num_envs=1)
-    with pytest.raises(NotImplementedError):
-        EmuBatchedMergeGeneric({"observation": {"type": "OccupancyGrid"}}, num_envs=1)
+    assert EmuBatchedMergeGeneric({"observation": {"type": "OccupancyGrid"}}, num_envs=1).single_observation_shape == (4, 11, 11)
+    with pytest.raises(NotImplementedError):  # a heading layer has no value for the end-of-lane Obstacle (objects.py:141-160)
+        EmuBatchedMergeGeneric({"observation": {"type": "Kinematics", "features": ["presence", "heading"]}}, num_envs=1)
 
 
 # ---- intersection-v0 (highway_env/envs/intersection_env.py) -----------------------------------------------------
