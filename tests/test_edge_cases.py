@@ -21,7 +21,7 @@ def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, com
     rng = np.random.default_rng(seed)
     live = np.ones(E, bool)
     for t in range(steps):
-        acts = (rng.integers(0, 5, size=(E, cfg.num_agents)) if actions is None else np.full((E, cfg.num_agents), actions[t % len(actions)])).astype(np.int32)
+        acts = (rng.integers(0, _abi.num_actions(cfg), size=(E, cfg.num_agents)) if actions is None else np.full((E, cfg.num_agents), actions[t % len(actions)])).astype(np.int32)
         obs, reward, term, trunc, info = eng.step(acts)
         o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
         wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)

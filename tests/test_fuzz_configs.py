@@ -23,7 +23,8 @@ def random_config(rng):
              ["x", "y", "heading", "vx"]][int(rng.integers(3))]
     obs = {"type": "Kinematics", "vehicles_count": int(rng.integers(2, 9)), "features": feats,
            "absolute": bool(rng.integers(2)), "see_behind": bool(rng.integers(2)), "normalize": bool(rng.integers(2)),
-           "clip": bool(rng.integers(2))}
+           "clip": bool(rng.integers(2)),
+           "order": "shuffled" if rng.integers(4) == 0 else "sorted"}  # (the engine's part: list-order selection)
     if rng.integers(4) == 0:  # OccupancyGrid (borders kept off the waypoint lattice, see the intersection test below)
         gfeats = [["presence", "vx", "vy", "on_road"], ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"]][int(rng.integers(2))]
         obs = {"type": "OccupancyGrid", "features": gfeats, "grid_size": [[-31.3, 28.7], [-13.3, 11.7]],
@@ -40,6 +41,11 @@ def random_config(rng):
         cfg["action"] = {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}}
     if rng.integers(3) == 0:
         tgt = {"type": "DiscreteMetaAction", "target_speeds": sorted(rng.uniform(10, 35, size=int(rng.integers(2, 6))).tolist())}
+        table = int(rng.integers(4))  # ACTIONS_ALL twice as often as the lateral-only / longitudinal-only tables
+        if table == 2:
+            tgt["longitudinal"] = False
+        elif table == 3:
+            tgt["lateral"] = False
         cfg["action"] = tgt if agents == 1 else {"type": "MultiAgentAction", "action_config": tgt}
     return cfg, fast
 
@@ -67,9 +73,15 @@ def random_merge_config(rng):
                 "simulation_frequency": int(rng.choice([5, 15])), "collision_reward": float(rng.uniform(-2, -0.1)),
                 "merging_speed_reward": float(rng.uniform(-1, -0.1)), "lane_change_reward": float(rng.uniform(-0.2, 0)),
                 "neighbour_vehicles_connected_lanes": bool(rng.integers(2))})   # merge-generic-v0 / -v1
+    kin = {"type": "Kinematics", "include_obstacles": bool(rng.integers(3)), "order": "shuffled" if rng.integers(4) == 0 else "sorted"}
+    obs = kin
+    if rng.integers(4) == 0:  # OccupancyGrid on the merge network (borders off the waypoint lattice)
+        obs = {"type": "OccupancyGrid", "grid_size": [[-31.3, 28.7], [-13.3, 11.7]], "grid_step": [float(rng.choice([2.5, 5]))] * 2,
+               "align_to_vehicle_axes": bool(rng.integers(2)), "clip": bool(rng.integers(2))}
+    cfg["observation"] = obs
     if agents > 1:
         cfg["action"] = {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}}
-        cfg["observation"] = {"type": "MultiAgentObservation", "observation_config": {"type": "Kinematics"}}
+        cfg["observation"] = {"type": "MultiAgentObservation", "observation_config": obs}
     return cfg
 
 

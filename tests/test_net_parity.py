@@ -105,7 +105,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed):
     n_term = n_crash = 0
     next_seed = 10_000_000 * seed
     for t in range(steps):
-        acts = rng.integers(0, 5, size=(E, cfg.num_agents)).astype(np.int32)
+        acts = rng.integers(0, _abi.num_actions(cfg), size=(E, cfg.num_agents)).astype(np.int32)
         obs, reward, term, trunc, info = eng.step(acts)
         o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
         what = f"step {t}"
