@@ -20,7 +20,7 @@ HWY_MAX_TARGET_SPEEDS = 8
 HWY_MAX_LANES = 16
 HWY_MAX_VEHICLES = 256
 HWY_MAX_GLANES = 24
-HWY_MAX_ROUTE = 3
+HWY_MAX_ROUTE = 11
 
 # hwy_status
 HWY_OK, HWY_ERR_INVALID_ARG, HWY_ERR_HIP, HWY_ERR_UNSUPPORTED, HWY_ERR_NO_DEVICE, HWY_ERR_ACTION = 0, -1, -2, -3, -4, -5
@@ -140,6 +140,7 @@ class HwyConfig(C.Structure):
         ("idm_comfort_acc_max", C.c_double),
         ("idm_comfort_acc_min", C.c_double),
         ("gnet", HwyGLane * HWY_MAX_GLANES),
+        ("gnet_routes", (C.c_int64 * 4) * HWY_MAX_GLANES),
         # tuning (ABI v5): 0 = the engine's own choice
         ("tune_block_kernel", C.c_int32),
         ("tune_waves_per_eu", C.c_int32),
@@ -167,7 +168,7 @@ STATE_I32 = ["lane", "target_lane", "speed_index", "flags"]
 
 class HwyState(C.Structure):
     _fields_ = ([(n, _DP) for n in STATE_F64] + [(n, _IP) for n in STATE_I32] + [("time", _DP)]
-                + [("route", _IP), ("road_steps", _IP)])  # intersection scenario only (NULL otherwise)
+                + [("route", C.POINTER(C.c_int64)), ("road_steps", _IP)])  # intersection scenario only (NULL otherwise)
 
 
 def alloc_state(num_envs: int, num_vehicles: int) -> dict:
@@ -182,7 +183,7 @@ def alloc_state_ix(num_envs: int, num_vehicles: int) -> dict:
     """Host SoA of the intersection scenario: + packed planned routes and RegulatedRoad.steps; every slot absent."""
     st = alloc_state(num_envs, num_vehicles)
     st["flags"][...] = F_ABSENT
-    st["route"] = np.zeros((num_envs, num_vehicles), np.int32)
+    st["route"] = np.zeros((num_envs, num_vehicles), np.int64)
     st["road_steps"] = np.zeros(num_envs, np.int32)
     return st
 
@@ -198,11 +199,14 @@ def state_struct(st: dict) -> HwyState:
         a = st[k]
         assert a.dtype == np.int32 and a.flags.c_contiguous, k
         setattr(s, k, a.ctypes.data_as(_IP))
-    for k in ("route", "road_steps"):  # intersection scenario
-        if k in st:
-            a = st[k]
-            assert a.dtype == np.int32 and a.flags.c_contiguous, k
-            setattr(s, k, a.ctypes.data_as(_IP))
+    if "route" in st:  # intersection scenario
+        a = st["route"]
+        assert a.dtype == np.int64 and a.flags.c_contiguous, "route"
+        s.route = a.ctypes.data_as(C.POINTER(C.c_int64))
+    if "road_steps" in st:
+        a = st["road_steps"]
+        assert a.dtype == np.int32 and a.flags.c_contiguous, "road_steps"
+        s.road_steps = a.ctypes.data_as(_IP)
     return s
 
 

@@ -33,11 +33,12 @@ struct hwy_engine {
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
-  int32_t *d_route = nullptr;       // intersection scenario: planned routes [E x pitch]
+  long long *d_route = nullptr;     // intersection scenario: planned routes [E x pitch] (64-bit route words)
   int32_t *d_road_steps = nullptr;  // intersection scenario: RegulatedRoad.steps [E]
   hwy_glane *d_gnet = nullptr;      // intersection scenario: lane table
   double *d_shadow_f64 = nullptr;   // intersection scenario, pre-warming of next episodes: second copy of the planes
-  int32_t *d_shadow_packed = nullptr, *d_shadow_route = nullptr, *d_shadow_meta = nullptr;
+  int32_t *d_shadow_packed = nullptr, *d_shadow_meta = nullptr;
+  long long *d_shadow_route = nullptr;
   unsigned long long *d_counters = nullptr;  // [HWY_CTR_COUNT] (hwy_get_counters)
   double *d_time = nullptr;
   uint8_t *d_done = nullptr;
@@ -305,16 +306,16 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   ALLOC(eng->d_f64, plane * 9 * sizeof(double));
   ALLOC(eng->d_packed, plane * sizeof(int32_t));
   if (cfg->scenario == HWY_SCENARIO_INTERSECTION) {
-    ALLOC(eng->d_route, plane * sizeof(int32_t));
+    ALLOC(eng->d_route, plane * sizeof(long long));
     ALLOC(eng->d_road_steps, E * sizeof(int32_t));
     ALLOC(eng->d_gnet, sizeof(hwy_glane) * HWY_MAX_GLANES);
-    if ((e = hipMemsetAsync(eng->d_route, 0, plane * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMemsetAsync(eng->d_route, 0, plane * sizeof(long long), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(eng->d_road_steps, 0, E * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemcpy(eng->d_gnet, cfg->gnet, sizeof(hwy_glane) * HWY_MAX_GLANES, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy");
     if (!(cfg->flags & HWY_C_HOST_TRAFFIC) && !cfg->tune_ix_no_prewarm) {  // (tuning: every auto-reset runs its warm-up inline)
       ALLOC(eng->d_shadow_f64, plane * 9 * sizeof(double));
       ALLOC(eng->d_shadow_packed, plane * sizeof(int32_t));
-      ALLOC(eng->d_shadow_route, plane * sizeof(int32_t));
+      ALLOC(eng->d_shadow_route, plane * sizeof(long long));
       ALLOC(eng->d_shadow_meta, E * 4 * sizeof(int32_t));
       if ((e = hipMemsetAsync(eng->d_shadow_f64, 0, plane * 9 * sizeof(double), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
       if ((e = hipMemsetAsync(eng->d_shadow_meta, 0xff, E * 4 * sizeof(int32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -355,7 +356,7 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   if ((e = hipMemsetAsync(eng->d_done, 0, E, eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   if ((e = hipMemsetAsync(eng->d_episode, 0, E * sizeof(uint32_t), eng->stream)) != hipSuccess) return bail(e, "hipMemset");
   // pinned staging: the largest of {state SoA, step I/O}
-  const size_t state_bytes = plane * (9 * sizeof(double) + 2 * sizeof(int32_t)) + E * (sizeof(double) + sizeof(int32_t));
+  const size_t state_bytes = plane * (9 * sizeof(double) + sizeof(int32_t) + sizeof(long long)) + E * (sizeof(double) + sizeof(int32_t));
   const size_t io_bytes = eng->out_bytes + n_act * 4 + E * 9 + 64;
   eng->h_pinned_bytes = state_bytes > io_bytes ? state_bytes : io_bytes;
   if ((e = hipHostMalloc(&eng->h_pinned, eng->h_pinned_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
@@ -440,12 +441,12 @@ extern "C" int hwy_set_state(hwy_engine *eng, const hwy_state *h) {
   double *tm = (double *)(pk + plane);
   std::memcpy(tm, h->time, sizeof(double) * E);
   if (is_ix(eng)) {
-    int32_t *rt = (int32_t *)(tm + E);
-    int32_t *rs = rt + plane;
+    long long *rt = (long long *)(tm + E);
+    int32_t *rs = (int32_t *)(rt + plane);
     for (int e = 0; e < E; ++e)
-      for (int i = 0; i < P; ++i) rt[(size_t)e * P + i] = i < N ? h->route[(size_t)e * N + i] : 0;
+      for (int i = 0; i < P; ++i) rt[(size_t)e * P + i] = i < N ? (long long)h->route[(size_t)e * N + i] : 0;
     std::memcpy(rs, h->road_steps, sizeof(int32_t) * E);
-    HWY_HIP(eng, hipMemcpyAsync(eng->d_route, rt, plane * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
+    HWY_HIP(eng, hipMemcpyAsync(eng->d_route, rt, plane * sizeof(long long), hipMemcpyHostToDevice, eng->stream));
     HWY_HIP(eng, hipMemcpyAsync(eng->d_road_steps, rs, E * sizeof(int32_t), hipMemcpyHostToDevice, eng->stream));
   }
   HWY_HIP(eng, hipMemcpyAsync(eng->d_f64, stage, plane * 9 * sizeof(double), hipMemcpyHostToDevice, eng->stream));
@@ -467,10 +468,10 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
   HWY_HIP(eng, hipMemcpyAsync(stage, eng->d_f64, plane * 9 * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(pk, eng->d_packed, plane * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
   HWY_HIP(eng, hipMemcpyAsync(tm, eng->d_time, E * sizeof(double), hipMemcpyDeviceToHost, eng->stream));
-  int32_t *rt = (int32_t *)(tm + E);
-  int32_t *rs = rt + plane;
+  long long *rt = (long long *)(tm + E);
+  int32_t *rs = (int32_t *)(rt + plane);
   if (is_ix(eng)) {
-    HWY_HIP(eng, hipMemcpyAsync(rt, eng->d_route, plane * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
+    HWY_HIP(eng, hipMemcpyAsync(rt, eng->d_route, plane * sizeof(long long), hipMemcpyDeviceToHost, eng->stream));
     HWY_HIP(eng, hipMemcpyAsync(rs, eng->d_road_steps, E * sizeof(int32_t), hipMemcpyDeviceToHost, eng->stream));
   }
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
@@ -483,7 +484,7 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
         if (h->target_lane) h->target_lane[k] = hwy::ix_word_target(w);
         if (h->speed_index) h->speed_index[k] = hwy::ix_word_speed_index(w);
         if (h->flags) h->flags[k] = hwy::ix_word_flags(w);
-        if (h->route) h->route[k] = rt[(size_t)e * P + i];
+        if (h->route) h->route[k] = (int64_t)rt[(size_t)e * P + i];
       }
     if (h->road_steps) std::memcpy(h->road_steps, rs, sizeof(int32_t) * E);
     double *flds[9] = {h->x, h->y, h->heading, h->speed, h->timer, h->target_speed, h->delta, h->impact_x, h->impact_y};

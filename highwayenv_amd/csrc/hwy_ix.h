@@ -34,14 +34,15 @@ struct IxParams {
   int32_t access_lane[4], exit_of[4];
   double spawn_probability, arrived_reward, d0, tau, a_max, b_min;
   const hwy_glane *lanes;  // device memory [n_lanes]
-  int32_t *route;          // [E][pitch]
+  long long *route;        // [E][pitch] planned routes (route word, below)
+  long long route_table[HWY_MAX_GLANES][4];  // plan_route_to("o" + k) from the END of lane L: hwy_config.gnet_routes
   int32_t *road_steps;     // [E]
   // next-episode pre-warming (auto-reset): a second copy of the vehicle planes and, per environment,
   // {episode the shadow belongs to, warm-up progress, RegulatedRoad.steps, unused}; nullptr = off
   int32_t num_envs;
   int32_t helpers;         // N <= 32: launch 64 threads per environment, lanes 32..63 help (see IxSharedT); 0 = 32 threads
   DevState shadow;
-  int32_t *shadow_route;
+  long long *shadow_route;
   int32_t *shadow_meta;    // [E][4]
   unsigned long long *counters;  // [HWY_CTR_COUNT] event counters of the engine (hwy_get_counters), nullptr = not counted
 };
@@ -54,21 +55,28 @@ __host__ __device__ inline int ix_word_lane(int32_t w) { return w & 0x1f; }
 __host__ __device__ inline int ix_word_target(int32_t w) { return (w >> 5) & 0x1f; }
 __host__ __device__ inline int ix_word_speed_index(int32_t w) { return (w >> 10) & 0x7; }
 __host__ __device__ inline int ix_word_flags(int32_t w) { return (w >> 13) & 0x7f; }
-// route word: r0 | r1 << 5 | r2 << 10 | len << 15
-__host__ __device__ inline int route_len(int32_t r) { return (r >> 15) & 0x3; }
-__host__ __device__ inline int route_at(int32_t r, int k) { return (r >> (5 * k)) & 0x1f; }
-__host__ __device__ inline int32_t route_pop(int32_t r) { return ((r >> 5) & 0x3ff) | ((route_len(r) - 1) << 15); }
-__host__ __device__ inline int32_t route_make(int r0, int r1, int r2, int len) {
-  return (r0 & 0x1f) | ((r1 & 0x1f) << 5) | ((r2 & 0x1f) << 10) | (len << 15);
+// route word (64 bits): the remaining roads of ControlledVehicle.route as gnet indices, 5 bits each, first road in the low
+// bits (up to HWY_MAX_ROUTE = 11 of them), their number in bits 56..59
+typedef long long route_t;
+__host__ __device__ inline int route_len(route_t r) { return (int)((r >> 56) & 0xf); }
+__host__ __device__ inline int route_at(route_t r, int k) { return (int)((r >> (5 * k)) & 0x1f); }
+__host__ __device__ inline route_t route_pop(route_t r) {
+  return ((r & (((route_t)1 << 55) - 1)) >> 5) | ((route_t)(route_len(r) - 1) << 56);
+}
+// [lane] + tail, where `tail` is a route word starting at the road AFTER `lane` (a row of IxParams::route_table)
+__host__ __device__ inline route_t route_prepend(int lane, route_t tail) {
+  return (route_t)(lane & 0x1f) | ((tail & (((route_t)1 << 50) - 1)) << 5) | ((route_t)(route_len(tail) + 1) << 56);
 }
 
 struct IxVeh {
   double x, y, h, v, timer, ts, delta, impx, impy;
   double ch, sh;  // cos / sin of the heading, refreshed whenever the heading changes
-  int lane, tgt, sidx, flags, route;
+  int lane, tgt, sidx, flags;
+  route_t route;
   // HBM write-back bookkeeping (ix_store_vehicle): the route word as loaded, and whether this SLOT now holds another
   // vehicle than the one it was loaded with (compaction, spawn, a state taken from the other set of planes)
-  int route0, dirty;
+  route_t route0;
+  int dirty;
 };
 
 #define HWY_IX_SAMPLES 11  // np.arange(0.25, 3, 0.25) (regulation.py:95)
@@ -373,21 +381,18 @@ __device__ inline bool ix_corner_inside(double c1x, double c1y, double a1, doubl
 
 // Vehicle ctor pieces shared by the device spawn paths: lane index, IDM timer, planned route to "o" + dest
 template <typename SH>
-__device__ inline int ix_plan_route(const IxParams &ip, const SH &sh, int lane, int dest) {
-  // plan_route_to (controller.py:71-87): [lane_index] + shortest path lane_index[1] -> "o" + dest; on this network
-  // the path from the end of an access lane is always [turn / crossing lane, exit lane]
-  const int ex = ip.exit_of[dest];
-  if (lane == ex) return route_make(lane, 0, 0, 1);
-  if (sh.to[lane] == sh.from[ex]) return route_make(lane, ex, 0, 2);
-  for (int K = 0; K < ip.n_lanes; ++K)
-    if (sh.from[K] == sh.to[lane] && sh.to[K] == sh.from[ex]) return route_make(lane, K, ex, 3);
-  return route_make(lane, 0, 0, 1);  // no path: route == [lane_index]
+__device__ inline route_t ix_plan_route(const IxParams &ip, const SH &sh, int lane, int dest) {
+  // plan_route_to (controller.py:71-87): [lane_index] + the shortest path from lane_index[1] to "o" + dest
+  // (RoadNetwork.shortest_path: breadth-first, neighbours in sorted order, road.py:159-188) -- planned once on the host for
+  // every (lane, destination) pair of the table, so any network and any route length up to HWY_MAX_ROUTE works here
+  (void)sh;
+  return route_prepend(lane, ip.route_table[lane][dest]);
 }
 
 __device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o, bool from_shadow = false) {
   const StepParams &p = ip.s;
   const DevState &st = from_shadow ? ip.shadow : ip.s.st;  // (wave-uniform choice)
-  const int32_t *route = from_shadow ? ip.shadow_route : ip.route;
+  const route_t *route = from_shadow ? ip.shadow_route : ip.route;
   const int i = threadIdx.x;
   o = IxVeh{};
   o.flags = HWY_F_ABSENT;
@@ -417,7 +422,7 @@ __device__ inline void ix_load_vehicle(const IxParams &ip, int e, IxVeh &o, bool
 __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &o, bool to_shadow = false, bool all = false) {
   const StepParams &p = ip.s;
   const DevState &st = to_shadow ? ip.shadow : ip.s.st;
-  int32_t *route = to_shadow ? ip.shadow_route : ip.route;
+  route_t *route = to_shadow ? ip.shadow_route : ip.route;
   const int i = threadIdx.x;
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
@@ -550,14 +555,15 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       constexpr int NH = SH::kNH;
       const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
       double s_me = veh ? sh.sl[me.lane][vi] : 0.0, v_me = me.v, x_me = me.x, y_me = me.y, c_me = ch, sn_me = shh;
-      int route_me = me.route, lane_me = me.lane;
+      route_t route_me = me.route;
+      int lane_me = me.lane;
       bool veh_v = veh;
       if constexpr (NH > 1) {
-        if (half == 0) { sh.xd[i] = s_me; sh.xi[i] = me.route; sh.xb[i] = me.lane | (veh ? 256 : 0); }
+        if (half == 0) { sh.xd[i] = s_me; sh.bcx[i] = __longlong_as_double(me.route); sh.xb[i] = me.lane | (veh ? 256 : 0); }
       }
       HWY_WAVE_LDS_FENCE();  // sl[][] is dead from here on: the trajectories share its storage
       if constexpr (NH > 1) {
-        s_me = sh.xd[vi]; route_me = sh.xi[vi];
+        s_me = sh.xd[vi]; route_me = __double_as_longlong(sh.bcx[vi]);  // (bcx is free until the circles below)
         lane_me = sh.xb[vi] & 255; veh_v = (sh.xb[vi] & 256) != 0;
         v_me = sh.v[vi]; x_me = sh.x[vi]; y_me = sh.y[vi]; c_me = sh.c[vi]; sn_me = sh.s[vi];  // frame snapshot (B)
       }
@@ -913,7 +919,12 @@ __device__ inline void ix_compact(IxVeh &me, bool keep) {
   int flags = keep ? me.flags : HWY_F_ABSENT;
   MOVE_D(me.x); MOVE_D(me.y); MOVE_D(me.h); MOVE_D(me.v); MOVE_D(me.timer); MOVE_D(me.ts); MOVE_D(me.delta);
   MOVE_D(me.impx); MOVE_D(me.impy); MOVE_D(me.ch); MOVE_D(me.sh);
-  MOVE_I(me.lane); MOVE_I(me.tgt); MOVE_I(me.sidx); MOVE_I(flags); MOVE_I(me.route);
+  MOVE_I(me.lane); MOVE_I(me.tgt); MOVE_I(me.sidx); MOVE_I(flags);
+  {
+    double rt = __longlong_as_double(me.route);
+    MOVE_D(rt);
+    me.route = __double_as_longlong(rt);
+  }
   me.flags = flags;
   me.dirty = 1;  // the list moved up: this slot may hold another vehicle now (write its constants back)
 #undef MOVE_I

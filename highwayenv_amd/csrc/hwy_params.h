@@ -72,6 +72,8 @@ inline void ix_params_from_config(const hwy_config &c, const StepParams &p, IP &
   ip.initial_count = c.initial_vehicle_count;
   ip.host_spawn = (c.flags & HWY_C_HOST_TRAFFIC) ? 1 : 0;
   ip.destination = c.destination;
+  for (int L = 0; L < HWY_MAX_GLANES; ++L)
+    for (int k = 0; k < 4; ++k) ip.route_table[L][k] = (long long)c.gnet_routes[L][k];
   for (int k = 0; k < 4; ++k) { ip.access_lane[k] = c.access_lane[k]; ip.exit_of[k] = c.exit_of[k]; }
   ip.spawn_probability = c.spawn_probability;
   ip.arrived_reward = c.arrived_reward;

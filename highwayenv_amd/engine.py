@@ -63,7 +63,7 @@ class Engine:
         want.update({k: (np.int32, (E, N)) for k in _abi.STATE_I32})
         want["time"] = (np.float64, (E,))
         if ix:
-            want["route"], want["road_steps"] = (np.int32, (E, N)), (np.int32, (E,))
+            want["route"], want["road_steps"] = (np.int64, (E, N)), (np.int32, (E,))
         out = {}
         for k, (dt, shape) in want.items():
             if k not in st:

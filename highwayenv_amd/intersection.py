@@ -143,6 +143,10 @@ def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
         c.access_lane[q] = lane_index_of(tab, f"o{q}", f"ir{q}")
         c.exit_of[q] = lane_index_of(tab, f"il{q}", f"o{q}")
     c.destination = int(dest[1]) if dest else -1  # -1: drawn per episode (1..3)
+    rt = route_table(tab)  # plan_route_to for every (lane, destination): BFS on the host, looked up by the kernel
+    for k in range(c.gnet_lanes):
+        for q in range(4):
+            c.gnet_routes[k][q] = int(rt[k, q])
     c.initial_vehicle_count = int(cfg["initial_vehicle_count"])
     c.spawn_probability = float(cfg["spawn_probability"])
     c.arrived_reward = float(cfg["arrived_reward"])
@@ -152,29 +156,58 @@ def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
 
 # --------------------------------------------------------------------------- routes
 def route_pack(lanes) -> int:
+    """Route word of hwy_state.route: gnet indices of the remaining roads, 5 bits each from bit 0, their number in bits 56..59."""
     lanes = list(lanes)
     assert len(lanes) <= _abi.HWY_MAX_ROUTE
-    w = len(lanes) << 15
+    w = len(lanes) << 56
     for k, l in enumerate(lanes):
         w |= (int(l) & 0x1f) << (5 * k)
     return w
 
 
 def route_unpack(w: int) -> list:
-    return [(int(w) >> (5 * k)) & 0x1f for k in range((int(w) >> 15) & 0x3)]
+    return [(int(w) >> (5 * k)) & 0x1f for k in range((int(w) >> 56) & 0xf)]
+
+
+def shortest_path(tab: dict, start: int, goal: int) -> list:
+    """RoadNetwork.shortest_path (road.py:159-188) on node ids: the first path of the breadth-first search whose frontier
+    expands the neighbours of a node in SORTED NAME order and never revisits a node of its own path; [] if there is none."""
+    out = {}
+    for k in range(len(tab["kind"])):
+        out.setdefault(int(tab["from_node"][k]), set()).add(int(tab["to_node"][k]))
+    queue = [(start, [start])]
+    while queue:
+        node, path = queue.pop(0)
+        if node not in out:  # `yield []` for a node without successors: shortest_path returns it as "no path"
+            return []
+        for nxt in sorted((n for n in out[node] if n not in path), key=lambda n: NODE_NAMES[n]):
+            if nxt == goal:
+                return path + [nxt]
+            if nxt in out:
+                queue.append((nxt, path + [nxt]))
+    return []
 
 
 def plan_route(tab: dict, lane: int, dest: int) -> list:
-    """plan_route_to("o" + dest) (controller.py:71-87): [lane_index] + the shortest path from lane_index[1]."""
-    ex = lane_index_of(tab, f"il{dest}", f"o{dest}")
-    if lane == ex:
-        return [lane]
-    if tab["to_node"][lane] == tab["from_node"][ex]:
-        return [lane, ex]
-    for k in range(len(tab["kind"])):
-        if tab["from_node"][k] == tab["to_node"][lane] and tab["to_node"][k] == tab["from_node"][ex]:
-            return [lane, k, ex]
-    return [lane]
+    """plan_route_to("o" + dest) (controller.py:71-87): [lane_index] + the roads of the shortest path from lane_index[1]
+    (one lane per road on this network: a road == its gnet index)."""
+    goal = NODE_NAMES.index(f"o{dest}")
+    path = shortest_path(tab, int(tab["to_node"][lane]), goal)
+    roads = [lane]
+    for a, b in zip(path[:-1], path[1:]):
+        hit = np.nonzero((tab["from_node"] == a) & (tab["to_node"] == b))[0]
+        roads.append(int(hit[0]))
+    return roads
+
+
+def route_table(tab: dict) -> np.ndarray:
+    """hwy_config.gnet_routes: for every lane L and destination k the route word of plan_route(L, k)[1:]."""
+    n = len(tab["kind"])
+    out = np.zeros((n, 4), np.int64)
+    for lane in range(n):
+        for k in range(4):
+            out[lane, k] = route_pack(plan_route(tab, lane, k)[1:])
+    return out
 
 
 # --------------------------------------------------------------------------- lane geometry on the host

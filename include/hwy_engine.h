@@ -46,7 +46,7 @@ extern "C" {
 #define HWY_MAX_VEHICLES 256
 #define HWY_MAX_GRID_CELLS 65536
 #define HWY_MAX_GLANES 24  /* lanes of a general (any direction / circular) road network: HWY_SCENARIO_INTERSECTION */
-#define HWY_MAX_ROUTE 3    /* remaining roads of a planned route kept per vehicle */
+#define HWY_MAX_ROUTE 11   /* remaining roads of a planned route kept per vehicle (64-bit route word, 5 bits per road) */
 
 typedef enum hwy_status {
   HWY_OK = 0,
@@ -234,6 +234,10 @@ typedef struct hwy_config {
   double idm_distance_wanted, idm_time_wanted, idm_comfort_acc_max, idm_comfort_acc_min; /* set on the vehicle class by
                                           IntersectionEnv._make_vehicles (intersection_env.py:243-247): 7, 1.5, 6, -3 */
   hwy_glane gnet[HWY_MAX_GLANES];
+  int64_t gnet_routes[HWY_MAX_GLANES][4]; /* ControlledVehicle.plan_route_to("o" + k) (controller.py:71-87) for a vehicle on lane L:
+                                          the route word (hwy_state.route encoding) of the roads AFTER L on the shortest path from
+                                          L's end node to "o" + k -- RoadNetwork.shortest_path (road.py:159-188: breadth-first,
+                                          neighbours in sorted name order), planned by the host once per network; length 0 = no path */
   /* Tuning (ABI v5; 0 everywhere = the engine's own choice).  These replace the process-global environment variables
    * earlier builds read with getenv: a knob now belongs to ONE engine and is part of its documented configuration.
    * None of them changes any result (tests/test_engine_parity.py, tests/test_ix_parity.py compare the variants). */
@@ -273,8 +277,9 @@ typedef struct hwy_state {
   int32_t *flags;                       /* HWY_F_* */
   double *time;                         /* AbstractEnv.time [E]                  abstract.py:274 */
   /* HWY_SCENARIO_INTERSECTION only (ABI v4; ignored / may be NULL otherwise): */
-  int32_t *route;                       /* ControlledVehicle.route [E*N]: r0 | r1 << 5 | r2 << 10 | len << 15, r_k = gnet
-                                           index of the k-th remaining road (controller.py:71-87, road.py:98-106) */
+  int64_t *route;                       /* ControlledVehicle.route [E*N]: r_k << 5k for k < len (r_k = gnet index of the k-th
+                                           remaining road, 5 bits each, len <= HWY_MAX_ROUTE) | len << 56
+                                           (controller.py:71-87, road.py:98-106) */
   int32_t *road_steps;                  /* RegulatedRoad.steps [E] (regulation.py:36-40) */
 } hwy_state;
 

@@ -62,12 +62,12 @@ class EmuEngine:
         self.autoreset = (0, 0, 2.0, 1.0, -1)
         if self.ix:  # next-episode pre-warming buffers (hwy_engine.hip allocates the same on the device)
             self.shadow = (np.zeros((9, self.E, self.N)), np.zeros((self.E, self.N), np.int32),
-                           np.zeros((self.E, self.N), np.int32), np.full((self.E, 4), -1, np.int32))
+                           np.zeros((self.E, self.N), np.int64), np.full((self.E, 4), -1, np.int32))
 
     def _bind_shadow(self):
         if self.ix:
             f, pk, rt, meta = self.shadow
-            lib().emu_set_shadow(_p(f, C.c_double), _p(pk, C.c_int32), _p(rt, C.c_int32), _p(meta, C.c_int32))
+            lib().emu_set_shadow(_p(f, C.c_double), _p(pk, C.c_int32), _p(rt, C.c_int64), _p(meta, C.c_int32))
         else:
             lib().emu_set_shadow(None, None, None, None)
 

@@ -70,14 +70,15 @@ const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road
 hwy_state *g_st = nullptr;          // host state of the call (intersection scenario: route / road_steps planes)
 // intersection scenario, next-episode pre-warming: shadow planes owned by the Python side (emu_set_shadow)
 double *g_shadow_f64 = nullptr;
-int32_t *g_shadow_packed = nullptr, *g_shadow_route = nullptr, *g_shadow_meta = nullptr;
+int32_t *g_shadow_packed = nullptr, *g_shadow_meta = nullptr;
+long long *g_shadow_route = nullptr;
 void dispatch(Which which, const StepParams &p, int E) {
   const int nw = (p.N + 63) / 64;
   if (g_cfg && g_cfg->scenario == HWY_SCENARIO_INTERSECTION) {
     hwy::IxParams ip;
     hwy::ix_params_from_config(*g_cfg, p, ip);
     ip.lanes = g_cfg->gnet;
-    ip.route = g_st->route;  // pitch == N in the emulation
+    ip.route = (long long *)g_st->route;  // pitch == N in the emulation
     ip.road_steps = g_st->road_steps;
     int grid = E;
     if (g_shadow_meta && !(g_cfg->flags & HWY_C_HOST_TRAFFIC)) {
@@ -225,7 +226,7 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
 
 void emu_force_block_kernel(int on) { g_force_block = on != 0; }
 
-void emu_set_shadow(double *f64, int32_t *packed, int32_t *route, int32_t *meta) {
+void emu_set_shadow(double *f64, int32_t *packed, long long *route, int32_t *meta) {
   g_shadow_f64 = f64; g_shadow_packed = packed; g_shadow_route = route; g_shadow_meta = meta;
 }
 

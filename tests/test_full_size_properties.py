@@ -315,7 +315,7 @@ def test_full_size_intersection_determinism_independence_oracle_and_invariants()
         assert (pres == (np.arange(30)[None, :] < n[:, None])).all()
         assert (((st["flags"] & _abi.F_CONTROLLED) != 0) & pres).sum(1).tolist() == [1] * E_ix
         assert ((st["lane"][pres] >= 0) & (st["lane"][pres] < cfg.gnet_lanes)).all()
-        assert (((st["route"][pres] >> 15) & 3) <= 3).all() and (n >= 1).all() and (n <= 30).all()
+        assert (((st["route"][pres] >> 56) & 0xf) <= 3).all() and (n >= 1).all() and (n <= 30).all()
         acts = rng.integers(0, 3, size=(E_ix, 1)).astype(np.int32)
         # the picked envs, one step from the big batch's own state on a host-traffic engine and on the oracle
         sub_st = {k: np.ascontiguousarray(v[pick]) for k, v in st.items()}
