@@ -36,12 +36,14 @@ from oracle import ref_stub  # noqa: E402
 
 ref_stub.install()
 
-from highway_env.envs.intersection_env import ConnectedLaneIntersectionEnv, IntersectionEnv  # noqa: E402
+from highway_env.envs.intersection_env import (ConnectedLaneIntersectionEnv, IntersectionEnv,  # noqa: E402
+                                               MultiAgentIntersectionEnv)
 from highway_env.road.lane import CircularLane, StraightLane  # noqa: E402
 from highway_env.vehicle.behavior import IDMVehicle  # noqa: E402
 from highway_env.vehicle.controller import MDPVehicle  # noqa: E402
 
-R_MAX = 4       # route entries kept per vehicle (the reference's routes here hold at most 3)
+R_MAX = 4       # route entries kept per vehicle (single-agent routes hold at most 3; multi-agent fixtures use R_MAX_MA)
+R_MAX_MA = 8    # MultiAgentIntersectionEnv: the second agent's default route o1 -> o1 loops through another arm (6 roads)
 DRAWS_MAX = 8   # np_random results logged per policy step (a spawn takes at most 6)
 
 F64_FIELDS = ["x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y"]
@@ -110,12 +112,12 @@ def lane_table(net) -> tuple:
     return tab, index, nodes
 
 
-def dump_state(env, index, nodes, n_slots, vids) -> dict:
+def dump_state(env, index, nodes, n_slots, vids, r_max=R_MAX) -> dict:
     vs = env.road.vehicles
     assert len(vs) <= n_slots and not env.road.objects
     out = {k: np.zeros(n_slots, np.float64) for k in F64_FIELDS}
     out.update({k: np.zeros(n_slots, np.int32) for k in INT_FIELDS})
-    out.update({k: np.full((n_slots, R_MAX), -1, np.int32) for k in ROUTE_FIELDS})
+    out.update({k: np.full((n_slots, r_max), -1, np.int32) for k in ROUTE_FIELDS})
     for i, v in enumerate(vs):
         out["present"][i] = 1
         out["x"][i], out["y"][i] = v.position
@@ -134,7 +136,7 @@ def dump_state(env, index, nodes, n_slots, vids) -> dict:
         out["controlled"][i] = any(v is c for c in env.controlled_vehicles)
         out["is_yielding"][i] = bool(getattr(v, "is_yielding", False))
         out["yield_timer"][i] = int(getattr(v, "yield_timer", 0))
-        assert v.route is not None and len(v.route) <= R_MAX
+        assert v.route is not None and len(v.route) <= r_max
         out["route_len"][i] = len(v.route)
         for k, (_f, _t, _i) in enumerate(v.route):
             out["route_from"][i, k], out["route_to"][i, k] = nodes[_f], nodes[_t]
@@ -163,6 +165,13 @@ SCENARIOS = [
     # config["destination"] = None: "o" + str(np_random.integers(1, 4)) per episode (intersection_env.py:295-297)
     dict(name="intersection_random_destination", config={"destination": None}, seeds=list(range(51, 59)), steps=8,
          action_seed=46, frames_for=0, n_slots=24),
+    # MultiAgentIntersectionEnv (intersection-multi-agent-v0, intersection_env.py:376-420): 2 agents, MultiAgentAction /
+    # MultiAgentObservation, the second agent's route o1 -> o1 (6 roads); and 3 agents with random destinations
+    dict(name="intersection_multi_agent", cls="MultiAgentIntersectionEnv", config={}, seeds=list(range(61, 67)), steps=10,
+         action_seed=47, frames_for=2, n_slots=24),
+    dict(name="intersection_multi_agent3", cls="MultiAgentIntersectionEnv",
+         config={"controlled_vehicles": 3, "destination": None, "initial_vehicle_count": 8}, seeds=list(range(71, 75)),
+         steps=9, action_seed=48, frames_for=0, n_slots=24),
     # intersection-v2: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
     dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
          config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},
@@ -173,12 +182,17 @@ SCENARIOS = [
 def run_scenario(sc: dict) -> dict:
     seeds, steps, n_slots, frames_for = sc["seeds"], sc["steps"], sc["n_slots"], sc["frames_for"]
     E = len(seeds)
+    cls = {"ConnectedLaneIntersectionEnv": ConnectedLaneIntersectionEnv, "MultiAgentIntersectionEnv": MultiAgentIntersectionEnv}.get(
+        sc.get("cls"), IntersectionEnv)
+    multi = cls is MultiAgentIntersectionEnv
+    A = int(dict(cls.default_config(), **sc["config"])["controlled_vehicles"])
+    r_max = R_MAX_MA if multi else R_MAX
     rng = np.random.default_rng(sc["action_seed"])
-    actions = rng.integers(0, 3, size=(steps, E, 1)).astype(np.int32)
+    actions = rng.integers(0, 3, size=(steps, E, A)).astype(np.int32)
     out: dict = {"seeds": np.asarray(seeds, np.int64), "actions": actions}
     per_env, tab0 = [], None
     for e, seed in enumerate(seeds):
-        env = (ConnectedLaneIntersectionEnv if sc.get("cls") == "ConnectedLaneIntersectionEnv" else IntersectionEnv)(dict(sc["config"]))
+        env = cls(dict(sc["config"]))
         obs0, _ = env.reset(seed=int(seed))
         tab, index, nodes = lane_table(env.road.network)
         tab0 = tab if tab0 is None else tab0
@@ -187,42 +201,47 @@ def run_scenario(sc: dict) -> dict:
         proxy = LoggingRandom(env.np_random)
         env.np_random = proxy
         env.road.np_random = proxy
-        rec = {"obs0": np.asarray(obs0), "init": dump_state(env, index, nodes, n_slots, vids),
+        rec = {"obs0": np.asarray(obs0), "init": dump_state(env, index, nodes, n_slots, vids, r_max),
                "road_steps0": env.road.steps, "obs": [], "reward": [], "terminated": [], "truncated": [], "speed": [],
-               "crashed": [], "step_state": [], "next_state": [], "frames": [], "draws": [], "n_draws": []}
+               "crashed": [], "step_state": [], "next_state": [], "frames": [], "draws": [], "n_draws": [],
+               "agents_rewards": [], "agents_terminated": []}
         if e < frames_for:
             road = env.road
             orig_step = road.step
 
             def step_and_dump(dt, _orig=orig_step, _env=env, _rec=rec, _index=index, _nodes=nodes, _vids=vids):
                 _orig(dt)
-                _rec["frames"].append(dump_state(_env, _index, _nodes, n_slots, _vids))
+                _rec["frames"].append(dump_state(_env, _index, _nodes, n_slots, _vids, r_max))
 
             road.step = step_and_dump
         orig_clear = env._clear_vehicles
 
         def clear_and_dump(_orig=orig_clear, _env=env, _rec=rec, _index=index, _nodes=nodes, _vids=vids):
-            _rec["step_state"].append(dump_state(_env, _index, _nodes, n_slots, _vids))
+            _rec["step_state"].append(dump_state(_env, _index, _nodes, n_slots, _vids, r_max))
             _orig()
 
         env._clear_vehicles = clear_and_dump
         for t in range(steps):
             proxy.log = []
-            o, r, te, tr, info = env.step(int(actions[t, e, 0]))
+            o, r, te, tr, info = env.step(tuple(int(a) for a in actions[t, e]) if multi else int(actions[t, e, 0]))
+            rec["agents_rewards"].append(np.asarray(info["agents_rewards"], np.float64))
+            rec["agents_terminated"].append(np.asarray(info["agents_terminated"], np.int8))
             rec["obs"].append(np.asarray(o))
             rec["reward"].append(r)
             rec["terminated"].append(te)
             rec["truncated"].append(tr)
             rec["speed"].append(info["speed"])
             rec["crashed"].append(info["crashed"])
-            rec["next_state"].append(dump_state(env, index, nodes, n_slots, vids))
+            rec["next_state"].append(dump_state(env, index, nodes, n_slots, vids, r_max))
             assert len(proxy.log) <= DRAWS_MAX
             rec["n_draws"].append(len(proxy.log))
             rec["draws"].append(proxy.log + [0.0] * (DRAWS_MAX - len(proxy.log)))
         rec["T"], rec["cfg"], rec["nodes"] = T, dict(env.config), nodes
         per_env.append(rec)
     cfg = per_env[0]["cfg"]
-    out["meta"] = np.asarray([E, n_slots, per_env[0]["T"], steps, frames_for, 1, R_MAX], np.int64)
+    out["meta"] = np.asarray([E, n_slots, per_env[0]["T"], steps, frames_for, A, r_max], np.int64)
+    out["agents_rewards"] = np.stack([np.stack(r["agents_rewards"]) for r in per_env], axis=1)        # [steps,E,A]
+    out["agents_terminated"] = np.stack([np.stack(r["agents_terminated"]) for r in per_env], axis=1)  # [steps,E,A]
     out["cfg_json"] = np.asarray(json.dumps({k: v for k, v in cfg.items()
                                              if isinstance(v, (int, float, str, bool, list, dict, type(None)))}))
     for k in LANE_F64 + LANE_I32:
