@@ -42,7 +42,8 @@
 #define LANE_CHANGE_DELAY 1.0
 #define LANE_VEHICLE_LENGTH 5.0
 #define IX_MAX_LANES 32
-#define IX_MAX_ROUTE 4
+#define IX_MAX_ROUTE 8 /* the multi-agent default sends its second car round another arm: 6 roads */
+#define IX_MAX_AGENTS 4
 #define IX_MAX_FEATURES 8
 
 enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_ON_ROAD = 13 };
@@ -73,6 +74,7 @@ typedef struct {
   int32_t outer_node[4];  /* node id of "o" + k */
   int32_t obs_type, grid_align, grid_shape[2]; /* obs_type 1: OccupancyGridObservation (observation.py:279-499) */
   double grid_min[2], grid_step[2];
+  int32_t num_agents, pad_; /* controlled_vehicles: MultiAgentIntersectionEnv (intersection_env.py:348-399) */
   ix_lane lanes[IX_MAX_LANES];
 } ix_config;
 
@@ -869,11 +871,14 @@ static void store_env(const ix_config *c, ix_state *st, int e, const veh_t *v, i
     }
   }
 }
-static int ego_index(const road_t *r) {
+/* env.controlled_vehicles[a]: the controlled vehicles keep their relative order in Road.vehicles (they are appended in
+ * that order, intersection_env.py:310-311, and every later filter of the list is stable) */
+static int agent_index(const road_t *r, int a) {
   for (int i = 0; i < r->n; i++)
-    if (r->v[i].controlled) return i;
+    if (r->v[i].controlled && a-- == 0) return i;
   return -1;
 }
+static int n_agents(const ix_config *c) { return c->num_agents > 0 ? c->num_agents : 1; }
 
 size_t orc_ix_config_size(void) { return sizeof(ix_config); }
 
@@ -884,10 +889,12 @@ int orc_ix_frames(const ix_config *c, ix_state *st, const int32_t *actions, int3
     road_t r = {c, buf, 0, st->road_steps[e]};
     r.n = load_env(c, st, e, buf);
     for (int f = 0; f < n_frames; f++) {
-      if (f == 0 && actions) {
-        int ego = ego_index(&r);
-        if (actions[e] < 0 || actions[e] > 2) { free(buf); return -6; }
-        if (ego >= 0) mdp_act(c, &r.v[ego], actions[e]); /* action_type.act(action), action.py:259-260 */
+      if (f == 0 && actions) { /* MultiAgentAction.act: one action per controlled vehicle, in order (action.py:352-355) */
+        for (int a = 0; a < n_agents(c); a++) {
+          int act = actions[e * n_agents(c) + a], ego = agent_index(&r, a);
+          if (act < 0 || act > 2) { free(buf); return -6; }
+          if (ego >= 0) mdp_act(c, &r.v[ego], act); /* action_type.act(action), action.py:259-260 */
+        }
       }
       road_act(&r);
       road_step(&r, c->dt);
@@ -923,8 +930,10 @@ int orc_ix_observe(const ix_config *c, const ix_state *st, float *obs) {
   for (int e = 0; e < c->num_envs; e++) {
     road_t r = {c, buf, 0, st->road_steps[e]};
     r.n = load_env(c, st, e, buf);
-    int ego = ego_index(&r);
-    if (ego >= 0) observe_agent(&r, ego, obs + e * per);
+    for (int a = 0; a < n_agents(c); a++) { /* MultiAgentObservation.observe (observation.py:733-734) */
+      int ego = agent_index(&r, a);
+      if (ego >= 0) observe_agent(&r, ego, obs + ((size_t)e * n_agents(c) + a) * per);
+    }
   }
   free(buf);
   return 0;
@@ -941,15 +950,24 @@ int orc_ix_step(const ix_config *c, ix_state *st, const int32_t *actions, float 
     road_t r = {c, buf, 0, st->road_steps[e]};
     r.n = load_env(c, st, e, buf);
     st->time[e] += c->policy_dt;
-    int ego = ego_index(&r);
-    if (ego < 0) { free(buf); return -7; }
-    const veh_t *v = &r.v[ego];
-    observe_agent(&r, ego, obs + e * per);
-    reward[e] = agent_reward(c, v) / 1; /* one controlled vehicle: the mean over agents is the agent's reward */
-    terminated[e] = v->crashed || has_arrived(c, v, 25) || (c->offroad_terminal && !on_road(c, v));
+    /* reward[e][a] = _agent_reward (the env's scalar is their mean, :62-66); info_crashed[e][a] bit 0 = crashed, bit 1 =
+     * has_arrived (agents_terminated = either, :119-121); terminated = any crashed or all arrived or the FIRST one off
+     * the road (:107-112) */
+    int A = n_agents(c), any_crashed = 0, all_arrived = 1;
+    for (int a = 0; a < A; a++) {
+      int ego = agent_index(&r, a);
+      if (ego < 0) { free(buf); return -7; }
+      const veh_t *v = &r.v[ego];
+      observe_agent(&r, ego, obs + ((size_t)e * A + a) * per);
+      reward[e * A + a] = agent_reward(c, v);
+      int arrived = has_arrived(c, v, 25);
+      any_crashed |= v->crashed;
+      all_arrived &= arrived;
+      if (info_speed) info_speed[e * A + a] = v->speed;
+      if (info_crashed) info_crashed[e * A + a] = (uint8_t)((v->crashed ? 1 : 0) | (arrived ? 2 : 0));
+    }
+    terminated[e] = any_crashed || all_arrived || (c->offroad_terminal && !on_road(c, &r.v[agent_index(&r, 0)]));
     truncated[e] = st->time[e] >= c->duration;
-    if (info_speed) info_speed[e] = v->speed;
-    if (info_crashed) info_crashed[e] = (uint8_t)v->crashed;
   }
   free(buf);
   return 0;

@@ -164,6 +164,9 @@ def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
 
 INTERSECTION = ["intersection_default", "intersection_dense", "intersection_v2"]   # per-frame fixtures (Kinematics observation)
 INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned"]  # per-step fixtures, OccupancyGrid observation
+# MultiAgentIntersectionEnv (2 agents with per-frame states; 3 agents with random destinations, per-step states only)
+INTERSECTION_MA = ["intersection_multi_agent", "intersection_multi_agent3"]
+INTERSECTION_MA_FRAMES = ["intersection_multi_agent"]
 
 
 class GoldenIntersection:
@@ -178,7 +181,7 @@ class GoldenIntersection:
         self.z = z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         self.E, self.N, self.T, self.steps, self.frames_for, self.A, self.R = (int(v) for v in z["meta"])
         self.config = json.loads(str(z["cfg_json"]))
-        self.actions = z["actions"]  # [steps, E, 1]
+        self.actions = z["actions"]  # [steps, E, A]
         self.lane_tab = {k: z["lane_" + k] for k in oracle_ix.LANE_F64 + oracle_ix.LANE_I32}
 
     def ix_config(self, num_envs=None):

@@ -8,14 +8,15 @@ Tolerances as in test_oracle_golden.py: f64 with glibc libm vs numpy's libm; fla
 import numpy as np
 import pytest
 
-from tests.golden_util import INTERSECTION, INTERSECTION_GRID, GoldenIntersection, assert_ix_state_close
+from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_MA, INTERSECTION_MA_FRAMES, GoldenIntersection,
+                               assert_ix_state_close)
 
 
 def _sub(st, sel):
     return {k: np.ascontiguousarray(v[sel]) for k, v in st.items()}
 
 
-@pytest.mark.parametrize("name", INTERSECTION)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES)
 def test_oracle_teacher_forced_frames(name):
     """Every single frame (meta-action on the first one, Road.act, RegulatedRoad.step incl. the regulation every
     7th frame), started from the reference's own state."""
@@ -34,7 +35,7 @@ def test_oracle_teacher_forced_frames(name):
             else:
                 st = g.state("frame", k - 1)
             st["road_steps"][...] = steps0 + k
-            acts = g.actions[step, :Ef, 0] if fr == 0 else None
+            acts = g.actions[step, :Ef] if fr == 0 else None
             ix.frames(cfg, st, acts, 1)
             want = g.state("frame", k)
             assert_ix_state_close(st, want, atol=1e-10, what=f"{name} step {step} frame {fr}")
@@ -42,7 +43,7 @@ def test_oracle_teacher_forced_frames(name):
     assert n_yield > 0  # the fixtures do exercise the regulation
 
 
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA)
 def test_oracle_steps_observation_reward_and_clear_spawn(name):
     """Whole policy steps from the reference's state at the start of each step: state before clear/spawn, obs, reward,
     terminated / truncated, info; then _clear_vehicles + _spawn_vehicle replayed on the recorded draws."""
@@ -57,7 +58,7 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
         st = g.state("init") if t == 0 else g.state("next", t - 1)
         st["road_steps"][...] = steps0 + t * g.T
         st["time"][...] = float(t)
-        obs, reward, term, trunc, info = ix.step(cfg, st, g.actions[t, :, 0])
+        obs, reward, term, trunc, info = ix.step(cfg, st, g.actions[t])
         want = g.state("step", t)
         what = f"{name} step {t}"
         wreck = ((want["present"] != 0) & ((want["crashed"] != 0) | (want["has_impact"] != 0))).any(1)
@@ -69,6 +70,9 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
         np.testing.assert_allclose(obs[clean], g.z["obs"][t][clean], rtol=0, atol=1e-6, err_msg=what)
         np.testing.assert_allclose(reward[clean], g.z["reward"][t][clean], rtol=0, atol=1e-9, err_msg=what)
         np.testing.assert_allclose(info["speed"][clean], g.z["info_speed"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+        if "agents_rewards" in g.z:  # MultiAgentIntersectionEnv's info (intersection_env.py:114-122)
+            np.testing.assert_array_equal(info["agents_terminated"][live], g.z["agents_terminated"][t].astype(bool)[live], err_msg=what)
+            np.testing.assert_allclose(info["agents_rewards"][clean], g.z["agents_rewards"][t][clean], rtol=0, atol=1e-9, err_msg=what)
         # clear + spawn from the reference's own pre-clear state
         st2 = g.state("step", t)
         used = ix.clear_spawn(cfg, st2, g.z["draws"][t], g.z["n_draws"][t])
@@ -85,7 +89,7 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
     assert n_spawned > 0 and (n_cleared > 0 or name != "intersection_dense")
 
 
-@pytest.mark.parametrize("name", INTERSECTION)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA)
 def test_oracle_free_running_episodes(name):
     """reset state -> whole episodes on the oracle's own state (steps, clear, spawn on the recorded draws), compared
     while the episode is live, no wreck is on the road and no vehicle has (nearly) stopped:
@@ -100,7 +104,7 @@ def test_oracle_free_running_episodes(name):
     live = np.ones(g.E, bool)
     compared = 0
     for t in range(g.steps):
-        obs, reward, term, trunc, info = ix.step(cfg, st, g.actions[t, :, 0])
+        obs, reward, term, trunc, info = ix.step(cfg, st, g.actions[t])
         want = g.state("step", t)
         what = f"{name} step {t}"
         wreck = ((want["present"] != 0) & ((want["crashed"] != 0) | (want["has_impact"] != 0))).any(1)
@@ -139,7 +143,7 @@ def test_connected_lanes_flag_is_load_bearing():
             else:
                 st = g.state("frame", k - 1)
             st["road_steps"][...] = steps0 + k
-            g.ix.frames(cfg, st, g.actions[step, :Ef, 0] if fr == 0 else None, 1)
+            g.ix.frames(cfg, st, g.actions[step, :Ef] if fr == 0 else None, 1)
             want = g.state("frame", k)
             pres = want["present"] != 0
             worst = max(worst, float(np.abs(st["speed"] - want["speed"])[pres].max()))
