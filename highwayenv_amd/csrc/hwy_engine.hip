@@ -140,7 +140,7 @@ static int validate(const hwy_config *c, std::string &why) {
   if (!(c->dt > 0) || !(c->policy_dt > 0)) BAD("dt and policy_dt must be positive");
   if (!(c->lane_width > 0) || !(c->road_length > 0)) BAD("lane_width and road_length must be positive");
   if (c->scenario == HWY_SCENARIO_INTERSECTION) {
-    if (c->num_agents != 1) BAD("the intersection scenario has one controlled vehicle");
+    if (c->num_agents > 4) BAD("the intersection scenario holds 1..4 controlled vehicles (one per access road)");
     if (c->num_vehicles < 4 || c->num_vehicles > 64) BAD("the intersection scenario needs 4..64 slots (one wavefront per environment)");
     if (c->gnet_lanes < 1 || c->gnet_lanes > HWY_MAX_GLANES) BAD("gnet_lanes must be in [1,%d]", HWY_MAX_GLANES);
     if (c->destination < -1 || c->destination > 3) BAD("destination must be the k of \"o\" + k, 0..3, or -1 for a random one");

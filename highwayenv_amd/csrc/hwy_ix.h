@@ -457,8 +457,11 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     const bool controlled = present && (me.flags & HWY_F_CONTROLLED);
     const u64 pm = __ballot(present);
     // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315): SLOWER / IDLE / FASTER ------
+    // MultiAgentAction.act (action.py:352-355): agent a == the a-th controlled vehicle of the list
+    const u64 ctl_m = (fr == 0 && actions) ? __ballot(controlled) : 0;
     if (fr == 0 && actions && controlled) {
-      const int act = actions[e];
+      const int agent = __popcll(ctl_m & (((u64)1 << i) - 1));
+      const int act = agent < p.A ? actions[(size_t)e * p.A + agent] : 1;
       if (act == 0 || act == 2) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
         int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == 2 ? 1 : -1);
@@ -737,14 +740,14 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
 //      the waypoints of EVERY lane of the network (fill_road_layer_by_lanes, :454-484: straight lanes of any direction
 //      and circular arcs).  sh.brho doubles as the per-lane origin table. ------------------------------------------------
 template <typename SH>
-__device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, const IxVeh &me, bool present, int ia) {
+__device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a, const IxVeh &me, bool present, int ia) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x, NT = (int)blockDim.x;
   const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
   const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
   const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
-  int32_t *own = p.grid_ws + (size_t)e * 2 * (size_t)WH, *road = own + WH;
-  float *out = p.obs + (size_t)e * (size_t)F * WH;
+  int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
+  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
   for (int t = i; t < WH; t += NT) {
     grid_ws_store(own + t, 0x7fffffff);
     grid_ws_store(road + t, 0);
@@ -823,32 +826,36 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
-  const u64 egos = __ballot(present && (me.flags & HWY_F_CONTROLLED));
+  const bool controlled = present && (me.flags & HWY_F_CONTROLLED);
+  const u64 egos = __ballot(controlled);
   if (egos == 0) return;
-  const int ia = ctz64(egos);
-  if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, me, present, ia);
   const int V = p.V, F = p.F;
-  const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
-  const double ech = wave_bcast(me.ch, ia), esh = wave_bcast(me.sh, ia);  // (cross-lane reads stay in uniform control flow)
-  const int elane = wave_bcast_i(me.lane, ia);
-  const double dxe = me.x - ex, dye = me.y - ey;
-  // observer.lane_distance_to(me): both projected on the observer's lane (wave-uniform lane: no divergence)
-  double s_mine, lat_unused;
-  ix_local(sh, elane, me.x, me.y, &s_mine, &lat_unused);
-  const double d_lane = s_mine - wave_bcast(s_mine, ia);
-  const bool elig = present && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
-                    ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
-  const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();  // (sort=False: list order)
-  const int n_elig = __popcll(__ballot(elig));
-  const int mrows = n_elig < V - 1 ? n_elig : V - 1;
-  int pos = 0;  // stable sort position (ties keep list order)
-  for (u64 em = __ballot(elig); em; em &= em - 1) {
-    const int k = ctz64(em);
-    const double kk = wave_bcast(key, k);
-    pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
-  }
-  if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
-    float *out = p.obs + (size_t)e * (size_t)(V * F);
+  // MultiAgentObservation.observe (observation.py:733-734): agent a == the a-th controlled vehicle of the list
+  int a = 0;
+  for (u64 am = egos; am && a < p.A; am &= am - 1, ++a) {
+    const int ia = ctz64(am);
+    if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, a, me, present, ia);
+    if (!(p.obs && p.obs_type == HWY_OBS_KINEMATICS)) continue;
+    const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
+    const double ech = wave_bcast(me.ch, ia), esh = wave_bcast(me.sh, ia);  // (cross-lane reads stay in uniform control flow)
+    const int elane = wave_bcast_i(me.lane, ia);
+    const double dxe = me.x - ex, dye = me.y - ey;
+    // observer.lane_distance_to(me): both projected on the observer's lane (wave-uniform lane: no divergence)
+    double s_mine, lat_unused;
+    ix_local(sh, elane, me.x, me.y, &s_mine, &lat_unused);
+    const double d_lane = s_mine - wave_bcast(s_mine, ia);
+    const bool elig = present && i != ia && (sqrt(dxe * dxe + dye * dye) < p.perception) &&
+                      ((p.flags & HWY_C_OBS_SEE_BEHIND) || (-2 * HWY_VEH_LENGTH < d_lane));
+    const double key = elig ? ((p.flags & HWY_C_OBS_UNSORTED) ? 0.0 : fabs(d_lane)) : __builtin_inf();  // (sort=False: list order)
+    const int n_elig = __popcll(__ballot(elig));
+    const int mrows = n_elig < V - 1 ? n_elig : V - 1;
+    int pos = 0;  // stable sort position (ties keep list order)
+    for (u64 em = __ballot(elig); em; em &= em - 1) {
+      const int k = ctz64(em);
+      const double kk = wave_bcast(key, k);
+      pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+    }
+    float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
     const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
     if (present && row >= 0) {
       const double ch = me.ch, shh = me.sh;
@@ -876,14 +883,23 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
     for (int t = i; t < V * F; t += (int)blockDim.x)
       if (t / F > mrows) out[t] = 0.0f;
   }
-  if (write_reward && i == ia) {
-    const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
+  if (!write_reward) return;
+  // every controlled vehicle rates itself (_agent_reward, intersection_env.py:79-105); the episode ends when ANY of them
+  // has crashed, ALL have arrived, or the FIRST one has left the road (:107-112)
+  const int agent = __popcll(egos & (((u64)1 << i) - 1));
+  const bool rated = controlled && agent < p.A;
+  const bool crashed = rated && (me.flags & HWY_F_CRASHED);
+  bool arrived = false, on_road = false;
+  if (rated) {
     double s, lat;
     ix_local(sh, me.lane, me.x, me.y, &s, &lat);
-    const bool arrived = sh.exitl[me.lane] && s >= 25.0;  // has_arrived (intersection_env.py:340-345)
-    const bool on_road = fabs(lat) <= sh.wid[me.lane] / 2 + 0.0 && -5.0 <= s && s < sh.len[me.lane] + 5.0;
+    arrived = sh.exitl[me.lane] && s >= 25.0;  // has_arrived (intersection_env.py:340-345)
+    on_road = fabs(lat) <= sh.wid[me.lane] / 2 + 0.0 && -5.0 <= s && s < sh.len[me.lane] + 5.0;
+  }
+  const u64 rated_m = __ballot(rated), crashed_m = __ballot(crashed), arrived_m = __ballot(arrived);
+  if (rated) {
     const double scaled_speed = lmap(me.v, p.rs0, p.rs1, 0.0, 1.0);
-    double reward = 0.0;  // _agent_reward (intersection_env.py:79-105)
+    double reward = 0.0;
     reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
     reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
     reward = reward + ip.arrived_reward * (arrived ? 1.0 : 0.0);
@@ -891,16 +907,20 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
     reward = arrived ? ip.arrived_reward : reward;
     reward *= (on_road ? 1.0 : 0.0);
     if (p.flags & HWY_C_NORMALIZE_REWARD) reward = lmap(reward, p.collision_reward, ip.arrived_reward, 0.0, 1.0);
-    p.reward[e] = reward;
-    if (p.info_speed) p.info_speed[e] = me.v;
-    if (p.info_crashed) p.info_crashed[e] = crashed ? 1 : 0;
-    const bool term = crashed || arrived || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
-    const double t = p.st.time[e] + p.policy_dt;
-    const bool trunc = t >= p.duration;
-    p.st.time[e] = t;
-    p.terminated[e] = term ? 1 : 0;
-    p.truncated[e] = trunc ? 1 : 0;
-    if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+    const size_t o = (size_t)e * p.A + agent;
+    p.reward[o] = reward;
+    if (p.info_speed) p.info_speed[o] = me.v;
+    // bit 0: vehicle.crashed; bit 1: has_arrived(vehicle) -- agents_terminated is either (:119-121)
+    if (p.info_crashed) p.info_crashed[o] = (crashed ? 1 : 0) | (arrived ? 2 : 0);
+    if (agent == 0) {
+      const bool term = crashed_m != 0 || arrived_m == rated_m || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
+      const double t = p.st.time[e] + p.policy_dt;
+      const bool trunc = t >= p.duration;
+      p.st.time[e] = t;
+      p.terminated[e] = term ? 1 : 0;
+      p.truncated[e] = trunc ? 1 : 0;
+      if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
+    }
   }
 }
 
@@ -1054,38 +1074,41 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
     philox_uniform2(seed, 500u, episode, 3u, &u6, &u7);
     ix_spawn(ip, sh, me, 60.0, 0.1, 0.0, 1.0, true, 0.0, u1, u2, u3, u4, u5, u6, u7);
   }
-  // the ego on ("o0", "ir0", 0) at 60 + 5 * normal(1.0), speed = speed_limit, route to config["destination"]
-  double u0, u1;
-  philox_uniform2(seed, 501u, episode, 0u, &u0, &u1);
-  // destination = config["destination"] or "o" + str(np_random.integers(1, 4)) (:295-297): uniform over {1, 2, 3}
-  int destination = ip.destination;
-  if (destination < 0) {
-    double ud, unused;
-    philox_uniform2(seed, 501u, episode, 1u, &ud, &unused);
-    const int k = (int)(ud * 3);
-    destination = 1 + (k > 2 ? 2 : k);
-  }
-  const int access = ip.access_lane[0];
-  double ex, ey;
-  ix_position(sh, access, 60.0 + 5.0 * (1.0 + ix_normal(u0, u1)), &ex, &ey);
-  const bool present = !(me.flags & HWY_F_ABSENT);
-  const double dx = me.x - ex, dy = me.y - ey;
-  const bool keep = present && !(sqrt(dx * dx + dy * dy) < 20);  // "prevent early collisions" (:283-290)
-  ix_compact(me, keep);
-  const int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
-  const double eh = ix_heading_at(sh, access, 60.0);
-  const int best = ix_closest_lane_uniform(ip, sh, ex, ey, eh);
-  if (i == slot && slot < p.N) {
-    me = IxVeh{};
-    me.dirty = 1;
-    me.x = ex; me.y = ey; me.h = eh; me.v = sh.lim[access];
-    me.lane = me.tgt = best;
-    me.route = ix_plan_route(ip, sh, best, destination);
-    const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
-    me.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
-    me.ts = p.target_speeds[me.sidx];
-    me.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
-    sincos_bounded(me.h, &me.sh, &me.ch);
+  // the controlled vehicles (:292-318): number k on ("o" + k % 4, "ir" + k % 4, 0) at 60 + 5 * normal(1.0), speed =
+  // speed_limit, route to config["destination"] or to "o" + integers(1, 4); after each one the OTHER vehicles within
+  // 20 m of it leave ("prevent early collisions", :313-318: controlled vehicles stay)
+  for (int k = 0; k < p.A; ++k) {
+    double u0, u1;
+    philox_uniform2(seed, 501u + (uint32_t)k, episode, 0u, &u0, &u1);
+    int destination = ip.destination;
+    if (destination < 0) {  // uniform over {1, 2, 3}
+      double ud, unused;
+      philox_uniform2(seed, 501u + (uint32_t)k, episode, 1u, &ud, &unused);
+      const int d = (int)(ud * 3);
+      destination = 1 + (d > 2 ? 2 : d);
+    }
+    const int access = ip.access_lane[k & 3];
+    double ex, ey;
+    ix_position(sh, access, 60.0 + 5.0 * (1.0 + ix_normal(u0, u1)), &ex, &ey);
+    const bool present = !(me.flags & HWY_F_ABSENT);
+    const double dx = me.x - ex, dy = me.y - ey;
+    const bool keep = present && ((me.flags & HWY_F_CONTROLLED) || !(sqrt(dx * dx + dy * dy) < 20));
+    ix_compact(me, keep);
+    const int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
+    const double eh = ix_heading_at(sh, access, 60.0);
+    const int best = ix_closest_lane_uniform(ip, sh, ex, ey, eh);
+    if (i == slot && slot < p.N) {
+      me = IxVeh{};
+      me.dirty = 1;
+      me.x = ex; me.y = ey; me.h = eh; me.v = sh.lim[access];
+      me.lane = me.tgt = best;
+      me.route = ix_plan_route(ip, sh, best, destination);
+      const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
+      me.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
+      me.ts = p.target_speeds[me.sidx];
+      me.flags = HWY_F_CONTROLLED | HWY_F_CHECK_COLLISIONS;
+      sincos_bounded(me.h, &me.sh, &me.ch);
+    }
   }
 }
 template <typename SH>
@@ -1180,10 +1203,12 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
   ix_store_vehicle(ip, e, me, false, role == RESPAWN);  // (a re-spawn moves the episode from the shadow planes to these)
   if (role == RESPAWN) {  // the step after terminated | truncated re-spawned the environment
     __threadfence();  // the shadow has been read before `done` is cleared (the pre-warming block starts over once it sees that)
+    if (i < p.A) {
+      p.reward[(size_t)e * p.A + i] = 0.0;
+      if (p.info_speed) p.info_speed[(size_t)e * p.A + i] = sh.lim[ip.access_lane[i & 3]];
+      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + i] = 0;
+    }
     if (i == 0) {
-      p.reward[e] = 0.0;
-      if (p.info_speed) p.info_speed[e] = sh.lim[ip.access_lane[0]];
-      if (p.info_crashed) p.info_crashed[e] = 0;
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
       p.st.episode[e] = next_episode;

@@ -96,7 +96,9 @@ class Engine:
         crashed = np.empty((E, A), np.uint8)
         self._check(self._lib.hwy_step(self._h, _ptr(acts), _ptr(obs), _ptr(reward), _ptr(term), _ptr(trunc),
                                        _ptr(speed), _ptr(crashed)))
-        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+        # info_crashed: bit 0 = vehicle.crashed; the intersection scenario adds bit 1 = has_arrived(vehicle) (hwy_engine.h)
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": (crashed & 1).astype(bool),
+                                                                    "arrived": (crashed & 2).astype(bool)}
 
     def step_device(self, d_actions: int, d_obs: int, d_reward: int, d_terminated: int, d_truncated: int,
                     d_info_speed: int = 0, d_info_crashed: int = 0):

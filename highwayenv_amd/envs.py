@@ -216,6 +216,7 @@ class BatchedHighwayEnv:
         self.time += 1 / self.config["policy_frequency"]
         self.steps += self._hcfg.frames_per_step
         out_info = {"speed": info["speed"][:, 0], "crashed": info["crashed"][:, 0], "action": acts if A > 1 else acts[:, 0]}
+        self._agents_step = (reward, info)  # per-agent [E, A] results of this step (scenario subclasses build their info from them)
         if A > 1:
             out_info["agents_rewards"] = reward
             out_info["agents_speed"], out_info["agents_crashed"] = info["speed"], info["crashed"]
@@ -356,8 +357,12 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
     def _define_spaces(self):
         self.config["host_traffic"] = self.spawn_mode == "reference"
         super()._define_spaces()
+        A = self._hcfg.num_agents
         if _gym is not None:
-            self.single_action_space = _gym.spaces.Discrete(3)
+            one = _gym.spaces.Discrete(3)
+            # MultiAgentAction.space / MultiAgentObservation.space: a Tuple with one entry per agent (action.py:336-340,
+            # observation.py:727-731); the observations come stacked as ONE [A, 15, 7] array instead of a tuple of A
+            self.single_action_space = one if A == 1 else _gym.spaces.Tuple([one] * A)
         else:
             self.single_action_space = _Discrete(3)
         self.action_space = self.single_action_space
@@ -385,31 +390,59 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
         obs = eng.observe()
         self.time[:] = 0
         self.steps = 0
-        ego = (st["flags"] & _abi.F_CONTROLLED) != 0
-        info = {"speed": st["speed"][ego], "crashed": (st["flags"][ego] & _abi.F_CRASHED) != 0, "action": None}
+        rows, ego = np.arange(E), self._ego_slots(st)
+        info = {"speed": st["speed"][rows, ego].copy(), "crashed": (st["flags"][rows, ego] & _abi.F_CRASHED) != 0, "action": None}
         return self._shape_obs(obs), info
 
     def step(self, action):
-        out = super().step(action)
+        obs, reward, term, trunc, info = super().step(action)
+        # IntersectionEnv._reward: the mean of the agents' rewards, summed left to right (:62-66); _info adds the per-agent
+        # rewards and "crashed or arrived" flags (:114-122) -- what MultiAgentWrapper hands out as reward / terminated
+        agents_rewards, agents = self._agents_step
+        A = self._hcfg.num_agents
+        if A > 1:
+            total = np.zeros(self.num_envs)
+            for a in range(A):
+                total = total + agents_rewards[:, a]
+            reward = total / A
+        info["agents_rewards"] = agents_rewards
+        info["agents_terminated"] = agents["crashed"] | agents["arrived"]
         if self.spawn_mode == "reference":  # IntersectionEnv.step: _clear_vehicles, _spawn_vehicle (:136-140)
             _ix.clear_and_spawn_reference_stream(self._engine, self._hcfg, self.config, self.np_random)
-        return out
+        return obs, reward, term, trunc, info
 
     def rewards(self, env_index: int = 0) -> dict:
-        """IntersectionEnv._agent_rewards (intersection_env.py:96-105) of one env, from the device state."""
+        """IntersectionEnv._rewards (intersection_env.py:68-77): the agents' _agent_rewards (:96-105) averaged, of one env,
+        from the device state."""
         st = self._engine.get_state()
         e = env_index
-        i = int(np.nonzero(st["flags"][e] & _abi.F_CONTROLLED)[0][0])
         tab = _ix.table_from_config(self._hcfg)
-        lane = int(st["lane"][e, i])
-        s, lat = _ix.lane_local(tab, lane, (st["x"][e, i], st["y"][e, i]))
         r0, r1 = self.config["reward_speed_range"]
-        scaled = 0 + (st["speed"][e, i] - r0) * (1 - 0) / (r1 - r0)
-        on_road = abs(lat) <= tab["width"][lane] / 2 and -5.0 <= s < tab["length"][lane] + 5.0
-        return {"collision_reward": float(bool(st["flags"][e, i] & _abi.F_CRASHED)),
-                "high_speed_reward": float(np.clip(scaled, 0, 1)),
-                "arrived_reward": float(bool(tab["exit_lane"][lane]) and s >= 25),
-                "on_road_reward": float(on_road)}
+        per_agent = []
+        for i in np.nonzero(st["flags"][e] & _abi.F_CONTROLLED)[0][:self._hcfg.num_agents]:
+            lane = int(st["lane"][e, i])
+            s, lat = _ix.lane_local(tab, lane, (st["x"][e, i], st["y"][e, i]))
+            scaled = 0 + (st["speed"][e, i] - r0) * (1 - 0) / (r1 - r0)
+            on_road = abs(lat) <= tab["width"][lane] / 2 and -5.0 <= s < tab["length"][lane] + 5.0
+            per_agent.append({"collision_reward": float(bool(st["flags"][e, i] & _abi.F_CRASHED)),
+                              "high_speed_reward": float(np.clip(scaled, 0, 1)),
+                              "arrived_reward": float(bool(tab["exit_lane"][lane]) and s >= 25),
+                              "on_road_reward": float(on_road)})
+        return {name: sum(r[name] for r in per_agent) / len(per_agent) for name in per_agent[0]}
+
+
+class BatchedMultiAgentIntersectionEnv(BatchedIntersectionEnv):
+    """E parallel ``intersection-multi-agent-v0`` environments (MultiAgentIntersectionEnv, intersection_env.py:348-399):
+    ``controlled_vehicles`` (default 2, at most 4) MDP vehicles, agent k entering from road ``o{k % 4}``; actions [E, A],
+    observations [E, A, 15, 7], ``reward`` the mean of ``info["agents_rewards"]`` [E, A], ``info["agents_terminated"]``."""
+
+    @classmethod
+    def default_config(cls) -> dict:
+        cfg = _ix.intersection_default_config()
+        cfg["action"] = {"type": "MultiAgentAction", "action_config": cfg["action"]}
+        cfg["observation"] = {"type": "MultiAgentObservation", "observation_config": cfg["observation"]}
+        cfg["controlled_vehicles"] = 2
+        return cfg
 
 
 # with gymnasium installed the single-environment drop-ins ARE gymnasium.Env's (gym.make / wrappers / checkers accept them)
@@ -461,18 +494,38 @@ class _SingleMergeMixin(_SingleEnvMixin):
 
 
 class _SingleIntersectionMixin(_SingleEnvMixin):
+    def step(self, action):
+        obs, reward, term, trunc, info = super().step(action)
+        batched = self._agents_step
+        info["agents_rewards"] = tuple(float(r) for r in batched[0][0])
+        info["agents_terminated"] = tuple(bool(c or a) for c, a in zip(batched[1]["crashed"][0], batched[1]["arrived"][0]))
+        return obs, reward, term, trunc, info
+
     @property
     def vehicle(self) -> VehicleView:
-        st = self._engine.get_state()
-        return VehicleView(st, 0, int(np.nonzero(st["flags"][0] & _abi.F_CONTROLLED)[0][0]))
+        return self.controlled_vehicles[0]
 
     @property
     def controlled_vehicles(self):
-        return [self.vehicle]
+        st = self._engine.get_state()
+        return [VehicleView(st, 0, int(i)) for i in np.nonzero(st["flags"][0] & _abi.F_CONTROLLED)[0]]
 
 
 class IntersectionEnv(_SingleIntersectionMixin, BatchedIntersectionEnv, *_GYM_BASES):
     """Drop-in for ``highway_env.envs.intersection_env.IntersectionEnv`` (``intersection-v0``)."""
+
+
+class MultiAgentIntersectionEnv(_SingleIntersectionMixin, BatchedMultiAgentIntersectionEnv, *_GYM_BASES):
+    """Drop-in for ``highway_env.envs.intersection_env.MultiAgentIntersectionEnv`` (``intersection-multi-agent-v0``): ``step``
+    takes a tuple of A meta-actions and returns the A observations stacked in one [A, 15, 7] array."""
+
+
+class BatchedConnectedLaneMultiAgentIntersectionEnv(_ConnectedLaneNeighboursMixin, BatchedMultiAgentIntersectionEnv):
+    """E parallel ConnectedLaneMultiAgentIntersectionEnv (intersection_env.py:405-408)."""
+
+
+class ConnectedLaneMultiAgentIntersectionEnv(_SingleIntersectionMixin, BatchedConnectedLaneMultiAgentIntersectionEnv, *_GYM_BASES):
+    """Drop-in for ``highway_env.envs.intersection_env.ConnectedLaneMultiAgentIntersectionEnv``."""
 
 
 class BatchedConnectedLaneIntersectionEnv(_ConnectedLaneNeighboursMixin, BatchedIntersectionEnv):
@@ -501,7 +554,8 @@ class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeG
 
 # The ids `highway_env/__init__.py:30-190` registers for this path (gym.make(id) -> the entry-point class): single
 # environment and batched class.  Ids of scenarios outside the path (parking, racetrack, roundabout, ...), the
-# continuous-action and multi-agent intersection ids raise KeyError.
+# continuous-action intersection id and the ids that wrap the multi-agent intersection in MultiAgentWrapper
+# (intersection-multi-agent-v1 / -v2: reward = info["agents_rewards"], terminated = info["agents_terminated"]) raise KeyError.
 REGISTRY = {
     "highway-v0": (HighwayEnv, BatchedHighwayEnv),
     "highway-fast-v0": (HighwayEnvFast, BatchedHighwayEnvFast),
@@ -511,6 +565,7 @@ REGISTRY = {
     "merge-generic-v1": (ConnectedLaneMergeGenericEnv, BatchedConnectedLaneMergeGenericEnv),
     "intersection-v0": (IntersectionEnv, BatchedIntersectionEnv),
     "intersection-v2": (ConnectedLaneIntersectionEnv, BatchedConnectedLaneIntersectionEnv),
+    "intersection-multi-agent-v0": (MultiAgentIntersectionEnv, BatchedMultiAgentIntersectionEnv),
 }
 
 

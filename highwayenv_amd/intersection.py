@@ -117,8 +117,9 @@ def table_from_config(c: _abi.HwyConfig) -> dict:
 
 def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
     """The intersection-specific part of _abi.make_config."""
-    if int(cfg.get("controlled_vehicles", 1)) != 1:
-        raise NotImplementedError("MultiAgentIntersectionEnv (controlled_vehicles > 1) is out of scope")
+    if not (1 <= int(cfg.get("controlled_vehicles", 1)) <= 4):
+        raise ValueError("the intersection holds 1..4 controlled vehicles (one per access road; a fifth would be "
+                         "created on top of the first, intersection_env.py:292-294)")
     dest = cfg.get("destination")
     # config["destination"] or "o" + str(np_random.integers(1, 4)) (intersection_env.py:295-297): None / "" = a random exit
     if dest and not (isinstance(dest, str) and dest in ("o0", "o1", "o2", "o3")):
@@ -127,7 +128,8 @@ def fill_config(c: _abi.HwyConfig, cfg: dict) -> None:
     c.num_vehicles = int(cfg.get("max_vehicles", 32))  # slots per environment (the list grows while an episode runs)
     if not (4 <= c.num_vehicles <= 64):
         raise ValueError("max_vehicles must be in [4, 64] (one wavefront per environment)")
-    c.agent_index[0] = 0          # the ego is found by its flag: its slot moves when the list is re-compacted
+    for a in range(int(cfg.get("controlled_vehicles", 1))):
+        c.agent_index[a] = a      # (unused: agent a is the a-th slot with F_CONTROLLED; slots move when the list is re-compacted)
     c.lanes_count = 1
     c.duration = float(cfg["duration"])
     c.road_length = 100.0
@@ -326,36 +328,37 @@ def make_vehicles_before_warmup(c, cfg, tab, st, e, rng) -> None:
 
 
 def make_vehicles_after_warmup(c, cfg, tab, st, e, rng) -> None:
-    """Second half (:260-290): challenger, the controlled vehicle, removal of traffic within 20 m of it."""
+    """Second half (:260-318): challenger, the controlled vehicles, removal of the traffic within 20 m of each."""
     spawn_vehicle(c, tab, st, e, rng, 60, spawn_probability=1.0, go_straight=True, position_deviation=0.1,
                   speed_deviation=0.0)
-    access = lane_index_of(tab, "o0", "ir0")
-    # destination = config["destination"] or "o" + str(np_random.integers(1, 4)): drawn BEFORE the position (:295-300)
-    destination = c.destination if c.destination >= 0 else int(rng.integers(1, 4))
-    pos = lane_position(tab, access, 60.0 + 5.0 * rng.normal(1.0))
-    heading = lane_heading_at(tab, access, 60.0)
-    speed = float(tab["speed_limit"][access])
-    i = _n_present(st, e)
-    if i >= c.num_vehicles:
-        raise RuntimeError("max_vehicles slots exhausted: raise config['max_vehicles']")
     ts = np.array([c.target_speeds[k] for k in range(c.num_target_speeds)])
-    lane = closest_lane(tab, pos, heading)
-    st["x"][e, i], st["y"][e, i], st["heading"][e, i], st["speed"][e, i] = pos[0], pos[1], heading, speed
-    st["lane"][e, i] = st["target_lane"][e, i] = lane
-    xs = (speed - ts[0]) / (ts[-1] - ts[0])
-    sidx = int(np.clip(np.round(xs * (ts.size - 1)), 0, ts.size - 1))   # speed_to_index (controller.py:326-344)
-    st["speed_index"][e, i] = sidx
-    st["target_speed"][e, i] = ts[sidx]
-    st["timer"][e, i] = st["delta"][e, i] = st["impact_x"][e, i] = st["impact_y"][e, i] = 0.0
-    st["flags"][e, i] = _abi.F_CONTROLLED | _abi.F_CHECK_COLLISIONS
-    st["route"][e, i] = route_pack(plan_route(tab, lane, destination))
-    present = (st["flags"][e] & _abi.F_ABSENT) == 0
-    keep = present.copy()
-    for j in np.nonzero(present)[0]:
-        if j != i and np.linalg.norm(np.array([st["x"][e, j], st["y"][e, j]]) - pos) < 20:
-            keep[j] = False
-    if not (keep == present).all():
-        _compact(st, e, keep)
+    for ego_id in range(c.num_agents):  # (:292-318)
+        access = lane_index_of(tab, f"o{ego_id % 4}", f"ir{ego_id % 4}")
+        # destination = config["destination"] or "o" + str(np_random.integers(1, 4)): drawn BEFORE the position (:295-300)
+        destination = c.destination if c.destination >= 0 else int(rng.integers(1, 4))
+        pos = lane_position(tab, access, 60.0 + 5.0 * rng.normal(1.0))
+        heading = lane_heading_at(tab, access, 60.0)
+        speed = float(tab["speed_limit"][access])
+        i = _n_present(st, e)
+        if i >= c.num_vehicles:
+            raise RuntimeError("max_vehicles slots exhausted: raise config['max_vehicles']")
+        lane = closest_lane(tab, pos, heading)
+        st["x"][e, i], st["y"][e, i], st["heading"][e, i], st["speed"][e, i] = pos[0], pos[1], heading, speed
+        st["lane"][e, i] = st["target_lane"][e, i] = lane
+        xs = (speed - ts[0]) / (ts[-1] - ts[0])
+        sidx = int(np.clip(np.round(xs * (ts.size - 1)), 0, ts.size - 1))   # speed_to_index (controller.py:326-344)
+        st["speed_index"][e, i] = sidx
+        st["target_speed"][e, i] = ts[sidx]
+        st["timer"][e, i] = st["delta"][e, i] = st["impact_x"][e, i] = st["impact_y"][e, i] = 0.0
+        st["flags"][e, i] = _abi.F_CONTROLLED | _abi.F_CHECK_COLLISIONS
+        st["route"][e, i] = route_pack(plan_route(tab, lane, destination))
+        present = (st["flags"][e] & _abi.F_ABSENT) == 0
+        keep = present.copy()
+        for j in np.nonzero(present)[0]:  # "prevent early collisions": the other controlled vehicles stay (:313-318)
+            if not (st["flags"][e, j] & _abi.F_CONTROLLED) and np.linalg.norm(np.array([st["x"][e, j], st["y"][e, j]]) - pos) < 20:
+                keep[j] = False
+        if not (keep == present).all():
+            _compact(st, e, keep)
 
 
 def reset_reference_stream(eng, c, cfg: dict, generators) -> dict:

@@ -330,6 +330,9 @@ int hwy_reset(hwy_engine *eng, const uint8_t *mask, const uint64_t *seeds, doubl
  *   terminated u8    [E]
  *   truncated  u8    [E]
  *   info_speed f64   [E][A], info_crashed u8 [E][A]    (may be NULL)
+ *              info_crashed bit 0 = vehicle.crashed; the intersection scenario
+ *              also sets bit 1 = has_arrived(vehicle) (intersection_env.py:340-345),
+ *              so that agents_terminated = (byte != 0) (:119-121)
  * hwy_step takes HOST pointers (H2D actions, kernels, D2H results, synchronises).
  * hwy_step_device takes DEVICE pointers, only enqueues on the engine's stream
  * and does not synchronise -- the path for on-GPU policies, RCCL gathers and

@@ -113,7 +113,8 @@ class EmuEngine:
                            _p(crashed, C.c_uint8), C.c_int(ar[0]), C.c_uint64(ar[1]), C.c_double(ar[2]),
                            C.c_double(ar[3]), C.c_int(ar[4]))
         assert rc == 0
-        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": crashed.astype(bool)}
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": (crashed & 1).astype(bool),
+                                                                    "arrived": (crashed & 2).astype(bool)}
 
     def step_frames(self, actions, n_frames):
         self._run(0, n_frames, actions)

@@ -260,8 +260,9 @@ def test_single_intersection_env_dropin_matches_reference_episode(real, e, v2):
 
 
 def test_intersection_config_errors():
-    with pytest.raises(NotImplementedError):
-        EmuBatchedIntersection({"controlled_vehicles": 2}, num_envs=1)
+    assert EmuBatchedIntersection({"controlled_vehicles": 2}, num_envs=1).single_observation_shape == (2, 15, 7)
+    with pytest.raises(ValueError):
+        EmuBatchedIntersection({"controlled_vehicles": 5}, num_envs=1)  # one controlled vehicle per access road
     assert EmuBatchedIntersection({"destination": None}, num_envs=1)._hcfg.destination == -1  # random exit per episode
     with pytest.raises(ValueError):
         EmuBatchedIntersection({"destination": "o7"}, num_envs=1)
@@ -298,7 +299,7 @@ def test_registry_mirrors_the_reference_ids():
     ref = {"highway-v0": "HighwayEnv", "highway-fast-v0": "HighwayEnvFast", "merge-v0": "MergeEnv",
            "merge-v1": "ConnectedLaneMergeEnv", "merge-generic-v0": "MergeGenericEnv",
            "merge-generic-v1": "ConnectedLaneMergeGenericEnv", "intersection-v0": "IntersectionEnv",
-           "intersection-v2": "ConnectedLaneIntersectionEnv"}
+           "intersection-v2": "ConnectedLaneIntersectionEnv", "intersection-multi-agent-v0": "MultiAgentIntersectionEnv"}
     assert {k: v[0].__name__ for k, v in envs.REGISTRY.items()} == ref
     for env_id, (single, batched) in envs.REGISTRY.items():
         assert issubclass(single, batched)
@@ -348,7 +349,7 @@ print("REGISTERED", len(reg.registry))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "REGISTERED 16" in r.stdout
+    assert "REGISTERED 18" in r.stdout
 
 
 def test_action_tables_longitudinal_or_lateral_only():
@@ -422,3 +423,58 @@ def test_random_destination_replays_the_reference_stream(real):
                 break
         env.close()
     assert len(dests) >= 2  # the draw really varies over the seeds
+
+
+# ---- intersection-multi-agent-v0 (MultiAgentIntersectionEnv, intersection_env.py:348-399) -----------------------------
+class EmuMultiAgentIntersection(envs._SingleIntersectionMixin, envs.BatchedMultiAgentIntersectionEnv):
+    _engine_factory = staticmethod(_emu_factory)
+
+
+def test_multi_agent_intersection_default_config_is_the_references():
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection("intersection_multi_agent")
+    mine = envs.BatchedMultiAgentIntersectionEnv.default_config()
+    for k, v in g.config.items():  # the reference's MultiAgentIntersectionEnv.default_config(), as recorded
+        if k not in ("screen_width", "screen_height", "centering_position", "scaling", "offscreen_rendering"):  # (rendering / test harness)
+            assert mine[k] == v, k
+    assert envs.REGISTRY["intersection-multi-agent-v0"][0] is envs.MultiAgentIntersectionEnv
+    with pytest.raises(ValueError, match="1..4 controlled vehicles"):
+        envs.BatchedMultiAgentIntersectionEnv({"controlled_vehicles": 5})
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+@pytest.mark.parametrize("name", ["intersection_multi_agent", "intersection_multi_agent3"])
+def test_multi_agent_intersection_dropin_matches_reference_episode(real, name):
+    """MultiAgentIntersectionEnv(config): reset(seed=s) spawns the A controlled vehicles on the reference's numpy stream (agent
+    k on road o{k % 4}; with destination None an integers(1, 4) draw before each position), then the golden tuple actions:
+    the reference's stacked observations, mean reward, info["agents_rewards"] / ["agents_terminated"], terminated."""
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection(name)
+    A = g.A
+    steps_compared = 0
+    for e in range(g.E):
+        env = (envs.MultiAgentIntersectionEnv if real else EmuMultiAgentIntersection)(dict(g.config))
+        obs, info = env.reset(seed=int(g.z["seeds"][e]))
+        assert obs.shape == (A, 15, 7) and len(env.controlled_vehicles) == A
+        np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)
+        for t in range(g.steps):
+            wst = g.state("step", t)
+            pres = wst["present"][e] != 0
+            stalled = (np.abs(wst["speed"][e][pres]) < 0.5).any()
+            wreck = ((wst["crashed"][e] != 0) | (wst["has_impact"][e] != 0))[pres].any()
+            if stalled:
+                break
+            obs, r, te, tr, info = env.step(tuple(int(a) for a in g.actions[t, e]))
+            what = f"{name} env {e} step {t}"
+            assert te == bool(g.z["terminated"][t, e]) and tr == bool(g.z["truncated"][t, e]), what
+            assert info["agents_terminated"] == tuple(bool(b) for b in g.z["agents_terminated"][t, e]), what
+            if wreck:
+                break
+            np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=what)
+            assert abs(r - g.z["reward"][t, e]) < 1e-9, what
+            np.testing.assert_allclose(info["agents_rewards"], g.z["agents_rewards"][t, e], atol=1e-9, err_msg=what)
+            steps_compared += 1
+            if te or tr:
+                break
+        env.close()
+    assert steps_compared >= 2 * g.E

@@ -119,7 +119,10 @@ def random_intersection_config(rng):
                 "destination": f"o{int(rng.integers(0, 4))}", "normalize_reward": bool(rng.integers(2)),
                 "offroad_terminal": bool(rng.integers(2)), "collision_reward": float(rng.uniform(-6, -1)),
                 "arrived_reward": float(rng.uniform(0.5, 2)),
-                "neighbour_vehicles_connected_lanes": bool(rng.integers(2))})   # intersection-v0 / -v2
+                "neighbour_vehicles_connected_lanes": bool(rng.integers(2)),    # intersection-v0 / -v2
+                "controlled_vehicles": int(rng.choice([1, 1, 2, 3, 4]))})       # > 1: MultiAgentIntersectionEnv
+    if rng.integers(3) == 0:
+        cfg["destination"] = None  # "o" + str(np_random.integers(1, 4)) per controlled vehicle
     return cfg
 
 
@@ -145,11 +148,13 @@ def test_random_intersection_configurations_vs_oracle(chunk):
             done_prev = np.zeros(E, bool)
             for t in range(10):
                 st = dev.get_state()
-                acts = rng.integers(0, 3, size=(E, 1)).astype(np.int32)
+                acts = rng.integers(0, 3, size=(E, c.num_agents)).astype(np.int32)
                 ost = ix_oracle_state(st, ch)
                 host.set_state(st)
                 h_obs, h_rew, h_term, h_trunc, _ = host.step(acts)
-                o_obs, o_rew, o_term, o_trunc, _ = oracle_ix.step(oc, ost, acts[:, 0])
+                o_obs, _, o_term, o_trunc, o_info = oracle_ix.step(oc, ost, acts)
+                o_rew = o_info["agents_rewards"]
+                rows = lambda o: o.reshape(-1, *o.shape[-2:])  # noqa: E731  ([n, A, V, F] or [n, V, F] -> agent rows)
                 pres = (st["flags"] & _abi.F_ABSENT) == 0
                 bad = (pres & ((st["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
                 # (steering_control divides by not_zero(speed) twice: below ~1 m/s last-bit differences grow fast)
@@ -175,11 +180,11 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                     def canon(o):
                         o = np.round(o.astype(np.float64), 5)
                         return np.stack([r[np.lexsort(r.T[::-1])] for r in o]) if len(o) else o
-                    np.testing.assert_allclose(canon(h_obs[ok, 0]), canon(o_obs[ok]), rtol=0, atol=2e-5, err_msg=f"step {t}")
-                    np.testing.assert_allclose(h_obs[ok, 0][:, 0], o_obs[ok][:, 0], rtol=0, atol=1e-6, err_msg=f"step {t}: ego row")
+                    np.testing.assert_allclose(canon(rows(h_obs[ok])), canon(rows(o_obs[ok])), rtol=0, atol=2e-5, err_msg=f"step {t}")
+                    np.testing.assert_allclose(rows(h_obs[ok])[:, 0], rows(o_obs[ok])[:, 0], rtol=0, atol=1e-6, err_msg=f"step {t}: ego row")
                 else:
-                    np.testing.assert_allclose(h_obs[ok, 0], o_obs[ok], rtol=0, atol=1e-6, err_msg=f"step {t}")
-                np.testing.assert_allclose(h_rew[ok, 0], o_rew[ok], rtol=0, atol=1e-9, err_msg=f"step {t}")
+                    np.testing.assert_allclose(h_obs[ok].reshape(o_obs[ok].shape), o_obs[ok], rtol=0, atol=1e-6, err_msg=f"step {t}")
+                np.testing.assert_allclose(h_rew[ok], o_rew[ok], rtol=0, atol=1e-9, err_msg=f"step {t}")
                 np.testing.assert_allclose(got["x"][ok], ost["x"][ok], rtol=0, atol=1e-7, err_msg=f"step {t}")
                 checked += int(ok.sum())
                 d_obs, d_rew, d_term, d_trunc, _ = dev.step(acts)

@@ -77,13 +77,16 @@ def _host_reset(backend, cfg, c, seeds, episode):
         hix.spawn_vehicle(c, tab, st, e, PhiloxAsGenerator(sd, 500, episode, force_spawn=True), 60, spawn_probability=1.0,
                           go_straight=True, position_deviation=0.1, speed_deviation=0.0)
 
-        class EgoDraw:
+        class EgoDraw:  # controlled vehicle k draws from stream 501 + k: (its destination,) its position
+            k = 0
+
             def normal(self, loc=0.0, _sd=sd):
-                a, b = philox_uniform2(int(_sd), 501, int(episode), 0)
+                a, b = philox_uniform2(int(_sd), 501 + self.k, int(episode), 0)
+                self.k += 1
                 return loc + np.sqrt(-2.0 * np.log(1.0 - a)) * np.cos(2 * np.pi * b)
 
             def integers(self, lo, hi, _sd=sd):  # destination = "o" + str(np_random.integers(1, 4))
-                k = min(int(philox_uniform2(int(_sd), 501, int(episode), 1)[0] * 3), 2)
+                k = min(int(philox_uniform2(int(_sd), 501 + self.k, int(episode), 1)[0] * 3), 2)
                 return lo + k
 
             def uniform(self, *a, **k):  # the challenger already took its draws
@@ -99,10 +102,12 @@ def _host_reset(backend, cfg, c, seeds, episode):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("destination", ["o1", None])
-def test_device_reset_follows_the_reference_rule(backend, destination):
+@pytest.mark.parametrize("destination,agents", [("o1", 1), (None, 1), ("o1", 2), (None, 4)])
+def test_device_reset_follows_the_reference_rule(backend, destination, agents):
+    """agents > 1: MultiAgentIntersectionEnv's loop over ego_id (intersection_env.py:292-318) -- agent k on road o{k % 4},
+    the traffic within 20 m of each new controlled vehicle removed, the controlled ones kept."""
     E = 6
-    cfg, c = _config(E, max_vehicles=24, destination=destination)
+    cfg, c = _config(E, max_vehicles=24, destination=destination, controlled_vehicles=agents)
     seeds = np.array([3, 2**40 + 17, 99, 12345678901234567, 0, 7], np.uint64)
     eng = make_engine(backend, c)
     obs = eng.reset(seeds=seeds)
@@ -111,9 +116,10 @@ def test_device_reset_follows_the_reference_rule(backend, destination):
     _assert_same_traffic(got, want, atol=1e-9, what="reset")
     np.testing.assert_array_equal(got["road_steps"], 45)
     assert (got["time"] == 0).all()
-    # one controlled vehicle per env, last in the list; the first observation row is the ego's absolute pose
+    # the controlled vehicles are the last ones of the list; the first observation row of agent a is its absolute pose
     ctrl = (got["flags"] & _abi.F_CONTROLLED) != 0
-    assert (ctrl.sum(1) == 1).all()
+    assert (ctrl.sum(1) == agents).all()
+    assert obs.shape[:2] == (E, agents)
     cfg_h = dict(cfg, host_traffic=True)
     ref = make_engine(backend, _abi.make_config(cfg_h, E, scenario="intersection"))
     ref.set_state(want)

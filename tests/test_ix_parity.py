@@ -11,7 +11,8 @@ import pytest
 
 from highwayenv_amd import _abi
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, GoldenIntersection, assert_ix_engine_state_close,
+from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_MA, INTERSECTION_MA_FRAMES, GoldenIntersection,
+                               assert_ix_engine_state_close,
                                ix_engine_state)
 
 
@@ -27,7 +28,7 @@ def _sub(st, sel):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES)
 def test_teacher_forced_frames_vs_reference(backend, name):
     """Each simulation frame (meta-action on the first frame of a step, Road.act, RegulatedRoad.step incl. the
     regulation every 7th frame) from the reference's own state; all recorded frames batched into two engine calls."""
@@ -48,7 +49,7 @@ def test_teacher_forced_frames_vs_reference(backend, name):
         w["road_steps"][...] = steps0 + k + 1
         starts.append(s0)
         wants.append(w)
-        acts.append(g.actions[step, :Ef, 0] if fr == 0 else np.ones(Ef, np.int32))
+        acts.append(g.actions[step, :Ef] if fr == 0 else np.ones((Ef, g.A), np.int32))
         has_act.append(np.full(Ef, fr == 0))
     cat = lambda sts: {f: np.concatenate([s[f] for s in sts]) for f in sts[0]}  # noqa: E731
     start, want = cat(starts), cat(wants)
@@ -59,7 +60,7 @@ def test_teacher_forced_frames_vs_reference(backend, name):
         cfg = _hwy_config(g, len(idx))
         eng = make_engine(backend, cfg)
         eng.set_state(ix_engine_state(g, _sub(start, idx), cfg))
-        eng.step_frames(acts[idx].reshape(-1, 1) if with_actions else None, 1)
+        eng.step_frames(acts[idx] if with_actions else None, 1)
         w = ix_engine_state(g, _sub(want, idx), cfg)
         assert_ix_engine_state_close(eng.get_state(), w, atol=1e-9, what=f"{name} actions={with_actions}")
         n_yield += int(((w["flags"] & _abi.F_YIELDING) != 0).sum())
@@ -68,7 +69,7 @@ def test_teacher_forced_frames_vs_reference(backend, name):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA)
 def test_policy_steps_vs_reference(backend, name):
     """Whole policy steps from the reference's state at the start of each step (host-traffic mode: the kernel does not
     clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call.
@@ -87,7 +88,7 @@ def test_policy_steps_vs_reference(backend, name):
     cfg = _hwy_config(g, E * S)
     eng = make_engine(backend, cfg)
     eng.set_state(ix_engine_state(g, cat(starts), cfg))
-    obs, reward, term, trunc, info = eng.step(g.actions[:, :, 0].reshape(E * S, 1))
+    obs, reward, term, trunc, info = eng.step(g.actions.reshape(E * S, g.A))
     got = eng.get_state()
     live = np.ones(E, bool)
     for t in range(S):
@@ -104,8 +105,15 @@ def test_policy_steps_vs_reference(backend, name):
         np.testing.assert_array_equal(term[rows][live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[rows][live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(info["crashed"][rows][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
-        np.testing.assert_allclose(obs[rows][clean, 0], g.z["obs"][t][clean], rtol=0, atol=1e-6, err_msg=what)
-        np.testing.assert_allclose(reward[rows][clean, 0], g.z["reward"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+        np.testing.assert_allclose(obs[rows][clean], g.z["obs"][t][clean].reshape(obs[rows][clean].shape), rtol=0, atol=1e-6,
+                                   err_msg=what)
+        if g.A == 1:
+            np.testing.assert_allclose(reward[rows][clean, 0], g.z["reward"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+        else:  # MultiAgentIntersectionEnv: per-agent rewards, "crashed or arrived" per agent (intersection_env.py:114-122)
+            np.testing.assert_allclose(reward[rows][clean], g.z["agents_rewards"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+            np.testing.assert_allclose(reward[rows][clean].sum(1) / g.A, g.z["reward"][t][clean], rtol=0, atol=1e-9, err_msg=what)
+            np.testing.assert_array_equal((info["crashed"] | info["arrived"])[rows][live],
+                                          g.z["agents_terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_allclose(info["speed"][rows][clean, 0], g.z["info_speed"][t][clean], rtol=0, atol=1e-9, err_msg=what)
         live &= ~g.z["terminated"][t].astype(bool)
     eng.close()
