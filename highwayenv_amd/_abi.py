@@ -148,7 +148,8 @@ class HwyConfig(C.Structure):
         ("tune_ix_no_prewarm", C.c_int32),
         ("tune_extra_lds", C.c_int32),
         ("tune_prio_shift", C.c_int32),
-        ("tune_reserved", C.c_int32 * 2),
+        ("tune_ix_prewarm_frames", C.c_int32),
+        ("tune_reserved", C.c_int32 * 1),
     ]
 
 
@@ -285,7 +286,7 @@ def agent_indices(vehicles_count: int, controlled: int) -> list:
     return idx
 
 
-TUNING_KEYS = ("block_kernel", "waves_per_eu", "ix_no_helpers", "ix_no_prewarm", "extra_lds", "prio_shift")
+TUNING_KEYS = ("block_kernel", "waves_per_eu", "ix_no_helpers", "ix_no_prewarm", "extra_lds", "prio_shift", "ix_prewarm_frames")
 
 
 def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str = "highway",

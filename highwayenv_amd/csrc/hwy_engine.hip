@@ -124,6 +124,7 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->frames_per_step < 0) BAD("frames_per_step must be >= 0");
   if (c->action_set < HWY_ACTIONS_ALL || c->action_set > HWY_ACTIONS_LAT) BAD("action_set must be HWY_ACTIONS_ALL / _LONGI / _LAT");
   if (c->tune_extra_lds < 0 || c->tune_extra_lds > 65536) BAD("tune_extra_lds must be in [0,65536]");
+  if (c->tune_ix_prewarm_frames < 0) BAD("tune_ix_prewarm_frames must be >= 0");
   if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
   if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");

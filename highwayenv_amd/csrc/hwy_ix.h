@@ -40,6 +40,7 @@ struct IxParams {
   // next-episode pre-warming (auto-reset): a second copy of the vehicle planes and, per environment,
   // {episode the shadow belongs to, warm-up progress, RegulatedRoad.steps, unused}; nullptr = off
   int32_t num_envs;
+  int32_t prewarm_frames;  // warm-up frames a pre-warming workgroup advances per launch
   int32_t helpers;         // N <= 32: launch 64 threads per environment, lanes 32..63 help (see IxSharedT); 0 = 32 threads
   DevState shadow;
   long long *shadow_route;
@@ -90,6 +91,15 @@ struct IxVeh {
 //   of parity t >> 5; partial results meet through LDS (ix_xchg) with the same tie rules the serial loops have
 //   (closest lane: minimum distance then lowest table index; impact: highest partner slot), so the results are the
 //   serial ones bit for bit.
+// One row of the lane table as the per-frame table walk reads it, in WALK order (straight lanes first, then arcs): four
+// ds_read_b128 at one address instead of an index read followed by eight scattered reads.
+//   straight: a, b = start; c, d = direction; g = heading            arc: a, b = centre; c = radius; d = +-1; g = start phase
+//   both: e = width / 2 + 1 (on_lane margin 1, lane.py:80-102), f = length, L = index in the lane table
+struct alignas(16) IxRow {
+  double a, b, c, d, e, f, g;
+  int L, pad;
+};
+
 template <int CAP, int NT = CAP>
 struct IxSharedT {
   static constexpr int kCap = CAP, kNH = NT / CAP;
@@ -104,6 +114,7 @@ struct IxSharedT {
   double sx[HWY_MAX_GLANES], sy[HWY_MAX_GLANES], lhead[HWY_MAX_GLANES], dirx[HWY_MAX_GLANES], diry[HWY_MAX_GLANES],
       cx[HWY_MAX_GLANES], cy[HWY_MAX_GLANES], rad[HWY_MAX_GLANES], sph[HWY_MAX_GLANES], len[HWY_MAX_GLANES],
       wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
+  IxRow row[HWY_MAX_GLANES];  // walk order
   u64 mask[HWY_MAX_GLANES];  // slot-space membership (on_lane, margin 1) of every lane
   // frame snapshot by slot (indexed by thread where every thread writes)
   double x[NT], y[NT], v[NT], c[NT], s[NT];
@@ -113,6 +124,10 @@ struct IxSharedT {
   int xi[kNH > 1 ? NT : 1], xb[kNH > 1 ? NT : 1];
   double hd[kNH > 1 ? CAP : 1];
   int vw[kNH > 1 ? CAP : 1];
+  // pair work of a frame (collision partners, regulation conflicts): candidate pairs (lower slot | higher slot << 8) are
+  // collected in a list and evaluated one pair per thread (ix_for_pairs); per-slot verdicts meet in jmax / flag / vlane
+  unsigned short plist[128];
+  int jmax[CAP], flag[CAP], vlane[CAP];
   union {
     double sl[HWY_MAX_GLANES][CAP];          // longitudinal coordinate of slot i on lane L (act phase)
     double traj[HWY_IX_SAMPLES][3][CAP];     // predicted (x, y, heading) of slot i at sample k (regulation)
@@ -192,6 +207,14 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
       if (ip.lanes[L].kind != 0) sh.ord[n++] = L;
   }
   __syncthreads();
+  if (i < ip.n_lanes) {
+    const int L = sh.ord[i];
+    const hwy_glane &l = ip.lanes[L];
+    const bool st = l.kind == 0;
+    sh.row[i] = IxRow{st ? l.sx : l.cx, st ? l.sy : l.cy, st ? l.dirx : l.radius, st ? l.diry : (double)l.direction,
+                      l.width / 2 + 1.0, l.length, st ? l.heading : l.start_phase, L, 0};
+  }
+  __syncthreads();
 }
 
 // helper lanes (IxSharedT): combine the two halves' partial (distance, lane) minima and membership bits
@@ -235,49 +258,72 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
   double bd = __builtin_inf(), lat_t = 0.0;  // lat_t: my lateral coordinate on my target lane (the next frame steers by it)
   bool has_lat = false;
   const int ns = sh.n_straight, n = ip.n_lanes;
-  for (int k = 0; k < ns; k += NH) {  // wave-uniform trip, one lane per half
-    const bool mine = k + half < ns;
-    const int L = sh.ord[mine ? k + half : k];
-    const double dx = x - sh.sx[L], dy = y - sh.sy[L];
-    const double s = dx * sh.dirx[L] + dy * sh.diry[L];
-    const double lat = dx * -sh.diry[L] + dy * sh.dirx[L];
-    const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
-    const double angle = fabs(wrap_to_pi(h - sh.lhead[L]));
-    const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-    if (mine) {
-      bits |= on ? (1 << L) : 0;
-      sh.sl[L][vi] = s;
-      if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
-      if (L == tgt) { lat_t = lat; has_lat = true; }
+  // A lone wavefront is bound by the LATENCY of its dependent f64 chains here, not by issue slots: every trip projects
+  // the body on TWO lanes per half (rows k and k + NH) in one basic block, so that the two chains interleave.
+  for (int k = 0; k < ns; k += 2 * NH) {  // wave-uniform trip
+    const int k0 = k + half, k1 = k0 + NH;
+    const bool m0 = k0 < ns, m1 = k1 < ns;
+    const IxRow r0 = sh.row[m0 ? k0 : k], r1 = sh.row[m1 ? k1 : k];
+    const double dx0 = x - r0.a, dy0 = y - r0.b, dx1 = x - r1.a, dy1 = y - r1.b;
+    const double s0 = dx0 * r0.c + dy0 * r0.d, s1 = dx1 * r1.c + dy1 * r1.d;
+    const double lat0 = dx0 * -r0.d + dy0 * r0.c, lat1 = dx1 * -r1.d + dy1 * r1.c;
+    const bool on0 = fabs(lat0) <= r0.e && -5.0 <= s0 && s0 < r0.f + 5.0;
+    const bool on1 = fabs(lat1) <= r1.e && -5.0 <= s1 && s1 < r1.f + 5.0;
+    const double ang0 = fabs(wrap_to_pi(h - r0.g)), ang1 = fabs(wrap_to_pi(h - r1.g));
+    const double d0 = fabs(lat0) + fmax(s0 - r0.f, 0.0) + fmax(0 - s0, 0.0) + 1.0 * ang0;
+    const double d1 = fabs(lat1) + fmax(s1 - r1.f, 0.0) + fmax(0 - s1, 0.0) + 1.0 * ang1;
+    if (m0) {
+      bits |= on0 ? (1 << r0.L) : 0;
+      sh.sl[r0.L][vi] = s0;
+      if (d0 < bd || (d0 == bd && r0.L < best)) { bd = d0; best = r0.L; }
+      if (r0.L == tgt) { lat_t = lat0; has_lat = true; }
+    }
+    if (m1) {
+      bits |= on1 ? (1 << r1.L) : 0;
+      sh.sl[r1.L][vi] = s1;
+      if (d1 < bd || (d1 == bd && r1.L < best)) { bd = d1; best = r1.L; }
+      if (r1.L == tgt) { lat_t = lat1; has_lat = true; }
     }
   }
   {
     int none = 0;
     ix_xchg(sh, bd, best, none);  // the arcs are filtered against the best distance over ALL straight lanes
   }
-  for (int k = ns; k < n; k += NH) {
-    const bool mine = k + half < n;
-    const int L = sh.ord[mine ? k + half : k];
-    const double dx = x - sh.cx[L], dy = y - sh.cy[L];
-    const double r = sqrt(dx * dx + dy * dy);
-    const double lat = sh.ldir[L] * (sh.rad[L] - r);
-    const bool need = mine && present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);
-    if (__ballot(need) == 0) {
-      if (mine) sh.sl[L][vi] = 0.0;
+  for (int k = ns; k < n; k += 2 * NH) {
+    const int k0 = k + half, k1 = k0 + NH;
+    const bool m0 = k0 < n, m1 = k1 < n;
+    const IxRow r0 = sh.row[m0 ? k0 : k], r1 = sh.row[m1 ? k1 : k];
+    const double dx0 = x - r0.a, dy0 = y - r0.b, dx1 = x - r1.a, dy1 = y - r1.b;
+    const double rr0 = sqrt(dx0 * dx0 + dy0 * dy0), rr1 = sqrt(dx1 * dx1 + dy1 * dy1);
+    const double lat0 = r0.d * (r0.c - rr0), lat1 = r1.d * (r1.c - rr1);
+    const bool need0 = m0 && present && (fabs(lat0) <= r0.e || !(fabs(lat0) > bd) || r0.L == tgt);
+    const bool need1 = m1 && present && (fabs(lat1) <= r1.e || !(fabs(lat1) > bd) || r1.L == tgt);
+    if (__ballot(need0 || need1) == 0) {
+      if (m0) sh.sl[r0.L][vi] = 0.0;
+      if (m1) sh.sl[r1.L][vi] = 0.0;
       continue;
     }
-    double phi = atan2_bounded(dy, dx);
-    phi = sh.sph[L] + wrap_to_pi(phi - sh.sph[L]);
-    const double s = sh.ldir[L] * (phi - sh.sph[L]) * sh.rad[L];
-    const double lane_h = (sh.ldir[L] * s / sh.rad[L] + sh.sph[L]) + HWY_PI / 2 * sh.ldir[L];
-    const bool on = fabs(lat) <= sh.wid[L] / 2 + 1.0 && -5.0 <= s && s < sh.len[L] + 5.0;
-    const double angle = fabs(wrap_to_pi(h - lane_h));
-    const double d = fabs(lat) + fmax(s - sh.len[L], 0.0) + fmax(0 - s, 0.0) + 1.0 * angle;
-    if (mine) {
-      bits |= on ? (1 << L) : 0;
-      sh.sl[L][vi] = s;
-      if (d < bd || (d == bd && L < best)) { bd = d; best = L; }
-      if (L == tgt) { lat_t = lat; has_lat = true; }
+    double phi0 = atan2_bounded(dy0, dx0), phi1 = atan2_bounded(dy1, dx1);
+    phi0 = r0.g + wrap_to_pi(phi0 - r0.g);
+    phi1 = r1.g + wrap_to_pi(phi1 - r1.g);
+    const double s0 = r0.d * (phi0 - r0.g) * r0.c, s1 = r1.d * (phi1 - r1.g) * r1.c;
+    const double lh0 = (r0.d * s0 / r0.c + r0.g) + HWY_PI / 2 * r0.d, lh1 = (r1.d * s1 / r1.c + r1.g) + HWY_PI / 2 * r1.d;
+    const bool on0 = fabs(lat0) <= r0.e && -5.0 <= s0 && s0 < r0.f + 5.0;
+    const bool on1 = fabs(lat1) <= r1.e && -5.0 <= s1 && s1 < r1.f + 5.0;
+    const double ang0 = fabs(wrap_to_pi(h - lh0)), ang1 = fabs(wrap_to_pi(h - lh1));
+    const double d0 = fabs(lat0) + fmax(s0 - r0.f, 0.0) + fmax(0 - s0, 0.0) + 1.0 * ang0;
+    const double d1 = fabs(lat1) + fmax(s1 - r1.f, 0.0) + fmax(0 - s1, 0.0) + 1.0 * ang1;
+    if (m0) {
+      bits |= on0 ? (1 << r0.L) : 0;
+      sh.sl[r0.L][vi] = s0;
+      if (d0 < bd || (d0 == bd && r0.L < best)) { bd = d0; best = r0.L; }
+      if (r0.L == tgt) { lat_t = lat0; has_lat = true; }
+    }
+    if (m1) {
+      bits |= on1 ? (1 << r1.L) : 0;
+      sh.sl[r1.L][vi] = s1;
+      if (d1 < bd || (d1 == bd && r1.L < best)) { bd = d1; best = r1.L; }
+      if (r1.L == tgt) { lat_t = lat1; has_lat = true; }
     }
   }
   ix_xchg(sh, bd, best, bits, &lat_t, has_lat);
@@ -362,11 +408,9 @@ __device__ inline void ix_along_route(const SH &sh, const IxVeh &me, double lon,
 
 // utils.has_corner_inside (utils.py:160-174): the 9 sample points of rect 1 (corners, centre, edge midpoints) against
 // rect 2 with the reference's +angle rotation (utils.py:79-95)
-__device__ inline bool ix_corner_inside(double c1x, double c1y, double a1, double c2x, double c2y, double a2) {
+// (c, s) = cos / sin of rect 1's angle, (c2, s2) of rect 2's: the caller tests both directions with one pair of sincos
+__device__ inline bool ix_corner_inside(double c1x, double c1y, double c, double s, double c2x, double c2y, double c2, double s2) {
   const double hl = 1.5 * HWY_VEH_LENGTH / 2, hw = 0.9 * HWY_VEH_WIDTH / 2;
-  double c, s, c2, s2;
-  sincos_bounded(a1, &s, &c);
-  sincos_bounded(a2, &s2, &c2);
   bool any = false;
   for (int k = 0; k < 9; ++k) {
     const double qx = (k == 0 || k == 1 || k == 5) ? -hl : ((k == 2 || k == 3 || k == 6) ? hl : (k == 7 ? -0.0 : 0.0));
@@ -439,6 +483,39 @@ __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &
         st.impact_y[k] = o.impy;
       }
     }
+  }
+}
+
+// ---- pair work: `trips` = the partner slots to visit (wave-uniform mask; with helper lanes bit j stands for the slots j and
+//      j + 1, one per half), cand(j) = "my vehicle and slot j are a candidate pair" (asked with my vehicle as the LOWER slot
+//      only: every unordered pair once), proc(pair) = the expensive evaluation of ONE pair per thread (pair < 0: none).
+//      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
+//      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
+template <typename SH, typename Cand, typename Proc>
+__device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
+  const int i = threadIdx.x;
+  const u64 below = ((u64)1 << i) - 1;
+  int n_list = 0;  // wave-uniform
+  while (trips || n_list) {
+    while (trips && n_list < 64) {
+      const int j = ctz64(trips) + half;
+      trips &= trips - 1;
+      const bool c = cand(j);
+      const u64 cm = __ballot(c);
+      if (cm) {
+        if (c) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | (j << 8));
+        n_list += __popcll(cm);
+      }
+    }
+    const int count = n_list < 64 ? n_list : 64;
+    HWY_WAVE_LDS_FENCE();
+    const int pair = i < count ? (int)sh.plist[i] : -1;
+    const int left = n_list - count;  // < 64
+    const int carry = i < left ? (int)sh.plist[count + i] : 0;
+    proc(pair);
+    HWY_WAVE_LDS_FENCE();
+    if (i < left) sh.plist[i] = (unsigned short)carry;
+    n_list = left;
   }
 }
 
@@ -593,54 +670,52 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         }
         my_rho = sqrt(my_rho);  // == the maximum of the 11 distances (sqrt is monotone)
       }
-      if (half == 0) { sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho; }
+      if (half == 0) {
+        sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho;
+        sh.flag[vi] = 0;
+        sh.vlane[vi] = lane_me;
+      }
       HWY_WAVE_LDS_FENCE();
-      bool yield = false;
-      // partner trips: one slot per half (NH == 2: slots j0 and j0 + 1), skipped when nobody is there
-      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform
-        const int j = ctz64(m) + half;
-        const bool pj = NH > 1 ? ((pm >> j) & 1) != 0 : true;
-        const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
-        const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
-        const bool possible = veh_v && pj && vi != j && bdx * bdx + bdy * bdy <= reach * reach;
-        if (__ballot(possible) == 0) continue;
-        int lane_j;
-        if constexpr (NH > 1) lane_j = sh.xb[j] & 255;
-        else lane_j = wave_bcast_i(me.lane, j);
-        bool conflict = false;
-        if (possible) {
-          for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
-            const double ax = sh.traj[k][0][vi], ay = sh.traj[k][1][vi], bx = sh.traj[k][0][j], by = sh.traj[k][1][j];
-            const double dx = bx - ax, dy = by - ay;
-            if (sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH) continue;
-            const double ah = sh.traj[k][2][vi], bh = sh.traj[k][2][j];
-            // rotated_rectangles_intersect(rect(lower slot), rect(higher slot)) is symmetric in its arguments
-            conflict = ix_corner_inside(ax, ay, ah, bx, by, bh) || ix_corner_inside(bx, by, bh, ax, ay, ah);
-          }
-        }
-        if (conflict) {
-          // respect_priorities(v1 = lower slot, v2 = higher slot) (regulation.py:70-86)
-          const int pj_ = sh.prio[lane_j], pi_ = sh.prio[lane_me];
-          const bool i_low = vi < j;
-          const int p1 = i_low ? pi_ : pj_, p2 = i_low ? pj_ : pi_;
-          bool low_yields;
-          if (p1 > p2) low_yields = false;
-          else if (p1 < p2) low_yields = true;
-          else {
-            const double fd_i = c_me * (sh.x[j] - x_me) + sn_me * (sh.y[j] - y_me);       // i.front_distance_to(j)
-            const double fd_j = sh.c[j] * (x_me - sh.x[j]) + sh.s[j] * (y_me - sh.y[j]);  // j.front_distance_to(i)
-            const double f1 = i_low ? fd_i : fd_j, f2 = i_low ? fd_j : fd_i;
-            low_yields = f1 > f2;
-          }
-          yield = yield || (low_yields == i_low);
-        }
-      }
-      if constexpr (NH > 1) {  // a vehicle yields iff one of its halves found a pair that names it
-        HWY_WAVE_LDS_FENCE();
-        sh.xi[i] = yield ? 1 : 0;
-        HWY_WAVE_LDS_FENCE();
-        yield = yield || sh.xi[i ^ SH::kCap] != 0;
-      }
+      // is_conflict_possible (regulation.py:88-111) + respect_priorities (:70-86) of every candidate pair, one pair per
+      // thread; a vehicle yields iff some pair names it (sh.flag)
+      ix_for_pairs(
+          sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
+          [&](int j) {
+            if (!(veh_v && vi < j && ((pm >> j) & 1))) return false;
+            const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
+            const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
+            return bdx * bdx + bdy * bdy <= reach * reach;
+          },
+          [&](int pair) {
+            if (pair < 0) return;
+            const int a = pair & 255, b = pair >> 8;  // a < b: v1 = a, v2 = b
+            bool conflict = false;
+            for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
+              const double ax = sh.traj[k][0][a], ay = sh.traj[k][1][a], bx = sh.traj[k][0][b], by = sh.traj[k][1][b];
+              const double dx = bx - ax, dy = by - ay;
+              if (sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH) continue;
+              const double ah = sh.traj[k][2][a], bh = sh.traj[k][2][b];
+              double ca, sa, cb, sb;
+              sincos_bounded(ah, &sa, &ca);
+              sincos_bounded(bh, &sb, &cb);
+              // rotated_rectangles_intersect(rect(lower slot), rect(higher slot))
+              conflict = ix_corner_inside(ax, ay, ca, sa, bx, by, cb, sb) || ix_corner_inside(bx, by, cb, sb, ax, ay, ca, sa);
+            }
+            if (conflict) {
+              const int p1 = sh.prio[sh.vlane[a]], p2 = sh.prio[sh.vlane[b]];
+              bool low_yields;
+              if (p1 > p2) low_yields = false;
+              else if (p1 < p2) low_yields = true;
+              else {
+                const double f1 = sh.c[a] * (sh.x[b] - sh.x[a]) + sh.s[a] * (sh.y[b] - sh.y[a]);  // a.front_distance_to(b)
+                const double f2 = sh.c[b] * (sh.x[a] - sh.x[b]) + sh.s[b] * (sh.y[a] - sh.y[b]);  // b.front_distance_to(a)
+                low_yields = f1 > f2;
+              }
+              sh.flag[low_yields ? a : b] = 1;
+            }
+          });
+      HWY_WAVE_LDS_FENCE();
+      const bool yield = i < SH::kCap && sh.flag[i] != 0;
       if (present && yield && !controlled) {  // only a ControlledVehicle that is not the MDPVehicle is stopped
         me.ts = 0.0;
         me.flags |= HWY_F_YIELDING;
@@ -688,42 +763,44 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       HWY_WAVE_LDS_FENCE();
       sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
       HWY_WAVE_LDS_FENCE();
-      // (helper lanes: thread t checks vehicle t & 31 against the partners of parity t >> 5)
+      // (helper lanes: thread t looks for the partners of vehicle t & 31 among the slots of parity t >> 5)
       const Body mine = NH > 1 ? Body{sh.x[vi], sh.y[vi], sh.v[vi], sh.c[vi], sh.s[vi]} : Body{me.x, me.y, me.v, c2, s2};
       const bool present_v = NH > 1 ? ((pm >> vi) & 1) != 0 : present;
-      int j_imp = -1;
-      double imp_x = 0.0, imp_y = 0.0;
-      bool crash = false;
-      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform, ascending
-        const int j = ctz64(m) + half;
-        bool near = false;
-        if (present_v && vi != j && (NH == 1 || ((pm >> j) & 1))) {
-          const double dx = sh.x[j] - mine.x, dy = sh.y[j] - mine.y;
-          const double lim = 5.5 + fmax(fabs(mine.v), fabs(sh.v[j])) * p.dt;
-          near = dx * dx + dy * dy <= lim * lim;
-        }
-        if (near) {
-          const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
-          const bool i_first = vi < j;
-          const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
-          double tx, ty;
-          const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
-          if (r & 2) {
-            imp_x = i_first ? tx / 2 : -tx / 2;
-            imp_y = i_first ? ty / 2 : -ty / 2;
-            j_imp = j;
-          }
-          if (r & 1) crash = true;
-        }
-      }
-      if constexpr (NH > 1) {  // the other half's verdict: the impact of the higher partner slot stays
-        HWY_WAVE_LDS_FENCE();
-        sh.xd[i] = imp_x; sh.bcx[i] = imp_y; sh.xi[i] = j_imp; sh.xb[i] = crash ? 1 : 0;
-        HWY_WAVE_LDS_FENCE();
-        const int o = i ^ SH::kCap;
-        if (sh.xi[o] > j_imp) { imp_x = sh.xd[o]; imp_y = sh.bcx[o]; j_imp = sh.xi[o]; }
-        crash = crash || sh.xb[o] != 0;
-      }
+      if (i < SH::kCap) { sh.jmax[i] = -1; sh.flag[i] = 0; }
+      HWY_WAVE_LDS_FENCE();
+      ix_for_pairs(
+          sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
+          [&](int j) {
+            if (!(present_v && vi < j && ((pm >> j) & 1))) return false;
+            const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
+            const double dx = other.x - mine.x, dy = other.y - mine.y;
+            const double lim = 5.5 + fmax(fabs(mine.v), fabs(other.v)) * p.dt;
+            if (!(dx * dx + dy * dy <= lim * lim)) return false;  // objects.py:124-127
+            return !surely_apart(mine, other, p.dt);  // (hwy_device.h: provably (False, False) without the SAT)
+          },
+          [&](int pair) {
+            const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+            int r = 0;
+            double tx = 0.0, ty = 0.0;
+            if (pair >= 0) {
+              const Body A{sh.x[a], sh.y[a], sh.v[a], sh.c[a], sh.s[a]}, Bb{sh.x[b], sh.y[b], sh.v[b], sh.c[b], sh.s[b]};
+              r = pair_collide(A, Bb, p.dt, &tx, &ty);
+              if (r & 1) sh.flag[a] = sh.flag[b] = 1;
+              if (r & 2) {  // the impact of the HIGHEST partner slot stays (the reference's loop overwrites)
+                __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+            HWY_WAVE_LDS_FENCE();
+            if (r & 2) {
+              if (sh.jmax[a] == b) { sh.bcx[a] = tx / 2; sh.bcy[a] = ty / 2; }
+              if (sh.jmax[b] == a) { sh.bcx[b] = -tx / 2; sh.bcy[b] = -ty / 2; }
+            }
+          });
+      HWY_WAVE_LDS_FENCE();
+      const int j_imp = i < SH::kCap ? sh.jmax[i] : -1;
+      const double imp_x = j_imp >= 0 ? sh.bcx[i] : 0.0, imp_y = j_imp >= 0 ? sh.bcy[i] : 0.0;
+      const bool crash = i < SH::kCap && sh.flag[i] != 0;
       if (present && j_imp >= 0) {
         me.impx = imp_x;
         me.impy = imp_y;
@@ -739,6 +816,10 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
 //      their features; a cell-strided pass writes the on-road layer and the zeros), with the on-road layer painted from
 //      the waypoints of EVERY lane of the network (fill_road_layer_by_lanes, :454-484: straight lanes of any direction
 //      and circular arcs).  sh.brho doubles as the per-lane origin table. ------------------------------------------------
+// Workspace access of the grid observation: LDS (plain accesses, one wavefront per workgroup) or the global workspace
+__device__ inline void ix_ws_store(int32_t *q, int32_t v, bool lds) { if (lds) *q = v; else grid_ws_store(q, v); }
+__device__ inline int32_t ix_ws_load(int32_t *q, bool lds) { return lds ? *q : grid_ws_load(q); }
+
 template <typename SH>
 __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a, const IxVeh &me, bool present, int ia) {
   const StepParams &p = ip.s;
@@ -746,11 +827,22 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
   const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
   const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
   const double ec = wave_bcast(me.ch, ia), es = wave_bcast(me.sh, ia);
-  int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
+  // The frames are over: the s table / trajectories (8 KB of LDS) are dead and hold the workspace of the observation --
+  // cell owners, on-road cells, and the list of the DISTINCT waypoints of the on-road layer -- when it fits (BASELINE
+  // config 4: 11 x 11 cells); larger grids go through the global workspace like the other scenarios' (hwy_device.h).
+  const int per_lane = p.g_nwp + 1;
+  int32_t *const lds_ws = reinterpret_cast<int32_t *>(&sh.traj[0][0][0]);
+  const int lds_ints = (int)(sizeof(sh.traj) / sizeof(int32_t));
+  const int list_cap = (lds_ints - 2 * WH - 2 * HWY_MAX_GLANES) * 4;  // bytes left for the waypoint list
+  const bool lds = 2 * WH + 2 * HWY_MAX_GLANES < lds_ints;              // wave-uniform
+  int32_t *own = lds ? lds_ws : p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
+  int32_t *w_off = lds_ws + 2 * WH, *w_j0 = w_off + HWY_MAX_GLANES;
+  unsigned char *w_lane = reinterpret_cast<unsigned char *>(w_j0 + HWY_MAX_GLANES);
   float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  __syncthreads();
   for (int t = i; t < WH; t += NT) {
-    grid_ws_store(own + t, 0x7fffffff);
-    grid_ws_store(road + t, 0);
+    ix_ws_store(own + t, 0x7fffffff, lds);
+    ix_ws_store(road + t, 0, lds);
   }
   __syncthreads();
   int my_ci = -1, my_cj = -1;
@@ -763,25 +855,58 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
     if (0 <= ci && ci < W && 0 <= cj && cj < H) {
       my_ci = ci;
       my_cj = cj;
-      grid_ws_min(own + ci * H + cj, i);
+      // the lowest slot of a cell owns it (the reference scatters the list in REVERSE): ds_min / L2 atomic min
+      if (lds) __hip_atomic_fetch_min(own + ci * H + cj, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else grid_ws_min(own + ci * H + cj, i);
     }
   }
   bool has_road = false;
   for (int f = 0; f < F; ++f) has_road |= (p.feat[f] == HWY_FEAT_ON_ROAD);
   if (has_road) {  // wave-uniform
     // origin of lane L = lane.local_coordinates(observer.position)[0], one lane per thread
+    // np.arange(origin - 100, origin + 100, spacing) holds ceil(((origin + 100) - (origin - 100)) / spacing) waypoints:
+    // g_nwp or, when the rounded difference exceeds 200, one more -- and on these short lanes that last waypoint is
+    // clipped to the lane's END, which can be a cell of its own, so the count is evaluated per lane like numpy does
+    int cnt = 0, j0 = 0;
     if (i < ip.n_lanes) {
       double s, lat;
       ix_local(sh, i, ex, ey, &s, &lat);
       sh.brho[i] = s;
+      // Most of the 200 m window lies before the start or beyond the end of these short lanes, and every waypoint there
+      // is clipped to the same end point: waypoint j is (s - 100) + j * spacing, so all j below jl are <= -spacing (clipped
+      // to 0 like jl itself) and all j above jh are >= length + spacing (clipped to the end like jh): [jl, jh] visits every
+      // DISTINCT clipped waypoint, i.e. paints the same cells
+      const int count = (int)ceil(((s + 100.0) - (s - 100.0)) / p.g_spacing);
+      const int jl = (int)floor((100.0 - s) / p.g_spacing) - 1, jh = (int)floor((100.0 - s + sh.len[i]) / p.g_spacing) + 2;
+      j0 = jl < 0 ? 0 : jl;
+      const int j1 = jh > count - 1 ? count - 1 : jh;
+      cnt = j1 >= j0 ? j1 - j0 + 1 : 0;
+    }
+    int off = 0, total = 0;
+    for (int k = 0; k < ip.n_lanes; ++k) {  // wave-uniform
+      const int c = wave_bcast_i(cnt, k);
+      off += k < i ? c : 0;
+      total += c;
+    }
+    const bool listed = lds && total <= list_cap;  // wave-uniform
+    if (listed) {
+      if (i < ip.n_lanes) {
+        w_off[i] = off;
+        w_j0[i] = j0;
+        for (int q = 0; q < cnt; ++q) w_lane[off + q] = (unsigned char)i;
+      }
     }
     __syncthreads();
-    // np.arange(origin - 100, origin + 100, spacing) holds ceil(((origin + 100) - (origin - 100)) / spacing) waypoints:
-    // g_nwp or, when the rounded difference exceeds 200, one more -- and on these short lanes that last waypoint is
-    // clipped to the lane's END, which can be a cell of its own, so the count is evaluated per lane like numpy does
-    const int per_lane = p.g_nwp + 1;
-    for (int t = i; t < ip.n_lanes * per_lane; t += NT) {
-      const int k = t / per_lane, j = t - k * per_lane;
+    const int n_items = listed ? total : ip.n_lanes * per_lane;
+    for (int t = i; t < n_items; t += NT) {
+      int k, j;
+      if (listed) {
+        k = w_lane[t];
+        j = w_j0[k] + (t - w_off[k]);
+      } else {
+        k = t / per_lane;
+        j = t - k * per_lane;
+      }
       const double o = sh.brho[k];
       if (j >= (int)ceil(((o + 100.0) - (o - 100.0)) / p.g_spacing)) continue;
       const double wp = clipd((o - 100.0) + j * p.g_spacing, 0.0, sh.len[k]);
@@ -789,12 +914,12 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
       ix_position(sh, k, wp, &px, &py);
       int ci, cj;
       grid_cell(p, px - ex, py - ey, ec, es, &ci, &cj);
-      if (0 <= ci && ci < W && 0 <= cj && cj < H) grid_ws_store(road + ci * H + cj, 1);
+      if (0 <= ci && ci < W && 0 <= cj && cj < H) ix_ws_store(road + ci * H + cj, 1, lds);
     }
   }
   __syncthreads();
   const bool clip = (p.flags & HWY_C_OBS_CLIP) != 0;
-  if (my_ci >= 0 && grid_ws_load(own + my_ci * H + my_cj) == i) {  // I own my cell: write the vehicle layers
+  if (my_ci >= 0 && ix_ws_load(own + my_ci * H + my_cj, lds) == i) {  // I own my cell: write the vehicle layers
     for (int f = 0; f < F; ++f) {
       const int fid = p.feat[f];
       if (fid == HWY_FEAT_ON_ROAD) continue;
@@ -814,8 +939,8 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
   }
   for (int t = i; t < F * WH; t += NT) {  // everything the owners do not write
     const int f = t / WH, c = t - f * WH;
-    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
-    else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;  // NaN (empty) -> 0
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = ix_ws_load(road + c, lds) ? 1.0f : 0.0f;
+    else if (ix_ws_load(own + c, lds) == 0x7fffffff) out[t] = 0.0f;  // NaN (empty) -> 0
   }
   __syncthreads();
 }
@@ -1168,7 +1293,7 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
     prog = usable ? m[1] : 0;
     road_steps = usable ? m[2] : 0;
     const int left = total - prog;  // < 0: the shadow is ready (challenger and ego included)
-    n_run = left < 0 ? 0 : (role == PREWARM && p.T < left ? p.T : left);
+    n_run = left < 0 ? 0 : (role == PREWARM && ip.prewarm_frames < left ? ip.prewarm_frames : left);
     finalise = left >= 0 && n_run == left;
   }
   IxVeh me;

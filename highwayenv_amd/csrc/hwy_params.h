@@ -69,6 +69,10 @@ inline void ix_params_from_config(const hwy_config &c, const StepParams &p, IP &
   ip.n_lanes = c.gnet_lanes;
   ip.num_envs = c.num_envs;
   ip.helpers = c.tune_ix_no_helpers ? 0 : 1;  // 0: 32-thread workgroups (no helper lanes) for N <= 32
+  // a third of a policy step per launch: the pre-warming wavefronts start when the first step wavefronts retire, and short
+  // ones fill the tail of the launch instead of making a second round of it (profiles/r02_history.md)
+  ip.prewarm_frames = c.tune_ix_prewarm_frames > 0 ? c.tune_ix_prewarm_frames : (c.frames_per_step + 2) / 3;
+  if (ip.prewarm_frames < 1) ip.prewarm_frames = 1;
   ip.initial_count = c.initial_vehicle_count;
   ip.host_spawn = (c.flags & HWY_C_HOST_TRAFFIC) ? 1 : 0;
   ip.destination = c.destination;

@@ -252,7 +252,9 @@ typedef struct hwy_config {
                                           -1 = off (hardware order: oldest wavefront first), 0 = the engine's default: 14
                                           (~7 us) when the whole grid of the step kernel is resident at once (occupancy x
                                           compute units >= num_envs), else off */
-  int32_t tune_reserved[2];
+  int32_t tune_ix_prewarm_frames;      /* HWY_SCENARIO_INTERSECTION auto-reset: warm-up frames of the NEXT episode advanced per
+                                          launch by the pre-warming workgroup of an environment (0 = a third of frames_per_step) */
+  int32_t tune_reserved[1];
 } hwy_config;
 
 /*

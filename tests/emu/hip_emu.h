@@ -124,9 +124,11 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
 // agent-scope atomics (fibers run on one OS thread: plain accesses)
 template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = *p; *p = old + (T)v; return old; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __hip_atomic_store(ptr, v, order, scope) (*(ptr) = (v))
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 #define __hip_atomic_fetch_min(ptr, v, order, scope) (*(ptr) = (*(ptr) < (v) ? *(ptr) : (v)))
+#define __hip_atomic_fetch_max(ptr, v, order, scope) (*(ptr) = (*(ptr) > (v) ? *(ptr) : (v)))
 inline double __longlong_as_double(long long v) { double d; __builtin_memcpy(&d, &v, 8); return d; }
 inline long long __double_as_longlong(double d) { long long v; __builtin_memcpy(&v, &d, 8); return v; }
 inline int __double2loint(double d) { long long b; __builtin_memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }

@@ -117,6 +117,42 @@ def net_ticks(text):
     return t
 
 
+def ix_ticks(text):
+    """s_memtime stamps around the sections of the intersection kernel (hwy_ix.h), accumulated in LDS by thread 0 and
+    written over the first observation words of the environment (tools/ix_section_dist.py reads them)."""
+    t = sub("  int vw[kNH > 1 ? CAP : 1];", "  int vw[kNH > 1 ? CAP : 1];\n  long long tk[16]; long long tprev;")(text)
+    t = sub("// ---- lane geometry from the LDS table, per-thread lane index",
+            "#define IXTICK(k) { if (threadIdx.x == 0) { const long long t_ = clock64(); sh.tk[k] += t_ - sh.tprev; sh.tprev = t_; } }\n"
+            "// ---- lane geometry from the LDS table, per-thread lane index")(t)
+    # inside the table walk: [11] = prologue + straight lanes, [12] = exchange + arcs, the final exchange stays in [5]
+    t = sub("  {\n    int none = 0;\n    ix_xchg(sh, bd, best, none);", "  IXTICK(11)\n  {\n    int none = 0;\n    ix_xchg(sh, bd, best, none);")(t)
+    t = sub("  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);\n  *bits_out", "  IXTICK(12)\n  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);\n  *bits_out")(t)
+    # inside the regulation: [13] = samples + circles, the partner loop stays in [3]
+    t = sub("      // is_conflict_possible (regulation.py:88-111) + respect_priorities", "      IXTICK(13)\n      // is_conflict_possible (regulation.py:88-111) + respect_priorities")(t)
+    t = sub("    // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act", "    IXTICK(fr == 0 ? 0 : 6)\n    // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act")(t)
+    t = sub("    // ---- C. Road.act (road.py:464-467)", "    IXTICK(1)\n    // ---- C. Road.act (road.py:464-467)")(t)
+    t = sub("    // ---- D. RegulatedRoad.step (regulation.py:36-68)", "    IXTICK(2)\n    // ---- D. RegulatedRoad.step (regulation.py:36-68)")(t)
+    t = sub("    // ---- E. Vehicle.step (kinematics.py:130-177", "    IXTICK(3)\n    // ---- E. Vehicle.step (kinematics.py:130-177")(t)
+    t = sub("    HWY_WAVE_LDS_FENCE();  // the trajectories (if any) are dead", "    IXTICK(4)\n    HWY_WAVE_LDS_FENCE();  // the trajectories (if any) are dead")(t)
+    t = sub("    // ---- F. collisions (road.py:477-481", "    IXTICK(5)\n    // ---- F. collisions (road.py:477-481")(t)
+    t = sub("      if (present && crash) me.flags |= HWY_F_CRASHED;\n    }\n  }\n}",
+            "      if (present && crash) me.flags |= HWY_F_CRASHED;\n    }\n  }\n  IXTICK(6)\n}")(t)
+    # the step kernel only (the first occurrence of each pattern after its head)
+    a = t.index("__global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel")
+    head, k = t[:a], t[a:]
+    k = sub("  ix_load_table(ip, sh);\n", "  ix_load_table(ip, sh);\n  if (i == 0) { for (int q = 0; q < 16; ++q) sh.tk[q] = 0; sh.tprev = clock64(); }\n")(k) if False else \
+        k.replace("  ix_load_table(ip, sh);\n", "  ix_load_table(ip, sh);\n  if (i == 0) { for (int q = 0; q < 16; ++q) sh.tk[q] = 0; sh.tprev = clock64(); }\n", 1)
+    k = k.replace("  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n",
+                  "  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n  IXTICK(9)\n", 1)
+    k = k.replace("    ix_observe(ip, sh, e, me, role == STEP);\n  }\n", "    ix_observe(ip, sh, e, me, role == STEP);\n  }\n  IXTICK(7)\n", 1)
+    k = k.replace("ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n", "ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n  IXTICK(8)\n", 1)
+    k = k.replace("  if (i == 0) ip.road_steps[e] = road_steps;\n}",
+                  "  if (i == 0) ip.road_steps[e] = road_steps;\n  IXTICK(10)\n"
+                  "  if (i == 0 && p.obs) { float *o = p.obs + (size_t)e * p.A * (p.obs_type == HWY_OBS_KINEMATICS ? p.V * p.F : p.F * p.gW * p.gH);\n"
+                  "    for (int q = 0; q < 14; ++q) o[q] = (float)sh.tk[q]; o[14] = (float)role; o[15] = (float)n_run; }\n}", 1)
+    return head + k
+
+
 def wave_reload(text):
     """Frame loop of the one-wavefront kernel reads its parameters through a per-iteration view of the kernarg segment
     (short-lived SGPRs instead of values kept -- and spilled -- across the loop)."""
@@ -183,6 +219,7 @@ VARIANTS = {
                           "    return;"))],
     # intersection kernel (hwy_ix.h): sections removed (timing only)
     "ixbase": [],
+    "ixticks": [(IX, ix_ticks)],
     "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],
     "ixnocoll": [(IX, sub("      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform, ascending", "      for (u64 m = 0; m; m &= m - 1) {"))],
     "ixnoarc": [(IX, sub("    const bool need = mine && present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);", "    const bool need = false;"))],
