@@ -122,8 +122,8 @@ struct IxSharedT {
   // helper-lane exchange (kNH == 2 only): one double and two ints per thread, plus what a helper needs of its vehicle
   double xd[kNH > 1 ? NT : 1], xl[kNH > 1 ? NT : 1];
   int xi[kNH > 1 ? NT : 1], xb[kNH > 1 ? NT : 1];
-  double hd[kNH > 1 ? CAP : 1];
-  int vw[kNH > 1 ? CAP : 1];
+  double hd[CAP];
+  int vw[CAP];
   // pair work of a frame (collision partners, regulation conflicts): candidate pairs (lower slot | higher slot << 8) are
   // collected in a list and evaluated one pair per thread (ix_for_pairs); per-slot verdicts meet in jmax / flag / vlane
   unsigned short plist[128];
@@ -234,6 +234,39 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double 
   }
 }
 
+// ---- pair work: `trips` = the partner slots to visit (wave-uniform mask; with helper lanes bit j stands for the slots j and
+//      j + 1, one per half), cand(j) = "my vehicle and slot j are a candidate pair" (asked with my vehicle as the LOWER slot
+//      only: every unordered pair once), proc(pair) = the expensive evaluation of ONE pair per thread (pair < 0: none).
+//      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
+//      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
+template <typename SH, typename Cand, typename Proc>
+__device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
+  const int i = threadIdx.x;
+  const u64 below = ((u64)1 << i) - 1;
+  int n_list = 0;  // wave-uniform
+  while (trips || n_list) {
+    while (trips && n_list < 64) {
+      const int j = ctz64(trips) + half;
+      trips &= trips - 1;
+      const bool c = cand(j);
+      const u64 cm = __ballot(c);
+      if (cm) {
+        if (c) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | (j << 8));
+        n_list += __popcll(cm);
+      }
+    }
+    const int count = n_list < 64 ? n_list : 64;
+    HWY_WAVE_LDS_FENCE();
+    const int pair = i < count ? (int)sh.plist[i] : -1;
+    const int left = n_list - count;  // < 64
+    const int carry = i < left ? (int)sh.plist[count + i] : 0;
+    proc(pair);
+    HWY_WAVE_LDS_FENCE();
+    if (i < left) sh.plist[i] = (unsigned short)carry;
+    n_list = left;
+  }
+}
+
 // One walk over the lane table for my body (lane index wave-uniform): membership bits (on_lane margin 1, lane.py:80-102),
 // closest lane (road.py:55-71, lane.py:132-147; minimum distance_with_heading, ties to the lowest table index) and s on
 // the lanes that can matter -> sh.sl[L][i].  Straight lanes first; a CircularLane costs an atan2, and it can neither hold
@@ -246,10 +279,11 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
                                     int *bits_out, int *closest_out, double *lat_tgt_out) {
   constexpr int NH = SH::kNH;
   const int t = threadIdx.x, vi = t & (SH::kCap - 1), half = NH > 1 ? t / SH::kCap : 0;
-  if constexpr (NH > 1) {  // a helper works on the body of vehicle t & 31
-    HWY_WAVE_LDS_FENCE();
-    if (half == 0) { sh.x[vi] = x; sh.y[vi] = y; sh.hd[vi] = h; sh.vw[vi] = tgt | (present ? 256 : 0); }
-    HWY_WAVE_LDS_FENCE();
+  // the poses by slot: a helper lane works on the body of vehicle t & 31, and the arc phase gathers them per pair
+  HWY_WAVE_LDS_FENCE();
+  if (half == 0) { sh.x[vi] = x; sh.y[vi] = y; sh.hd[vi] = h; sh.vw[vi] = tgt | (present ? 256 : 0); }
+  HWY_WAVE_LDS_FENCE();
+  if constexpr (NH > 1) {
     x = sh.x[vi]; y = sh.y[vi]; h = sh.hd[vi];
     const int w = sh.vw[vi];
     tgt = w & 255; present = (w & 256) != 0;
@@ -289,41 +323,65 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
     int none = 0;
     ix_xchg(sh, bd, best, none);  // the arcs are filtered against the best distance over ALL straight lanes
   }
-  for (int k = ns; k < n; k += 2 * NH) {
-    const int k0 = k + half, k1 = k0 + NH;
-    const bool m0 = k0 < n, m1 = k1 < n;
-    const IxRow r0 = sh.row[m0 ? k0 : k], r1 = sh.row[m1 ? k1 : k];
-    const double dx0 = x - r0.a, dy0 = y - r0.b, dx1 = x - r1.a, dy1 = y - r1.b;
-    const double rr0 = sqrt(dx0 * dx0 + dy0 * dy0), rr1 = sqrt(dx1 * dx1 + dy1 * dy1);
-    const double lat0 = r0.d * (r0.c - rr0), lat1 = r1.d * (r1.c - rr1);
-    const bool need0 = m0 && present && (fabs(lat0) <= r0.e || !(fabs(lat0) > bd) || r0.L == tgt);
-    const bool need1 = m1 && present && (fabs(lat1) <= r1.e || !(fabs(lat1) > bd) || r1.L == tgt);
-    if (__ballot(need0 || need1) == 0) {
-      if (m0) sh.sl[r0.L][vi] = 0.0;
-      if (m1) sh.sl[r1.L][vi] = 0.0;
-      continue;
-    }
-    double phi0 = atan2_bounded(dy0, dx0), phi1 = atan2_bounded(dy1, dx1);
-    phi0 = r0.g + wrap_to_pi(phi0 - r0.g);
-    phi1 = r1.g + wrap_to_pi(phi1 - r1.g);
-    const double s0 = r0.d * (phi0 - r0.g) * r0.c, s1 = r1.d * (phi1 - r1.g) * r1.c;
-    const double lh0 = (r0.d * s0 / r0.c + r0.g) + HWY_PI / 2 * r0.d, lh1 = (r1.d * s1 / r1.c + r1.g) + HWY_PI / 2 * r1.d;
-    const bool on0 = fabs(lat0) <= r0.e && -5.0 <= s0 && s0 < r0.f + 5.0;
-    const bool on1 = fabs(lat1) <= r1.e && -5.0 <= s1 && s1 < r1.f + 5.0;
-    const double ang0 = fabs(wrap_to_pi(h - lh0)), ang1 = fabs(wrap_to_pi(h - lh1));
-    const double d0 = fabs(lat0) + fmax(s0 - r0.f, 0.0) + fmax(0 - s0, 0.0) + 1.0 * ang0;
-    const double d1 = fabs(lat1) + fmax(s1 - r1.f, 0.0) + fmax(0 - s1, 0.0) + 1.0 * ang1;
-    if (m0) {
-      bits |= on0 ? (1 << r0.L) : 0;
-      sh.sl[r0.L][vi] = s0;
-      if (d0 < bd || (d0 == bd && r0.L < best)) { bd = d0; best = r0.L; }
-      if (r0.L == tgt) { lat_t = lat0; has_lat = true; }
-    }
-    if (m1) {
-      bits |= on1 ? (1 << r1.L) : 0;
-      sh.sl[r1.L][vi] = s1;
-      if (d1 < bd || (d1 == bd && r1.L < best)) { bd = d1; best = r1.L; }
-      if (r1.L == tgt) { lat_t = lat1; has_lat = true; }
+  // Arcs.  A CircularLane costs an atan2, and most (vehicle, arc) pairs cannot matter: the arc can only hold the vehicle
+  // if |lateral| = |radius - r| <= width / 2 + 1, can only be its closest lane if |lateral| <= the best distance over the
+  // straight lanes (its distance is at least |lateral|), or it is its target lane.  The pairs that pass this filter are
+  // collected and projected one pair per thread (ix_for_pairs); their verdicts meet per vehicle: membership bits (or),
+  // the closest arc (minimum of the distance's bit pattern -- distances are >= 0 --, then the lowest table index among the
+  // arcs at that minimum: the serial rule) and the lateral coordinate on the target lane.
+  const int na = n - ns;
+  if (na > 0) {  // wave-uniform
+    unsigned long long *const dmin = reinterpret_cast<unsigned long long *>(sh.bcx);
+    if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; sh.flag[t] = 0; sh.vlane[t] = 0; }
+    HWY_WAVE_LDS_FENCE();
+    const u64 rows = na >= 64 ? ~(u64)0 : (((u64)1 << na) - 1);
+    ix_for_pairs(
+        sh, NH > 1 ? ((rows | (rows >> 1)) & 0x5555555555555555ull) : rows, vi, half,
+        [&](int j) {
+          if (!(present && j < na)) return false;
+          const IxRow r = sh.row[ns + j];
+          if (r.L == tgt) return true;
+          // |radius - rr| <= m with m = max(width / 2 + 1, best straight distance), on the squares (a filter: 1e-9 of slack)
+          const double dx = x - r.a, dy = y - r.b, r2 = dx * dx + dy * dy;
+          const double m = fmax(r.e, bd) + 1e-9, lo = r.c - m, hi = r.c + m;
+          return (lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi;
+        },
+        [&](int pair) {
+          const int v = pair & 255;
+          unsigned long long key = 0;
+          int L = 0;
+          if (pair >= 0) {
+            const IxRow r = sh.row[ns + (pair >> 8)];
+            const double px = sh.x[v], py = sh.y[v], ph = sh.hd[v];
+            const double dx = px - r.a, dy = py - r.b;
+            const double rr = sqrt(dx * dx + dy * dy);
+            const double lat = r.d * (r.c - rr);
+            double phi = atan2_bounded(dy, dx);
+            phi = r.g + wrap_to_pi(phi - r.g);
+            const double sa = r.d * (phi - r.g) * r.c;
+            const double lane_h = (r.d * sa / r.c + r.g) + HWY_PI / 2 * r.d;
+            const bool on = fabs(lat) <= r.e && -5.0 <= sa && sa < r.f + 5.0;
+            const double angle = fabs(wrap_to_pi(ph - lane_h));
+            const double d = fabs(lat) + fmax(sa - r.f, 0.0) + fmax(0 - sa, 0.0) + 1.0 * angle;
+            L = r.L;
+            sh.sl[L][v] = sa;
+            if (on) __hip_atomic_fetch_or(&sh.flag[v], 1 << L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (L == (sh.vw[v] & 255)) { sh.bcy[v] = lat; sh.vlane[v] = 1; }
+            key = (unsigned long long)__double_as_longlong(d);
+            __hip_atomic_fetch_min(&dmin[v], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          HWY_WAVE_LDS_FENCE();
+          if (pair >= 0 && dmin[v] == key)
+            __hip_atomic_fetch_min(&sh.jmax[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        });
+    HWY_WAVE_LDS_FENCE();
+    const unsigned long long akey = dmin[vi];
+    if (present && akey != ~0ull) {
+      const double ad = __longlong_as_double((long long)akey);
+      const int aL = sh.jmax[vi];
+      if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+      bits |= sh.flag[vi];
+      if (sh.vlane[vi]) { lat_t = sh.bcy[vi]; has_lat = true; }
     }
   }
   ix_xchg(sh, bd, best, bits, &lat_t, has_lat);
@@ -486,39 +544,6 @@ __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &
   }
 }
 
-// ---- pair work: `trips` = the partner slots to visit (wave-uniform mask; with helper lanes bit j stands for the slots j and
-//      j + 1, one per half), cand(j) = "my vehicle and slot j are a candidate pair" (asked with my vehicle as the LOWER slot
-//      only: every unordered pair once), proc(pair) = the expensive evaluation of ONE pair per thread (pair < 0: none).
-//      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
-//      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
-template <typename SH, typename Cand, typename Proc>
-__device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
-  const int i = threadIdx.x;
-  const u64 below = ((u64)1 << i) - 1;
-  int n_list = 0;  // wave-uniform
-  while (trips || n_list) {
-    while (trips && n_list < 64) {
-      const int j = ctz64(trips) + half;
-      trips &= trips - 1;
-      const bool c = cand(j);
-      const u64 cm = __ballot(c);
-      if (cm) {
-        if (c) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | (j << 8));
-        n_list += __popcll(cm);
-      }
-    }
-    const int count = n_list < 64 ? n_list : 64;
-    HWY_WAVE_LDS_FENCE();
-    const int pair = i < count ? (int)sh.plist[i] : -1;
-    const int left = n_list - count;  // < 64
-    const int carry = i < left ? (int)sh.plist[count + i] : 0;
-    proc(pair);
-    HWY_WAVE_LDS_FENCE();
-    if (i < left) sh.plist[i] = (unsigned short)carry;
-    n_list = left;
-  }
-}
-
 // ---- n_frames x { [meta-action]; Road.act(); RegulatedRoad.step(dt) } on the wave's registers + LDS --------------
 template <typename SH>
 __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, int n_frames, const int32_t *actions,
@@ -611,7 +636,14 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
           const int f = ix_front(sh, Lq, i);
           if (f >= 0) {
             // lane_distance_to is measured on MY current lane (objects.py:183-198)
-            const double d = sh.sl[me.lane][f] - sh.sl[me.lane][i];
+            // (the table walk projects a vehicle on an ARC only where the arc can hold it, be its closest lane or its
+            //  target: a leader found on my target lane -- or, with connected lanes, beyond my lane's end -- may have none)
+            double s_f = sh.sl[me.lane][f];
+            if (sh.kind[me.lane] != 0 && !((sh.mask[me.lane] >> f) & 1)) {
+              double lat_f;
+              ix_local(sh, me.lane, sh.x[f], sh.y[f], &s_f, &lat_f);
+            }
+            const double d = s_f - sh.sl[me.lane][i];
             const double dv = (me.v * ch - sh.v[f] * sh.c[f]) * ch + (me.v * shh - sh.v[f] * sh.s[f]) * shh;
             const double d_star = ip.d0 + me.v * ip.tau + (me.v * dv) * inv_ab2;
             const double r = d_star * fast_rcp(not_zero(d));

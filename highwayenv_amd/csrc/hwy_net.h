@@ -246,8 +246,8 @@ __device__ inline void net_update_rank(double x, bool present, u64 pm, int n_pre
 //              first minimum in table order; the straight lanes share the heading term.
 // Straight lanes are walked first (branch-free), the SineLanes (bit set in sine_mask) afterwards.
 template <bool CLOSEST>
-__device__ inline void net_lane_pass(const NetParams &np, const NetShared &sh, unsigned sine_mask, double x, double y, double h,
-                                     int *bits_out, int *closest_out) {
+__device__ inline void net_lane_pass(const NetParams &np, const NetShared &sh, unsigned sine_mask, bool present, double x,
+                                     double y, double h, int *bits_out, int *closest_out) {
   const double angle0 = CLOSEST ? fabs(wrap_to_pi(h - 0.0)) : 0.0;
   const int n = np.n_lanes;
   int bits = 0, best = 0;
@@ -281,6 +281,15 @@ __device__ inline void net_lane_pass(const NetParams &np, const NetShared &sh, u
     const int L = __builtin_ctz(m);
     const hwy_lane &l = np.lane[L];
     const double s = x - l.x0;
+    {
+      // |lateral| >= |y - y0| - |amplitude| and the distance is at least |lateral| + the longitudinal overshoot: when that
+      // bound already exceeds both the membership margin and the best distance so far, the lane can neither hold the
+      // body nor be its closest lane -- for most of an episode no body of the wave is anywhere near the ramp
+      const double lat_lb = fmax(fabs(y - l.y0) - fabs(l.amplitude), 0.0);
+      const double lb = lat_lb + fmax(s - l.length, 0.0) + fmax(0 - s, 0.0);
+      const bool need = (!(lat_lb > l.width / 2 + 1.0 + 1e-9) && -5.0 <= s && s < l.length + 5.0) || (CLOSEST && !(lb > bd + 1e-9));
+      if (__ballot(present && need) == 0) continue;  // (an empty slot's result is discarded by the caller)
+    }
     double sn, cs;
     sincos_bounded(l.pulsation * s + l.phase, &sn, &cs);
     const double r = (y - l.y0) - l.amplitude * sn;
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
   int bits;
   {
     int unused;
-    net_lane_pass<false>(np, sh, sine_mask, me.x, me.y, me.h, &bits, &unused);
+    net_lane_pass<false>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits, &unused);
     bits = present ? bits : 0;
   }
   int rank = 0;
@@ -843,7 +852,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     }
     {
       int cl_new, bits_new;  // on_state_update (kinematics.py:170-177) + the next frame's membership bits
-      net_lane_pass<true>(np, sh, sine_mask, me.x, me.y, me.h, &bits_new, &cl_new);
+      net_lane_pass<true>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new);
       if (veh) me.lane = cl_new;
       bits = present ? bits_new : 0;
     }
@@ -889,36 +898,83 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
           cand |= near ? ((u64)1 << r2) : 0;
         }
       }
-      // Phase 2: every thread's collected partners, one per trip (a handful of trips for the whole wave)
+      // Phase 2: the collected partners are filtered (pair type, checkers, provable separation) and every unordered pair
+      // that survives is listed ONCE, by the thread of its lower slot; phase 3 runs the SAT one PAIR per thread -- one pass
+      // for the whole wave instead of one pass per partner rank -- and the verdicts meet per slot in LDS: crashed flags,
+      // the highest partner slot with a pending impact ("last pair in loop order wins") and that pair's translation.
+      // (the snapshot arrays of this frame are dead here: they hold the per-slot results and the pair list)
       const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, obstacle ? 1.0 : HWY_VEH_LENGTH / 2, obstacle ? 1.0 : HWY_VEH_WIDTH / 2};
-      int best = -1;
-      while (__ballot(cand != 0) != 0) {  // wave-uniform
-        if (cand == 0) continue;
-        const int r2 = ctz64(cand);
-        cand &= cand - 1;
-        const int q = sh.idx[r2];
-        const bool q_obs = sh.kind[r2] == 0;
-        if (obstacle && q_obs) continue;  // road.py:477-481: vehicle-vehicle and vehicle-object pairs only
-        if (!(i_check || ((chk >> q) & 1))) continue;  // objects.py:98
-        const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
-                            q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
-        // provable separation on MY two body axes (any axis of either rectangle is one of the SAT's axes, so which
-        // body plays "A" does not matter for a proof of separation); the ordered pair is only built for the SAT
-        if (net_surely_apart(mine, other, p.dt)) continue;
-        const bool i_first = i < q;
-        const NetBody A = select_nbody(i_first, mine, other), Bb = select_nbody(i_first, other, mine);
-        double tx, ty;
-        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
-        if ((r & 2) && q > best && veh) {  // "last pair in loop order wins" == the partner in the highest slot
-          best = q;
-          // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
-          const double share = q_obs ? 1.0 : 0.5;
-          me.impx = i_first ? tx * share : -tx * share;
-          me.impy = i_first ? ty * share : -ty * share;
-          me.flags |= HWY_F_HAS_IMPACT;
+      int *const jmax = reinterpret_cast<int *>(sh.lr), *const hit = reinterpret_cast<int *>(sh.ox);
+      double *const ipx = sh.v, *const ipy = sh.c;
+      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.scratch);  // 128 entries: rank | partner rank << 8
+      jmax[i] = -1;
+      hit[i] = 0;
+      const u64 below = ((u64)1 << i) - 1;
+      int n_list = 0;  // wave-uniform
+      u64 pending = __ballot(cand != 0);
+      while (pending || n_list) {
+        while (pending && n_list < 64) {
+          bool keep = false;
+          int r2 = 0;
+          if (cand != 0) {
+            r2 = ctz64(cand);
+            cand &= cand - 1;
+            const int q = sh.idx[r2];
+            const bool q_obs = sh.kind[r2] == 0;
+            // every pair once (lower slot); road.py:477-481: vehicle-vehicle and vehicle-object pairs only; objects.py:98
+            if (i < q && !(obstacle && q_obs) && (i_check || ((chk >> q) & 1))) {
+              const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
+                                  q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
+              // provable separation on MY two body axes (any axis of either rectangle is one of the SAT's axes)
+              keep = !net_surely_apart(mine, other, p.dt);
+            }
+          }
+          const u64 km = __ballot(keep);
+          if (km) {
+            if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(rank | (r2 << 8));
+            n_list += __popcll(km);
+          }
+          pending = __ballot(cand != 0);
         }
-        if (r & 1) me.flags |= HWY_F_CRASHED;
+        const int count = n_list < 64 ? n_list : 64, left = n_list - count;
+        HWY_WAVE_LDS_FENCE();
+        const int pair = i < count ? (int)plist[i] : -1;
+        const int carry = i < left ? (int)plist[count + i] : 0;
+        int r = 0, a = 0, b = 0;
+        bool a_veh = false, b_veh = false;
+        double tx = 0.0, ty = 0.0;
+        if (pair >= 0) {
+          const int ra = pair & 255, rb = pair >> 8;
+          a = sh.idx[ra];
+          b = sh.idx[rb];  // a < b: the reference's `self` and `other`
+          a_veh = sh.kind[ra] != 0;
+          b_veh = sh.kind[rb] != 0;
+          const NetBody A{sh.nx[ra], sh.ny[ra], sh.nv[ra], sh.nc[ra], sh.ns[ra], a_veh ? HWY_VEH_LENGTH / 2 : 1.0, a_veh ? HWY_VEH_WIDTH / 2 : 1.0};
+          const NetBody Bb{sh.nx[rb], sh.ny[rb], sh.nv[rb], sh.nc[rb], sh.ns[rb], b_veh ? HWY_VEH_LENGTH / 2 : 1.0, b_veh ? HWY_VEH_WIDTH / 2 : 1.0};
+          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
+          if (r & 1) hit[a] = hit[b] = 1;
+          if (r & 2) {
+            if (a_veh) __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (b_veh) __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        HWY_WAVE_LDS_FENCE();
+        if (r & 2) {  // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
+          const double sa = b_veh ? 0.5 : 1.0, sb = a_veh ? 0.5 : 1.0;
+          if (a_veh && jmax[a] == b) { ipx[a] = tx * sa; ipy[a] = ty * sa; }
+          if (b_veh && jmax[b] == a) { ipx[b] = -tx * sb; ipy[b] = -ty * sb; }
+        }
+        if (i < left) plist[i] = (unsigned short)carry;
+        n_list = left;
+        HWY_WAVE_LDS_FENCE();
       }
+      HWY_WAVE_LDS_FENCE();
+      if (veh && jmax[i] >= 0) {
+        me.impx = ipx[i];
+        me.impy = ipy[i];
+        me.flags |= HWY_F_HAS_IMPACT;
+      }
+      if (present && hit[i]) me.flags |= HWY_F_CRASHED;
     }
   }  // frames
 

@@ -128,6 +128,7 @@ template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = 
 #define __hip_atomic_store(ptr, v, order, scope) (*(ptr) = (v))
 #define __hip_atomic_load(ptr, order, scope) (*(ptr))
 #define __hip_atomic_fetch_min(ptr, v, order, scope) (*(ptr) = (*(ptr) < (v) ? *(ptr) : (v)))
+#define __hip_atomic_fetch_or(ptr, v, order, scope) (*(ptr) |= (v))
 #define __hip_atomic_fetch_max(ptr, v, order, scope) (*(ptr) = (*(ptr) > (v) ? *(ptr) : (v)))
 inline double __longlong_as_double(long long v) { double d; __builtin_memcpy(&d, &v, 8); return d; }
 inline long long __double_as_longlong(double d) { long long v; __builtin_memcpy(&v, &d, 8); return v; }

@@ -120,7 +120,7 @@ def net_ticks(text):
 def ix_ticks(text):
     """s_memtime stamps around the sections of the intersection kernel (hwy_ix.h), accumulated in LDS by thread 0 and
     written over the first observation words of the environment (tools/ix_section_dist.py reads them)."""
-    t = sub("  int vw[kNH > 1 ? CAP : 1];", "  int vw[kNH > 1 ? CAP : 1];\n  long long tk[16]; long long tprev;")(text)
+    t = sub("  int vw[CAP];", "  int vw[CAP];\n  long long tk[16]; long long tprev;")(text)
     t = sub("// ---- lane geometry from the LDS table, per-thread lane index",
             "#define IXTICK(k) { if (threadIdx.x == 0) { const long long t_ = clock64(); sh.tk[k] += t_ - sh.tprev; sh.tprev = t_; } }\n"
             "// ---- lane geometry from the LDS table, per-thread lane index")(t)
