@@ -553,36 +553,78 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
       sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
       const bool wide = __ballot(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
       HWY_WAVE_LDS_FENCE();
-      if (active) {
-        // radius + relative motion, for bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and
-        // are not faster than 50 m/s afterwards (the radius term).  Both are checked on the actual values (`wide`,
-        // wave-uniform): the reference does not clamp speeds (clip_actions only pulls them back, kinematics.py:155-168)
-        // and hwy_set_state accepts any, so a faster body or a larger push turns the scan into the literal all-pairs loop.
-        const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
-        int best = -1;
-        for (int dir = -1; dir <= 1; dir += 2) {
-          for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {
-            if (fabs(sh.x[r2] - x_old) > reach) break;  // sh.x: frame-start x in rank order
-            const int q = sh.idx[r2];
-            const Body other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q]};
-            const double dx = other.x - me.x, dy = other.y - me.y;
-            const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
-            if (dx * dx + dy * dy > lim * lim) continue;
-            const bool i_first = i < q;
-            const Body A = select_body(i_first, mine, other), Bb = select_body(i_first, other, mine);
-            if (surely_apart(A, Bb, p.dt)) continue;
-            double tx, ty;
-            const int r = pair_collide(A, Bb, p.dt, &tx, &ty);
-            if ((r & 2) && q > best) {
-              best = q;
-              sh.impx[i] = i_first ? tx / 2 : -tx / 2;
-              sh.impy[i] = i_first ? ty / 2 : -ty / 2;
-              me.flags |= HWY_F_HAS_IMPACT;
+      // Every unordered pair once, by the thread of its lower slot: the walk only COLLECTS the pairs that pass the sphere
+      // pre-check and the provable-separation test; the SAT then runs one PAIR per thread -- one pass for the whole wave
+      // instead of one per walk step in which some thread met a close partner -- and the verdicts meet per slot in LDS
+      // (crashed flags, the highest partner slot with a pending impact, that pair's translation).  The rank-ordered
+      // snapshot of this frame (v, lr) is dead here and holds the pair list and the per-slot results.
+      int *const jmax = reinterpret_cast<int *>(sh.lr), *const hit = jmax + 64;
+      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.v);  // 256 entries: lower slot | higher slot << 8
+      jmax[i] = -1;
+      hit[i] = 0;
+      // radius + relative motion, for bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and
+      // are not faster than 50 m/s afterwards (the radius term).  Both are checked on the actual values (`wide`,
+      // wave-uniform): the reference does not clamp speeds (clip_actions only pulls them back, kinematics.py:155-168)
+      // and hwy_set_state accepts any, so a faster body or a larger push turns the scan into the literal all-pairs loop.
+      const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      const u64 below = ((u64)1 << i) - 1;
+      int n_list = 0, k = 1;  // wave-uniform
+      bool go_a = active, go_b = active, walking = true;
+      while (walking || n_list) {
+        while (walking && n_list < 64) {
+          const int ra = rank - k, rb = rank + k;
+          go_a = go_a && ra >= 0;
+          go_b = go_b && rb < N;
+          const int ia_ = go_a ? ra : 0, ib_ = go_b ? rb : 0;
+          go_a = go_a && !(fabs(sh.x[ia_] - x_old) > reach);  // sh.x: frame-start x in rank order
+          go_b = go_b && !(fabs(sh.x[ib_] - x_old) > reach);
+          ++k;
+          if (__ballot(go_a || go_b) == 0 || k > N) walking = false;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int q = sh.idx[side ? ib_ : ia_];
+            bool keep = false;
+            if ((side ? go_b : go_a) && i < q) {
+              const Body other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q]};
+              const double dx = other.x - me.x, dy = other.y - me.y;
+              const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
+              keep = !(dx * dx + dy * dy > lim * lim) && !surely_apart(mine, other, p.dt);
             }
-            if (r & 1) me.flags |= HWY_F_CRASHED;
+            const u64 km = __ballot(keep);
+            if (km) {
+              if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i | (q << 8));
+              n_list += __popcll(km);
+            }
           }
         }
+        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
+        HWY_WAVE_LDS_FENCE();
+        const int pair = i < count ? (int)plist[i] : -1;
+        const int c0 = i < left ? (int)plist[count + i] : 0, c1 = 64 + i < left ? (int)plist[count + 64 + i] : 0;
+        const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+        int r = 0;
+        double tx = 0.0, ty = 0.0;
+        if (pair >= 0) {
+          const Body A{sh.nx[a], sh.ny[a], sh.nv[a], sh.nc[a], sh.ns[a]}, Bb{sh.nx[b], sh.ny[b], sh.nv[b], sh.nc[b], sh.ns[b]};
+          r = pair_collide(A, Bb, p.dt, &tx, &ty);
+          if (r & 1) hit[a] = hit[b] = 1;
+          if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
+            __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        HWY_WAVE_LDS_FENCE();
+        if (r & 2) {
+          if (jmax[a] == b) { sh.impx[a] = tx / 2; sh.impy[a] = ty / 2; }
+          if (jmax[b] == a) { sh.impx[b] = -tx / 2; sh.impy[b] = -ty / 2; }
+        }
+        if (i < left) plist[i] = (unsigned short)c0;
+        if (64 + i < left) plist[64 + i] = (unsigned short)c1;
+        n_list = left;
+        HWY_WAVE_LDS_FENCE();
       }
+      if (active && jmax[i] >= 0) me.flags |= HWY_F_HAS_IMPACT;
+      if (active && hit[i]) me.flags |= HWY_F_CRASHED;
     } else {
       // sparse checkers (highway-fast-v0: the ego only)
       u64 cm = chk;
