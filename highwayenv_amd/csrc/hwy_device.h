@@ -311,6 +311,11 @@ struct EnvBlock {
     u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
     u64 bal0[NW], bal1[NW], bal2[NW];
     u64 chk[NW];                  // vehicles with check_collisions (index space)
+    // full pairwise collisions: per-wavefront list of candidate pairs (lower index | higher index << 8) and the per-vehicle
+    // verdicts they meet in (highest partner with a pending impact, crashed flag, that pair's translation: aux1 / ipy)
+    unsigned short plist[NW][256];
+    int jmax[NV], hit[NV];
+    double ipy[NV];
   };
 
   // ---- workgroup-wide ballot: out[w] = ballot of wave w.  Must be called by ALL threads.
@@ -1056,30 +1061,79 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
       // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the scan is the literal all-pairs loop
       const bool wide = __syncthreads_or(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
-      if (active) {
-        const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
-        int best = -1;
-        for (int dir = -1; dir <= 1; dir += 2) {
-          for (int r2 = rank + dir; r2 >= 0 && r2 < N; r2 += dir) {
-            const int q = sh.perm[r2];
-            if (fabs(sh.aux0[q] - x_old) > reach) break;
-            const double dx = sh.x[q] - me.x, dy = sh.y[q] - me.y;
-            const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.v[q])) * p.dt;
-            if (dx * dx + dy * dy > lim * lim) continue;
-            const int a = i < q ? i : q, b = i < q ? q : i;
-            if (B::surely_apart(sh, a, b, p.dt)) continue;
-            double tx, ty;
-            const int r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
-            if ((r & 2) && q > best) {
-              best = q;
-              me.impx = (i == a) ? tx / 2 : -tx / 2;
-              me.impy = (i == a) ? ty / 2 : -ty / 2;
-              me.flags |= HWY_F_HAS_IMPACT;
+      // Every unordered pair once, by the thread of its lower index: the walk only COLLECTS the pairs that pass the sphere
+      // pre-check and the provable-separation test (one list per wavefront); the SAT then runs one PAIR per thread, and the
+      // verdicts meet per vehicle in LDS -- across wavefronts, hence the workgroup barrier between "highest partner with a
+      // pending impact" (ds_max) and the winner's write of its translation (hwy_wave.h has the one-wavefront version).
+      unsigned short *const plist = sh.plist[i >> 6];
+      const int lane_id_ = i & 63;
+      sh.jmax[i] = -1;
+      sh.hit[i] = 0;
+      __syncthreads();
+      const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      const u64 below = ((u64)1 << lane_id_) - 1;
+      const Body mine{me.x, me.y, me.v, me.ch, me.sh};
+      int n_list = 0, k = 1;  // wave-uniform
+      bool go_a = active, go_b = active, walking = true;
+      for (;;) {
+        while (walking && n_list < 64) {
+          const int ra = rank - k, rb = rank + k;
+          go_a = go_a && ra >= 0;
+          go_b = go_b && rb < N;
+          const int qa = sh.perm[go_a ? ra : 0], qb = sh.perm[go_b ? rb : 0];
+          go_a = go_a && !(fabs(sh.aux0[qa] - x_old) > reach);  // sh.aux0: frame-start x by index
+          go_b = go_b && !(fabs(sh.aux0[qb] - x_old) > reach);
+          ++k;
+          if (__ballot(go_a || go_b) == 0 || k > N) walking = false;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int q = side ? qb : qa;
+            bool keep = false;
+            if ((side ? go_b : go_a) && i < q) {
+              const Body other{sh.x[q], sh.y[q], sh.v[q], sh.c[q], sh.s[q]};
+              const double dx = other.x - me.x, dy = other.y - me.y;
+              const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
+              keep = !(dx * dx + dy * dy > lim * lim) && !hwy::surely_apart(mine, other, p.dt);
             }
-            if (r & 1) me.flags |= HWY_F_CRASHED;
+            const u64 km = __ballot(keep);
+            if (km) {
+              if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i | (q << 8));
+              n_list += __popcll(km);
+            }
           }
         }
+        if (__syncthreads_or(walking || n_list > 0) == 0) break;  // block-uniform
+        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
+        const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
+        const int c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
+        const int c1 = 64 + lane_id_ < left ? (int)plist[count + 64 + lane_id_] : 0;
+        const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+        int r = 0;
+        double tx = 0.0, ty = 0.0;
+        if (pair >= 0) {
+          r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
+          if (r & 1) sh.hit[a] = sh.hit[b] = 1;
+          if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
+            __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        __syncthreads();
+        if (r & 2) {
+          if (sh.jmax[a] == b) { sh.aux1[a] = tx / 2; sh.ipy[a] = ty / 2; }
+          if (sh.jmax[b] == a) { sh.aux1[b] = -tx / 2; sh.ipy[b] = -ty / 2; }
+        }
+        if (lane_id_ < left) plist[lane_id_] = (unsigned short)c0;
+        if (64 + lane_id_ < left) plist[64 + lane_id_] = (unsigned short)c1;
+        n_list = left;
       }
+      __syncthreads();
+      if (active && sh.jmax[i] >= 0) {
+        me.impx = sh.aux1[i];
+        me.impy = sh.ipy[i];
+        me.flags |= HWY_F_HAS_IMPACT;
+      }
+      if (active && sh.hit[i]) me.flags |= HWY_F_CRASHED;
     } else {
       // sparse checkers (highway-fast-v0: the ego only): for each checker c, thread q evaluates the pair
       // {c, q}; q applies it to itself (ascending c == loop order), c gathers from all q.

@@ -34,6 +34,7 @@ struct Fiber {
   emu_dim3 tid, bid, bdim;
   unsigned ballot_phase = 0;
   unsigned xchg_phase = 0;
+  unsigned bor_phase = 0;
   bool finished = false;
   char *stack = nullptr;
 };
@@ -60,6 +61,21 @@ inline void barrier() {
     while (bar_gen == gen) yield();
   }
 }
+// rendezvous of the (up to) 64 fibers of ONE wavefront: ballots / readlane / ds_permute are wave-level operations, and the
+// wavefronts of a multi-wave workgroup may execute different numbers of them between two workgroup barriers
+inline int wbar_count[16];
+inline unsigned wbar_gen[16];
+inline void wave_barrier() {
+  const int w = cur->tid.x >> 6;
+  const int size = n_fibers - 64 * w < 64 ? n_fibers - 64 * w : 64;
+  const unsigned gen = wbar_gen[w];
+  if (++wbar_count[w] == size) {
+    wbar_count[w] = 0;
+    ++wbar_gen[w];
+  } else {
+    while (wbar_gen[w] == gen) yield();
+  }
+}
 }  // namespace emu
 
 #define threadIdx (emu::cur->tid)
@@ -79,16 +95,16 @@ inline unsigned long long __ballot(int pred) {
   unsigned long long &acc = emu::g_ballot[emu::cur->ballot_phase & 1][wave];
   emu::cur->ballot_phase++;
   if (pred) acc |= 1ull << lane;
-  emu::barrier();
+  emu::wave_barrier();
   const unsigned long long v = acc;
-  emu::barrier();
+  emu::wave_barrier();
   if (lane == 0) acc = 0;  // reused two ballots later, with >= 1 rendezvous in between
   return v;
 }
 inline int __syncthreads_or(int pred) {  // barrier + OR of the predicate over the whole workgroup
-  unsigned long long any = __ballot(pred);  // per-wave OR (two rendezvous) ...
+  unsigned long long any = __ballot(pred);  // per-wave OR (two wave rendezvous) ...
   __shared__ unsigned long long acc[2];
-  const unsigned ph = emu::cur->ballot_phase & 1;  // (advanced once per call by the __ballot above, uniformly)
+  const unsigned ph = emu::cur->bor_phase++ & 1;  // (its own counter: the wavefronts' ballot counts may differ)
   if (any) acc[ph] = 1;
   emu::barrier();
   const int v = acc[ph] != 0;
@@ -106,13 +122,13 @@ namespace emu {
 inline int readlane(int v, int lane) {
   int *buf = g_xchg[cur->xchg_phase++ & 1];
   buf[threadIdx.x] = v;
-  barrier();
+  wave_barrier();
   return buf[(threadIdx.x & ~63) + (lane & 63)];
 }
 inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 (a permutation in our use)
   int *buf = g_xchg[cur->xchg_phase++ & 1];
   buf[(threadIdx.x & ~63) + ((addr >> 2) & 63)] = v;
-  barrier();
+  wave_barrier();
   return buf[threadIdx.x];
 }
 }  // namespace emu
@@ -164,6 +180,7 @@ void launch(K kernel, int grid, int block, const P &params) {
   n_fibers = block;
   bar_count = 0;
   bar_gen = 0;
+  for (int w = 0; w < 16; ++w) { wbar_count[w] = 0; wbar_gen[w] = 0; }
   g_done = 0;
   g_grid = grid;
   for (auto &row : g_ballot)
