@@ -196,6 +196,43 @@ def test_autoreset_next_step_semantics(backend):
     eng.close()
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_when_the_next_episode_is_prepared_cannot_change_any_result(backend):
+    """hwy_config.tune_ix_no_prewarm / tune_ix_prewarm_frames only move the warm-up frames of an environment's NEXT episode
+    between launches (inline at the auto-reset, 15 frames per launch, the default third of a step, 2 frames): the episodes --
+    two controlled vehicles, random destinations -- must be the same BIT FOR BIT."""
+    E = 6
+    rng = np.random.default_rng(11)
+    acts = rng.integers(0, 3, size=(9, E, 2)).astype(np.int32)
+    runs = []
+    for tuning in ({"ix_no_prewarm": 1}, {"ix_prewarm_frames": 15}, None, {"ix_prewarm_frames": 2}):
+        cfg = hix.intersection_default_config()
+        cfg.update(max_vehicles=24, duration=3, controlled_vehicles=2, destination=None)
+        eng = make_engine(backend, _abi.make_config(cfg, E, scenario="intersection", tuning=tuning))
+        eng.reset(seeds=np.uint64(77) + np.arange(E, dtype=np.uint64))
+        eng.set_autoreset(True, base_seed=77)
+        rows = []
+        for t in range(acts.shape[0]):
+            out = eng.step(acts[t])
+            st = eng.get_state()
+            pres = (st["flags"] & _abi.F_ABSENT) == 0
+            rows.append((out[0].copy(), out[1].copy(), out[2].copy(), out[3].copy(),
+                         {k: np.where(pres, v, 0) for k, v in st.items() if v.ndim == 2}))
+        runs.append(rows)
+        eng.close()
+    n_done = 0
+    for other in runs[1:]:
+        for (o0, r0, t0, u0, s0), (o1, r1, t1, u1, s1) in zip(runs[0], other):
+            np.testing.assert_array_equal(o0, o1)
+            np.testing.assert_array_equal(r0, r1)
+            np.testing.assert_array_equal(t0, t1)
+            np.testing.assert_array_equal(u0, u1)
+            for k in s0:
+                np.testing.assert_array_equal(s0[k], s1[k], err_msg=k)
+            n_done += int((t0 | u0).sum())
+    assert n_done >= 3 * E  # every variant went through auto-resets
+
+
 @pytest.mark.gpu
 def test_spawn_counters_report_what_the_slot_cap_drops():
     """The reference's vehicle list is unbounded (intersection_env.py:324-352); the engine has ``max_vehicles`` slots and
