@@ -373,13 +373,20 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           HWY_WAVE_LDS_FENCE();
           if (pair >= 0 && dmin[v] == key)
             __hip_atomic_fetch_min(&sh.jmax[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          HWY_WAVE_LDS_FENCE();
+          // the owners fold THIS pass's closest arc into their running minimum and clear the slots: a later pass (more than
+          // 64 candidate pairs) starts over, so "lowest index among the arcs at the minimum" never mixes two passes
+          const unsigned long long akey = dmin[vi];
+          if (present && akey != ~0ull) {
+            const double ad = __longlong_as_double((long long)akey);
+            const int aL = sh.jmax[vi];
+            if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+          }
+          HWY_WAVE_LDS_FENCE();
+          if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; }
         });
     HWY_WAVE_LDS_FENCE();
-    const unsigned long long akey = dmin[vi];
-    if (present && akey != ~0ull) {
-      const double ad = __longlong_as_double((long long)akey);
-      const int aL = sh.jmax[vi];
-      if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+    if (present) {
       bits |= sh.flag[vi];
       if (sh.vlane[vi]) { lat_t = sh.bcy[vi]; has_lat = true; }
     }
