@@ -93,3 +93,33 @@ def test_env_api_exposes_grid_shape():
     env2 = Emu(g.config, num_envs=3)
     obs, _ = env2.reset(seed=0)
     np.testing.assert_allclose(obs, g.z["obs0"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("half,step", [(15.0, 1.0), (20.0, 1.0), (27.5, 5.0)])
+def test_intersection_grid_workspace_paths_agree_with_the_oracle(backend, half, step):
+    """csrc/hwy_ix.h keeps the OccupancyGrid's workspace in LDS when it fits and paints only the DISTINCT clipped waypoints of
+    every lane from a list that has to fit too: 30 x 30 cells = LDS without the list, 40 x 40 cells = the global workspace
+    (the other scenarios' path), 11 x 11 = BASELINE config 4 (LDS + list).  Same cells either way."""
+    from highwayenv_amd import intersection as hix
+    from oracle import oracle_ix
+    from tests.golden_util import ix_oracle_config, ix_oracle_state
+    cfg_d = hix.intersection_default_config()
+    # (borders off the waypoint lattice: see the knife edge described in tests/test_fuzz_configs.py)
+    cfg_d["observation"] = {"type": "OccupancyGrid", "grid_size": [[-half - 0.3, half - 0.3], [-half + 0.2, half + 0.2]],
+                            "grid_step": [step, step], "features": ["presence", "vx", "vy", "on_road"],
+                            "align_to_vehicle_axes": step == 1.0 and half == 20.0}
+    cfg_d.update(max_vehicles=30, host_traffic=True)
+    E = 4
+    c = _abi.make_config(cfg_d, E, scenario="intersection")
+    eng = make_engine(backend, c)
+    obs = eng.reset(seeds=np.arange(E, dtype=np.uint64) + 5)
+    st = eng.get_state()
+    want = oracle_ix.observe(ix_oracle_config(cfg_d, c, E), ix_oracle_state(st, c))
+    assert want[:, -1].sum() > 10  # the on-road layer is not empty
+    np.testing.assert_allclose(obs[:, 0], want, rtol=0, atol=1e-6)
+    for t in range(2):
+        obs = eng.step(np.ones((E, 1), np.int32))[0]
+        want = oracle_ix.observe(ix_oracle_config(cfg_d, c, E), ix_oracle_state(eng.get_state(), c))
+        np.testing.assert_allclose(obs[:, 0], want, rtol=0, atol=1e-6)
+    eng.close()
