@@ -241,11 +241,11 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double 
 //      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
 template <typename SH, typename Cand, typename Proc>
 __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
-  const int i = threadIdx.x;
+  const int i = threadIdx.x, width = (int)blockDim.x;  // pairs per pass: 64, or 32 in the 32-thread build
   const u64 below = ((u64)1 << i) - 1;
   int n_list = 0;  // wave-uniform
   while (trips || n_list) {
-    while (trips && n_list < 64) {
+    while (trips && n_list < width) {
       const int j = ctz64(trips) + half;
       trips &= trips - 1;
       const bool c = cand(j);
@@ -255,10 +255,10 @@ __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand ca
         n_list += __popcll(cm);
       }
     }
-    const int count = n_list < 64 ? n_list : 64;
+    const int count = n_list < width ? n_list : width;
     HWY_WAVE_LDS_FENCE();
     const int pair = i < count ? (int)sh.plist[i] : -1;
-    const int left = n_list - count;  // < 64
+    const int left = n_list - count;  // < width
     const int carry = i < left ? (int)sh.plist[count + i] : 0;
     proc(pair);
     HWY_WAVE_LDS_FENCE();

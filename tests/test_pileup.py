@@ -100,8 +100,9 @@ def test_merge_pileup_needs_several_passes(backend):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("slots", [30, 48])  # helper-lane build (32 slots) / 64-slot build
-def test_intersection_pileup_needs_several_passes(backend, slots):
+@pytest.mark.parametrize("slots,tuning", [(30, None), (30, {"ix_no_helpers": 1}), (48, None)],
+                         ids=["helper-lanes", "32-threads", "64-slots"])  # the three builds of csrc/hwy_ix.h
+def test_intersection_pileup_needs_several_passes(backend, slots, tuning):
     """A crowd inside the junction: hundreds of collision candidates, regulation conflicts and (vehicle, arc) projections in
     one frame -- the frame is a regulation frame (RegulatedRoad.steps % 7 == 6 before it)."""
     from highwayenv_amd import intersection as hix
@@ -110,7 +111,7 @@ def test_intersection_pileup_needs_several_passes(backend, slots):
     cfg_d = hix.intersection_default_config()
     cfg_d.update(max_vehicles=slots, initial_vehicle_count=slots - 4, spawn_probability=1.0, host_traffic=True)
     E = 3
-    c = _abi.make_config(cfg_d, E, scenario="intersection")
+    c = _abi.make_config(cfg_d, E, scenario="intersection", tuning=tuning)
     eng = make_engine(backend, c)
     eng.reset(seeds=np.arange(E, dtype=np.uint64) + 21)
     st = eng.get_state()
