@@ -528,6 +528,38 @@ class ConnectedLaneMultiAgentIntersectionEnv(_SingleIntersectionMixin, BatchedCo
     """Drop-in for ``highway_env.envs.intersection_env.ConnectedLaneMultiAgentIntersectionEnv``."""
 
 
+class _MultiAgentWrapperMixin:
+    """``MultiAgentWrapper`` (envs/common/abstract.py:468-477), which the reference registers on top of the
+    ``intersection-multi-agent-v1`` / ``-v2`` ids: ``reward`` and ``terminated`` become the per-agent tuples of the info dict."""
+
+    def step(self, action):
+        obs, _, _, truncated, info = super().step(action)
+        return obs, info["agents_rewards"], info["agents_terminated"], truncated, info
+
+
+class MultiAgentIntersectionEnvV1(_MultiAgentWrapperMixin, MultiAgentIntersectionEnv):
+    """Drop-in for ``gym.make("intersection-multi-agent-v1")``: MultiAgentIntersectionEnv under MultiAgentWrapper."""
+
+
+class MultiAgentIntersectionEnvV2(_MultiAgentWrapperMixin, ConnectedLaneMultiAgentIntersectionEnv):
+    """Drop-in for ``gym.make("intersection-multi-agent-v2")``: ConnectedLaneMultiAgentIntersectionEnv under MultiAgentWrapper."""
+
+
+class _BatchedMultiAgentWrapperMixin:
+    def step(self, action):
+        obs, _, _, truncated, info = super().step(action)
+        return obs, info["agents_rewards"], info["agents_terminated"], truncated, info
+
+
+class BatchedMultiAgentIntersectionEnvV1(_BatchedMultiAgentWrapperMixin, BatchedMultiAgentIntersectionEnv):
+    """E parallel ``intersection-multi-agent-v1``: ``reward`` [E, A] and ``terminated`` [E, A] per agent (the auto-reset of the
+    engine still follows the ENVIRONMENT's terminated | truncated)."""
+
+
+class BatchedMultiAgentIntersectionEnvV2(_BatchedMultiAgentWrapperMixin, BatchedConnectedLaneMultiAgentIntersectionEnv):
+    """E parallel ``intersection-multi-agent-v2``."""
+
+
 class BatchedConnectedLaneIntersectionEnv(_ConnectedLaneNeighboursMixin, BatchedIntersectionEnv):
     """E parallel ``intersection-v2`` environments (ConnectedLaneIntersectionEnv, intersection_env.py:423)."""
 
@@ -553,9 +585,9 @@ class ConnectedLaneMergeGenericEnv(_SingleMergeMixin, BatchedConnectedLaneMergeG
 
 
 # The ids `highway_env/__init__.py:30-190` registers for this path (gym.make(id) -> the entry-point class): single
-# environment and batched class.  Ids of scenarios outside the path (parking, racetrack, roundabout, ...), the
-# continuous-action intersection id and the ids that wrap the multi-agent intersection in MultiAgentWrapper
-# (intersection-multi-agent-v1 / -v2: reward = info["agents_rewards"], terminated = info["agents_terminated"]) raise KeyError.
+# environment and batched class (the -v1 / -v2 multi-agent intersection ids are the reference's classes under its
+# MultiAgentWrapper: the drop-ins fold the wrapper in).  Ids of scenarios outside the path (parking, racetrack, roundabout,
+# ...) and the continuous-action intersection id raise KeyError.
 REGISTRY = {
     "highway-v0": (HighwayEnv, BatchedHighwayEnv),
     "highway-fast-v0": (HighwayEnvFast, BatchedHighwayEnvFast),
@@ -566,6 +598,8 @@ REGISTRY = {
     "intersection-v0": (IntersectionEnv, BatchedIntersectionEnv),
     "intersection-v2": (ConnectedLaneIntersectionEnv, BatchedConnectedLaneIntersectionEnv),
     "intersection-multi-agent-v0": (MultiAgentIntersectionEnv, BatchedMultiAgentIntersectionEnv),
+    "intersection-multi-agent-v1": (MultiAgentIntersectionEnvV1, BatchedMultiAgentIntersectionEnvV1),
+    "intersection-multi-agent-v2": (MultiAgentIntersectionEnvV2, BatchedMultiAgentIntersectionEnvV2),
 }
 
 

@@ -299,11 +299,18 @@ def test_registry_mirrors_the_reference_ids():
     ref = {"highway-v0": "HighwayEnv", "highway-fast-v0": "HighwayEnvFast", "merge-v0": "MergeEnv",
            "merge-v1": "ConnectedLaneMergeEnv", "merge-generic-v0": "MergeGenericEnv",
            "merge-generic-v1": "ConnectedLaneMergeGenericEnv", "intersection-v0": "IntersectionEnv",
-           "intersection-v2": "ConnectedLaneIntersectionEnv", "intersection-multi-agent-v0": "MultiAgentIntersectionEnv"}
+           "intersection-v2": "ConnectedLaneIntersectionEnv", "intersection-multi-agent-v0": "MultiAgentIntersectionEnv",
+           # the reference registers these two as MultiAgentIntersectionEnv / ConnectedLaneMultiAgentIntersectionEnv UNDER its
+           # MultiAgentWrapper (highway_env/__init__.py:76-85); the drop-in classes fold the wrapper in
+           "intersection-multi-agent-v1": "MultiAgentIntersectionEnvV1", "intersection-multi-agent-v2": "MultiAgentIntersectionEnvV2"}
     assert {k: v[0].__name__ for k, v in envs.REGISTRY.items()} == ref
+    assert issubclass(envs.MultiAgentIntersectionEnvV1, envs.MultiAgentIntersectionEnv)
+    assert issubclass(envs.MultiAgentIntersectionEnvV2, envs.ConnectedLaneMultiAgentIntersectionEnv)
     for env_id, (single, batched) in envs.REGISTRY.items():
-        assert issubclass(single, batched)
-        assert single.default_config()["neighbour_vehicles_connected_lanes"] is env_id.endswith(("-v1", "-v2"))
+        # (the wrapped ids: single and batched classes each fold the wrapper over the same batched engine class)
+        assert issubclass(single, batched if "agent-v1" not in env_id and "agent-v2" not in env_id else batched.__mro__[2])
+        connected = env_id.endswith(("-v1", "-v2")) and env_id != "intersection-multi-agent-v1"
+        assert single.default_config()["neighbour_vehicles_connected_lanes"] is connected
     with pytest.raises(KeyError):
         envs.make("parking-v0")
     with pytest.raises(RuntimeError):  # no GPU in the build container: loud, no fallback
@@ -349,7 +356,7 @@ print("REGISTERED", len(reg.registry))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "REGISTERED 18" in r.stdout
+    assert "REGISTERED 22" in r.stdout
 
 
 def test_action_tables_longitudinal_or_lateral_only():
@@ -440,6 +447,25 @@ def test_multi_agent_intersection_default_config_is_the_references():
     assert envs.REGISTRY["intersection-multi-agent-v0"][0] is envs.MultiAgentIntersectionEnv
     with pytest.raises(ValueError, match="1..4 controlled vehicles"):
         envs.BatchedMultiAgentIntersectionEnv({"controlled_vehicles": 5})
+
+
+class EmuMultiAgentIntersectionV1(envs._MultiAgentWrapperMixin, EmuMultiAgentIntersection):
+    pass
+
+
+def test_multi_agent_wrapper_ids_hand_out_the_per_agent_tuples():
+    """intersection-multi-agent-v1 (MultiAgentWrapper, abstract.py:468-477): reward = info["agents_rewards"], terminated =
+    info["agents_terminated"] -- the reference's recorded per-agent values."""
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection("intersection_multi_agent")
+    env = EmuMultiAgentIntersectionV1(dict(g.config))
+    env.reset(seed=int(g.z["seeds"][1]))
+    obs, reward, terminated, truncated, info = env.step(tuple(int(a) for a in g.actions[0, 1]))
+    assert isinstance(reward, tuple) and isinstance(terminated, tuple) and len(reward) == g.A
+    np.testing.assert_allclose(reward, g.z["agents_rewards"][0, 1], atol=1e-9)
+    assert terminated == tuple(bool(b) for b in g.z["agents_terminated"][0, 1]) and truncated == bool(g.z["truncated"][0, 1])
+    assert envs.REGISTRY["intersection-multi-agent-v1"][0].__mro__[1] is envs._MultiAgentWrapperMixin
+    env.close()
 
 
 @pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
