@@ -38,6 +38,7 @@ C_HOST_TRAFFIC = 256
 C_CONNECTED_LANES = 512
 C_OBS_UNSORTED = 1024
 C_OBS_VEHICLES_ONLY = 2048
+C_OBS_INTENTIONS = 4096
 OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
 HWY_MAX_GRID_CELLS = 65536
 
@@ -452,12 +453,12 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         flags |= C_OBS_UNSORTED       # close_objects_to(sort=False); envs.py shuffles the rows on env.np_random
     if not grid and not obs.get("include_obstacles", True):
         flags |= C_OBS_VEHICLES_ONLY  # (only the merge scenarios have objects)
+    if not grid and obs.get("observe_intentions", False):
+        flags |= C_OBS_INTENTIONS     # (cos_d / sin_d of the other vehicles; zeros anyway where nothing has a route)
     if ix:
         for name in feats:
-            if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h") + (("on_road",) if grid else ()):
+            if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h") + (("on_road",) if grid else ("cos_d", "sin_d")):
                 raise NotImplementedError(f"feature {name!r} is out of scope for the intersection scenario")
-        if obs.get("observe_intentions", False):
-            raise NotImplementedError("observe_intentions is out of scope")
         if cfg.get("host_traffic", False):
             flags |= C_HOST_TRAFFIC
     if merge:

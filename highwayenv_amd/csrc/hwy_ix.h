@@ -994,6 +994,24 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
   const u64 egos = __ballot(controlled);
   if (egos == 0) return;
   const int V = p.V, F = p.F;
+  // Vehicle.destination_direction (kinematics.py:211-235) for the cos_d / sin_d features: the unit vector towards the end of
+  // the LAST lane of my route (zeros without a route or at the destination itself)
+  double dest_x = 0.0, dest_y = 0.0;
+  {
+    bool wanted = false;  // wave-uniform
+    for (int f = 0; f < F; ++f) wanted |= p.feat[f] == HWY_FEAT_COS_D || p.feat[f] == HWY_FEAT_SIN_D;
+    if (wanted && present && route_len(me.route) > 0) {
+      const int last = route_at(me.route, route_len(me.route) - 1);
+      double px, py;
+      ix_position(sh, last, sh.len[last], &px, &py);
+      const double ex = px - me.x, ey = py - me.y;
+      if (ex != 0.0 || ey != 0.0) {
+        const double nrm = sqrt(ex * ex + ey * ey);
+        dest_x = ex / nrm;
+        dest_y = ey / nrm;
+      }
+    }
+  }
   // MultiAgentObservation.observe (observation.py:733-734): agent a == the a-th controlled vehicle of the list
   int a = 0;
   for (u64 am = egos; am && a < p.A; am &= am - 1, ++a) {
@@ -1028,6 +1046,10 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
         double val = fid == HWY_FEAT_PRESENCE ? 1.0 : fid == HWY_FEAT_X ? me.x : fid == HWY_FEAT_Y ? me.y
                    : fid == HWY_FEAT_VX ? me.v * ch : fid == HWY_FEAT_VY ? me.v * shh : fid == HWY_FEAT_HEADING ? me.h
                    : fid == HWY_FEAT_COS_H ? ch : fid == HWY_FEAT_SIN_H ? shh : 0.0;
+        // to_dict(origin, observe_intentions) zeroes the destination of the OTHER vehicles unless intentions are observed;
+        // the observer's own row is to_dict() with the default True (observation.py:239,253; kinematics.py:255-256)
+        if ((fid == HWY_FEAT_COS_D || fid == HWY_FEAT_SIN_D) && (row == 0 || (p.flags & HWY_C_OBS_INTENTIONS)))
+          val = fid == HWY_FEAT_COS_D ? dest_x : dest_y;
         const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
         if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
           const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ech : ev * esh;

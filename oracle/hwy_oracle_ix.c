@@ -44,9 +44,9 @@
 #define IX_MAX_LANES 32
 #define IX_MAX_ROUTE 8 /* the multi-agent default sends its second car round another arm: 6 roads */
 #define IX_MAX_AGENTS 4
-#define IX_MAX_FEATURES 8
+#define IX_MAX_FEATURES 16
 
-enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_ON_ROAD = 13 };
+enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_COS_D, FEAT_SIN_D, FEAT_ON_ROAD = 13 };
 enum { ACT_SLOWER = 0, ACT_IDLE = 1, ACT_FASTER = 2 }; /* IntersectionEnv.ACTIONS, intersection_env.py:14 */
 
 typedef struct {
@@ -74,7 +74,8 @@ typedef struct {
   int32_t outer_node[4];  /* node id of "o" + k */
   int32_t obs_type, grid_align, grid_shape[2]; /* obs_type 1: OccupancyGridObservation (observation.py:279-499) */
   double grid_min[2], grid_step[2];
-  int32_t num_agents, pad_; /* controlled_vehicles: MultiAgentIntersectionEnv (intersection_env.py:348-399) */
+  int32_t num_agents;      /* controlled_vehicles: MultiAgentIntersectionEnv (intersection_env.py:348-399) */
+  int32_t obs_intentions;  /* KinematicObservation.observe_intentions (observation.py:171,253) */
   ix_lane lanes[IX_MAX_LANES];
 } ix_config;
 
@@ -672,6 +673,44 @@ static void road_step(road_t *r, double dt) {
 }
 
 /* ---- observation (observation.py:234-276, road.py:421-450, kinematics.py:237-261) ------------------------- */
+/* Vehicle.destination / destination_direction (kinematics.py:211-235): the end of the LAST lane of the route (lane id None
+ * -> 0), or the position itself without a route; the unit vector towards it, or zeros when they coincide */
+static void destination_direction(const ix_config *c, const veh_t *v, double *dx, double *dy) {
+  *dx = *dy = 0;
+  if (v->route_len <= 0) return;
+  int q = v->route_len - 1;
+  int L = lane_index_of(c, v->route_from[q], v->route_to[q], v->route_id[q] < 0 ? 0 : v->route_id[q]);
+  if (L < 0) return;
+  double px, py;
+  lane_position(&c->lanes[L], c->lanes[L].length, 0, &px, &py);
+  double ex = px - v->x, ey = py - v->y;
+  if (ex != 0 || ey != 0) {
+    double n = sqrt(ex * ex + ey * ey);
+    *dx = ex / n;
+    *dy = ey / n;
+  }
+}
+static double feature_of_c(const ix_config *c, const veh_t *v, int fid, int observed_by_another) {
+  if (fid == FEAT_COS_D || fid == FEAT_SIN_D) {
+    /* to_dict(origin, observe_intentions): zeroed for the OTHER vehicles unless intentions are observed; the observer's
+     * own row is to_dict() with the default True (observation.py:239,253; kinematics.py:255-256) */
+    if (observed_by_another && !c->obs_intentions) return 0;
+    double dx, dy;
+    destination_direction(c, v, &dx, &dy);
+    return fid == FEAT_COS_D ? dx : dy;
+  }
+  switch (fid) {
+    case FEAT_PRESENCE: return 1;
+    case FEAT_X: return v->x;
+    case FEAT_Y: return v->y;
+    case FEAT_VX: return v->speed * cos(v->heading);
+    case FEAT_VY: return v->speed * sin(v->heading);
+    case FEAT_HEADING: return v->heading;
+    case FEAT_COS_H: return cos(v->heading);
+    case FEAT_SIN_H: return sin(v->heading);
+  }
+  return 0;
+}
 static double feature_of(const veh_t *v, int fid) {
   switch (fid) {
     case FEAT_PRESENCE: return 1;
@@ -717,7 +756,7 @@ static void observe_agent(const road_t *r, int ego_idx, float *obs) {
       double val = 0;
       if (row <= m) {
         const veh_t *v = row == 0 ? ego : &r->v[close[row - 1].idx];
-        val = feature_of(v, fid);
+        val = feature_of_c(c, v, fid, row > 0);
         if (row > 0 && !c->obs_absolute && (fid == FEAT_X || fid == FEAT_Y || fid == FEAT_VX || fid == FEAT_VY))
           val -= feature_of(ego, fid);
         if (c->obs_normalize) {

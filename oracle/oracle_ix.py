@@ -11,8 +11,8 @@ import numpy as np
 
 from . import oracle as _base
 
-IX_MAX_LANES, IX_MAX_ROUTE, IX_MAX_FEATURES = 32, 4, 8
-FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7, "on_road": 13}
+IX_MAX_LANES, IX_MAX_ROUTE, IX_MAX_FEATURES = 32, 8, 16
+FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7, "cos_d": 8, "sin_d": 9, "on_road": 13}
 LANE_F64 = ["sx", "sy", "ex", "ey", "heading", "dirx", "diry", "cx", "cy", "radius", "start_phase", "end_phase",
             "length", "width", "speed_limit"]
 LANE_I32 = ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "id"]
@@ -44,7 +44,7 @@ class IxConfig(C.Structure):
                 + [("spawn_probability", C.c_double), ("access_lane", C.c_int32 * 4), ("outer_node", C.c_int32 * 4),
                    ("obs_type", C.c_int32), ("grid_align", C.c_int32), ("grid_shape", C.c_int32 * 2),
                    ("grid_min", C.c_double * 2), ("grid_step", C.c_double * 2),
-                   ("num_agents", C.c_int32), ("pad_", C.c_int32),
+                   ("num_agents", C.c_int32), ("obs_intentions", C.c_int32),
                    ("lanes", IxLane * IX_MAX_LANES)])
 
 
@@ -110,6 +110,7 @@ def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots
     c.obs_absolute, c.obs_normalize = int(obs.get("absolute", False)), int(obs.get("normalize", True))
     c.obs_clip, c.obs_see_behind = int(obs.get("clip", True)), int(obs.get("see_behind", False))
     c.obs_unsorted = int(obs.get("order", "sorted") == "shuffled")
+    c.obs_intentions = int(bool(obs.get("observe_intentions", False)))
     inf = float("inf")
     for name, field in (("x", c.obs_range_x), ("y", c.obs_range_y), ("vx", c.obs_range_vx), ("vy", c.obs_range_vy)):
         field[0], field[1] = (float(fr[name][0]), float(fr[name][1])) if name in fr else (-inf, inf)

@@ -172,6 +172,20 @@ SCENARIOS = [
     dict(name="intersection_multi_agent3", cls="MultiAgentIntersectionEnv",
          config={"controlled_vehicles": 3, "destination": None, "initial_vehicle_count": 8}, seeds=list(range(71, 75)),
          steps=9, action_seed=48, frames_for=0, n_slots=24),
+    # the destination features cos_d / sin_d (Vehicle.destination_direction, kinematics.py:211-235): with observe_intentions
+    # every observed vehicle's, without it (the default) only the observer's own (objects.py / kinematics.py to_dict)
+    dict(name="intersection_intentions",
+         config={"observation": {"type": "Kinematics", "vehicles_count": 10,
+                                 "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "cos_d", "sin_d"],
+                                 "features_range": {"x": [-100, 100], "y": [-100, 100], "vx": [-20, 20], "vy": [-20, 20]},
+                                 "absolute": False, "observe_intentions": True}, "destination": None},
+         seeds=list(range(81, 85)), steps=9, action_seed=49, frames_for=0, n_slots=24),
+    dict(name="intersection_no_intentions",
+         config={"observation": {"type": "Kinematics", "vehicles_count": 15,
+                                 "features": ["presence", "x", "y", "cos_d", "sin_d"],
+                                 "features_range": {"x": [-100, 100], "y": [-100, 100]},
+                                 "absolute": True, "observe_intentions": False}},
+         seeds=list(range(91, 94)), steps=8, action_seed=50, frames_for=0, n_slots=24),
     # intersection-v2: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
     dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
          config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},

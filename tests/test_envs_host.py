@@ -268,6 +268,9 @@ def test_intersection_config_errors():
         EmuBatchedIntersection({"destination": "o7"}, num_envs=1)
     with pytest.raises(NotImplementedError):
         EmuBatchedIntersection({"observation": {"type": "OccupancyGrid", "features": ["presence", "lat_off"]}}, num_envs=1)
+    kin = dict(EmuBatchedIntersection.default_config()["observation"], observe_intentions=True,
+               features=["presence", "x", "y", "cos_d", "sin_d"])
+    assert EmuBatchedIntersection({"observation": kin}, num_envs=1)._hcfg.flags & _abi.C_OBS_INTENTIONS
     assert EmuBatchedIntersection({"observation": {"type": "OccupancyGrid"}}, num_envs=1).single_observation_shape == (4, 11, 11)
     env = EmuBatchedIntersection(num_envs=2)
     assert env.single_action_space.n == 3 and env.single_observation_shape == (15, 7)
@@ -504,3 +507,30 @@ def test_multi_agent_intersection_dropin_matches_reference_episode(real, name):
                 break
         env.close()
     assert steps_compared >= 2 * g.E
+
+
+@pytest.mark.parametrize("real", [False, pytest.param(True, marks=pytest.mark.gpu)], ids=["emu", "hip"])
+@pytest.mark.parametrize("name", ["intersection_intentions", "intersection_no_intentions"])
+def test_destination_features_replay_the_reference(real, name):
+    """cos_d / sin_d (Vehicle.destination_direction): IntersectionEnv(config).reset(seed=s) and the first steps give the reference's
+    observations -- with observe_intentions every observed vehicle's destination, without it only the observer's own."""
+    from tests.golden_util import GoldenIntersection
+    g = GoldenIntersection(name)
+    n_rows = 0
+    for e in range(g.E):
+        env = (envs.IntersectionEnv if real else EmuIntersection)(dict(g.config))
+        obs, info = env.reset(seed=int(g.z["seeds"][e]))
+        np.testing.assert_allclose(obs, g.z["obs0"][e], atol=1e-6)
+        dest = obs[:, -2:]
+        n_rows += int((np.abs(dest).sum(1) > 0).sum())
+        for t in range(3):
+            wst = g.state("step", t)
+            pres = wst["present"][e] != 0
+            if ((wst["crashed"][e] != 0) | (wst["has_impact"][e] != 0))[pres].any() or (np.abs(wst["speed"][e][pres]) < 0.5).any():
+                break
+            obs, r, te, tr, info = env.step(int(g.actions[t, e, 0]))
+            np.testing.assert_allclose(obs, g.z["obs"][t, e], atol=1e-6, err_msg=f"env {e} step {t}")
+            if te or tr:
+                break
+        env.close()
+    assert n_rows > g.E if g.config["observation"]["observe_intentions"] else n_rows == g.E

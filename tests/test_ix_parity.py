@@ -11,7 +11,8 @@ import pytest
 
 from highwayenv_amd import _abi
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_MA, INTERSECTION_MA_FRAMES, GoldenIntersection,
+from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_INTENTIONS, INTERSECTION_MA, INTERSECTION_MA_FRAMES,
+                               GoldenIntersection,
                                assert_ix_engine_state_close,
                                ix_engine_state)
 
@@ -69,12 +70,13 @@ def test_teacher_forced_frames_vs_reference(backend, name):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS)
 def test_policy_steps_vs_reference(backend, name):
     """Whole policy steps from the reference's state at the start of each step (host-traffic mode: the kernel does not
     clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call.
     The *_grid fixtures carry BASELINE config 4's OccupancyGrid observation (on-road layer over straight lanes of any
-    direction and circular arcs, world- and vehicle-aligned cells)."""
+    direction and circular arcs, world- and vehicle-aligned cells); the *intentions fixtures the cos_d / sin_d features
+    (Vehicle.destination_direction) with and without observe_intentions."""
     g = GoldenIntersection(name)
     E, S = g.E, g.steps
     steps0 = g.z["road_steps0"]

@@ -8,7 +8,8 @@ Tolerances as in test_oracle_golden.py: f64 with glibc libm vs numpy's libm; fla
 import numpy as np
 import pytest
 
-from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_MA, INTERSECTION_MA_FRAMES, GoldenIntersection,
+from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_INTENTIONS, INTERSECTION_MA, INTERSECTION_MA_FRAMES,
+                               GoldenIntersection,
                                assert_ix_state_close)
 
 
@@ -43,7 +44,7 @@ def test_oracle_teacher_forced_frames(name):
     assert n_yield > 0  # the fixtures do exercise the regulation
 
 
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS)
 def test_oracle_steps_observation_reward_and_clear_spawn(name):
     """Whole policy steps from the reference's state at the start of each step: state before clear/spawn, obs, reward,
     terminated / truncated, info; then _clear_vehicles + _spawn_vehicle replayed on the recorded draws."""
