@@ -1012,6 +1012,18 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
       }
     }
   }
+  // Vehicle.lane_offset (kinematics.py:228-235) for the long_off / lat_off / ang_off features: my coordinates on my CURRENT lane
+  // and the heading relative to it (lane.py:145-147)
+  double off_s = 0.0, off_lat = 0.0, off_ang = 0.0;
+  {
+    bool wanted = false;  // wave-uniform
+    for (int f = 0; f < F; ++f)
+      wanted |= p.feat[f] == HWY_FEAT_LONG_OFF || p.feat[f] == HWY_FEAT_LAT_OFF || p.feat[f] == HWY_FEAT_ANG_OFF;
+    if (wanted && present) {
+      ix_local(sh, me.lane, me.x, me.y, &off_s, &off_lat);
+      off_ang = wrap_to_pi(me.h - ix_heading_at(sh, me.lane, off_s));
+    }
+  }
   // MultiAgentObservation.observe (observation.py:733-734): agent a == the a-th controlled vehicle of the list
   int a = 0;
   for (u64 am = egos; am && a < p.A; am &= am - 1, ++a) {
@@ -1050,6 +1062,8 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
         // the observer's own row is to_dict() with the default True (observation.py:239,253; kinematics.py:255-256)
         if ((fid == HWY_FEAT_COS_D || fid == HWY_FEAT_SIN_D) && (row == 0 || (p.flags & HWY_C_OBS_INTENTIONS)))
           val = fid == HWY_FEAT_COS_D ? dest_x : dest_y;
+        if (fid == HWY_FEAT_LONG_OFF || fid == HWY_FEAT_LAT_OFF || fid == HWY_FEAT_ANG_OFF)
+          val = fid == HWY_FEAT_LONG_OFF ? off_s : fid == HWY_FEAT_LAT_OFF ? off_lat : off_ang;
         const bool rel = fid == HWY_FEAT_X || fid == HWY_FEAT_Y || fid == HWY_FEAT_VX || fid == HWY_FEAT_VY;
         if (row > 0 && rel && !(p.flags & HWY_C_OBS_ABSOLUTE)) {
           const double origin = fid == HWY_FEAT_X ? ex : fid == HWY_FEAT_Y ? ey : fid == HWY_FEAT_VX ? ev * ech : ev * esh;

@@ -46,7 +46,7 @@
 #define IX_MAX_AGENTS 4
 #define IX_MAX_FEATURES 16
 
-enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_COS_D, FEAT_SIN_D, FEAT_ON_ROAD = 13 };
+enum { FEAT_PRESENCE = 0, FEAT_X, FEAT_Y, FEAT_VX, FEAT_VY, FEAT_HEADING, FEAT_COS_H, FEAT_SIN_H, FEAT_COS_D, FEAT_SIN_D, FEAT_LONG_OFF, FEAT_LAT_OFF, FEAT_ANG_OFF, FEAT_ON_ROAD = 13 };
 enum { ACT_SLOWER = 0, ACT_IDLE = 1, ACT_FASTER = 2 }; /* IntersectionEnv.ACTIONS, intersection_env.py:14 */
 
 typedef struct {
@@ -698,6 +698,13 @@ static double feature_of_c(const ix_config *c, const veh_t *v, int fid, int obse
     double dx, dy;
     destination_direction(c, v, &dx, &dy);
     return fid == FEAT_COS_D ? dx : dy;
+  }
+  if (fid == FEAT_LONG_OFF || fid == FEAT_LAT_OFF || fid == FEAT_ANG_OFF) {
+    /* Vehicle.lane_offset (kinematics.py:228-235): local coordinates on the CURRENT lane and local_angle (lane.py:145-147) */
+    const ix_lane *l = &c->lanes[v->lane];
+    double s, lat;
+    lane_local(l, v->x, v->y, &s, &lat);
+    return fid == FEAT_LONG_OFF ? s : fid == FEAT_LAT_OFF ? lat : wrap_to_pi(v->heading - lane_heading_at(l, s));
   }
   switch (fid) {
     case FEAT_PRESENCE: return 1;

@@ -12,7 +12,7 @@ import numpy as np
 from . import oracle as _base
 
 IX_MAX_LANES, IX_MAX_ROUTE, IX_MAX_FEATURES = 32, 8, 16
-FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7, "cos_d": 8, "sin_d": 9, "on_road": 13}
+FEATURE_IDS = {"presence": 0, "x": 1, "y": 2, "vx": 3, "vy": 4, "heading": 5, "cos_h": 6, "sin_h": 7, "cos_d": 8, "sin_d": 9, "long_off": 10, "lat_off": 11, "ang_off": 12, "on_road": 13}
 LANE_F64 = ["sx", "sy", "ex", "ey", "heading", "dirx", "diry", "cx", "cy", "radius", "start_phase", "end_phase",
             "length", "width", "speed_limit"]
 LANE_I32 = ["kind", "direction", "priority", "forbidden", "from_node", "to_node", "id"]

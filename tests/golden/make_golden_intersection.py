@@ -186,6 +186,13 @@ SCENARIOS = [
                                  "features_range": {"x": [-100, 100], "y": [-100, 100]},
                                  "absolute": True, "observe_intentions": False}},
          seeds=list(range(91, 94)), steps=8, action_seed=50, frames_for=0, n_slots=24),
+    # the lane-offset features (Vehicle.lane_offset, kinematics.py:228-235) on straight lanes of every direction and on arcs
+    dict(name="intersection_lane_offsets",
+         config={"observation": {"type": "Kinematics", "vehicles_count": 12,
+                                 "features": ["presence", "x", "y", "long_off", "lat_off", "ang_off"],
+                                 "features_range": {"x": [-100, 100], "y": [-100, 100]}, "absolute": True},
+                 "initial_vehicle_count": 12, "spawn_probability": 0.8},
+         seeds=list(range(101, 105)), steps=10, action_seed=51, frames_for=0, n_slots=24),
     # intersection-v2: Road.neighbour_vehicles also searches the connected lane segments (road.py:508-529)
     dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
          config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},

@@ -167,8 +167,8 @@ INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned"]  # per-st
 # MultiAgentIntersectionEnv (2 agents with per-frame states; 3 agents with random destinations, per-step states only)
 INTERSECTION_MA = ["intersection_multi_agent", "intersection_multi_agent3"]
 INTERSECTION_MA_FRAMES = ["intersection_multi_agent"]
-# the destination features cos_d / sin_d with and without observe_intentions (per-step fixtures)
-INTERSECTION_INTENTIONS = ["intersection_intentions", "intersection_no_intentions"]
+# the destination features cos_d / sin_d with and without observe_intentions, the lane-offset features (per-step fixtures)
+INTERSECTION_INTENTIONS = ["intersection_intentions", "intersection_no_intentions", "intersection_lane_offsets"]
 
 
 class GoldenIntersection:
