@@ -112,8 +112,10 @@ def random_intersection_config(rng):
                               "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
                               "features_range": {"x": [-50, 50], "y": [-50, 50], "vx": [-20, 20], "vy": [-20, 20]}}
     else:
+        extra = [[], ["cos_d", "sin_d"], ["long_off", "lat_off", "ang_off"], ["heading", "cos_d", "sin_d", "lat_off"]][int(rng.integers(4))]
         cfg["observation"] = dict(cfg["observation"], vehicles_count=int(rng.integers(3, 16)), see_behind=bool(rng.integers(2)),
-                                  absolute=bool(rng.integers(2)))
+                                  absolute=bool(rng.integers(2)), observe_intentions=bool(rng.integers(2)),
+                                  features=cfg["observation"]["features"] + extra)
     cfg.update({"initial_vehicle_count": int(rng.integers(2, 15)), "spawn_probability": float(rng.uniform(0, 1)),
                 "duration": int(rng.integers(5, 20)), "max_vehicles": int(rng.choice([20, 28, 32, 40])),
                 "destination": f"o{int(rng.integers(0, 4))}", "normalize_reward": bool(rng.integers(2)),
