@@ -182,8 +182,10 @@ typedef struct hwy_config {
   int32_t abi_version;                 /* = HWY_ABI_VERSION */
   int32_t num_envs;                    /* E */
   int32_t num_vehicles;                /* N = vehicles_count + controlled_vehicles */
-  int32_t num_agents;                  /* A = controlled_vehicles */
-  int32_t agent_index[HWY_MAX_AGENTS]; /* index of each controlled vehicle in the vehicle list */
+  int32_t num_agents;                  /* A = controlled_vehicles (HWY_SCENARIO_INTERSECTION: 1..4, MultiAgentIntersectionEnv) */
+  int32_t agent_index[HWY_MAX_AGENTS]; /* index of each controlled vehicle in the vehicle list (HWY_SCENARIO_INTERSECTION: unused --
+                                          its list is re-compacted while an episode runs, so agent a is the a-th slot that carries
+                                          HWY_F_CONTROLLED) */
   int32_t lanes_count;                 /* L: lane k is centred on y = k*lane_width (road.py:291-321); merge: highway lanes */
   int32_t frames_per_step;             /* T = simulation_frequency // policy_frequency (abstract.py:289-291) */
   int32_t flags;                       /* HWY_C_* */
