@@ -102,12 +102,13 @@ def net_ticks(text):
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
     # collisions split: phase 1 (walk) -> acc[10], phase 2 (SAT trips) -> acc[12]; trip / walk-step counters
-    t = sub("      // Phase 2: every thread's collected partners", "      TICK(10)\n      // Phase 2: every thread's collected partners")(t)
+    t = sub("      // Phase 2: the collected partners are filtered", "      TICK(10)\n      // Phase 2: the collected partners are filtered")(t)
     t = sub("  }  // frames\n\n  // ---- G. observe", "  TICK(12)\n  }  // frames\n\n  // ---- G. observe")(t)
     t = sub("    TICK(10)\n  TICK(12)\n  }  // frames", "  TICK(12)\n  }  // frames")(t)
     t = sub("        if (__ballot(go_a || go_b) == 0) break;", "        if (__ballot(go_a || go_b) == 0) break;\n        n_walk += 1.0f;")(t)
-    t = sub("        if (cand == 0) continue;\n        const int r2 = ctz64(cand);", "        n_trip += 1.0f; if (cand == 0) continue;\n        const int r2 = ctz64(cand);")(t)
-    t = sub("        double tx, ty;\n        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "        n_sat += 1.0f;\n        double tx, ty;\n        const int r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
+    t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count",
+            "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        n_trip += 1.0f;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count")(t)
+    t = sub("          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "          n_sat += 1.0f;\n          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
     t = sub("  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};", "  float n_walk = 0, n_trip = 0, n_sat = 0; long long t_prev = clock64(); long long acc[13] = {0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
     t = sub("    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
             "    TICK(11)\n    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
