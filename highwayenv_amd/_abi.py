@@ -39,6 +39,7 @@ C_CONNECTED_LANES = 512
 C_OBS_UNSORTED = 1024
 C_OBS_VEHICLES_ONLY = 2048
 C_OBS_INTENTIONS = 4096
+C_GRID_IMAGE = 8192
 OBS_KINEMATICS, OBS_OCCUPANCY_GRID = 0, 1
 HWY_MAX_GRID_CELLS = 65536
 
@@ -396,8 +397,6 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
         feats = obs["features"] if obs.get("features") is not None else ["presence", "vx", "vy", "on_road"]
         if obs.get("absolute", False):
             raise NotImplementedError()  # the reference raises it too (observation.py:358-359)
-        if obs.get("as_image", False):
-            raise NotImplementedError("OccupancyGrid as_image (uint8) is out of scope")
         gs = np.array(obs["grid_size"] if obs.get("grid_size") is not None else [[-27.5, 27.5], [-27.5, 27.5]], np.float64)
         step = np.array(obs["grid_step"] if obs.get("grid_step") is not None else [5, 5], np.float64)
         shape = np.asarray(np.floor((gs[:, 1] - gs[:, 0]) / step), dtype=np.intp)
@@ -469,6 +468,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
                 raise NotImplementedError(f"feature {name!r} is undefined for the Obstacle of the merge scenarios")
     if grid and obs.get("align_to_vehicle_axes", False):
         flags |= C_GRID_ALIGN
+    if grid and obs.get("as_image", False):
+        flags |= C_GRID_IMAGE         # uint8 cells (the engine writes integer-valued f32; envs.py casts)
     if fast:  # HighwayEnvFast._create_vehicles (highway_env.py:177-182)
         flags |= C_EGO_ONLY_COLLISIONS
     c.flags = flags

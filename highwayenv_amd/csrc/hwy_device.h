@@ -561,6 +561,9 @@ __device__ inline void grid_ws_store(int32_t *q, int32_t v) { __hip_atomic_store
 __device__ inline int32_t grid_ws_load(int32_t *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void grid_ws_min(int32_t *q, int32_t v) { __hip_atomic_fetch_min(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// OccupancyGridObservation(as_image=True) (observation.py:408-409): ((clip(v, -1, 1) + 1) / 2 * 255).astype(uint8) truncates
+__device__ inline double grid_image(double v) { return (double)(int)((clipd(v, -1.0, 1.0) + 1.0) / 2 * 255); }
+
 __device__ inline void grid_cell(const StepParams &p, double px, double py, double ec, double es, int *ci, int *cj) {
   if (p.flags & HWY_C_GRID_ALIGN) {  // pos_to_index: [[c, s], [-s, c]] @ position  (observation.py:431-435)
     const double qx = ec * px + es * py, qy = -es * px + ec * py;
@@ -628,12 +631,13 @@ __device__ inline void observe_grid(const StepParams &p, int e, int a, const Veh
         if (r0 > -__builtin_inf()) val = lmap(val, r0, r1, -1.0, 1.0);
       }
       if (clip) val = clipd(val, -1.0, 1.0);
+      if (p.flags & HWY_C_GRID_IMAGE) val = grid_image(val);
       out[(f * W + my_ci) * H + my_cj] = (float)val;
     }
   }
   for (int t = i; t < F * WH; t += NT) {  // everything the owners do not write
     const int f = t / WH, c = t - f * WH;
-    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? ((p.flags & HWY_C_GRID_IMAGE) ? 255.0f : 1.0f) : 0.0f;
     else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;  // NaN (empty) -> 0
   }
   __syncthreads();  // the workspace of this (env, agent) may be reused by the next call

@@ -395,12 +395,13 @@ __device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh
         if (r0 > -__builtin_inf()) val = lmap(val, r0, r1, -1.0, 1.0);
       }
       if (clip) val = clipd(val, -1.0, 1.0);
+      if (p.flags & HWY_C_GRID_IMAGE) val = grid_image(val);
       out[(f * W + my_ci) * H + my_cj] = (float)val;
     }
   }
   for (int t = i; t < F * WH; t += NT) {
     const int f = t / WH, c = t - f * WH;
-    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? 1.0f : 0.0f;
+    if (p.feat[f] == HWY_FEAT_ON_ROAD) out[t] = grid_ws_load(road + c) ? ((p.flags & HWY_C_GRID_IMAGE) ? 255.0f : 1.0f) : 0.0f;
     else if (grid_ws_load(own + c) == 0x7fffffff) out[t] = 0.0f;
   }
   __syncthreads();

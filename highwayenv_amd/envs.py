@@ -41,7 +41,8 @@ class _Discrete:
 
 class _Box:
     def __init__(self, shape, dtype=np.float32):
-        self.shape, self.dtype, self.low, self.high = tuple(shape), np.dtype(dtype), -np.inf, np.inf
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.low, self.high = (0, 255) if self.dtype == np.uint8 else (-np.inf, np.inf)
 
     def contains(self, x):
         return tuple(np.shape(x)) == self.shape
@@ -123,10 +124,12 @@ class BatchedHighwayEnv:
         self.single_observation_shape = _abi.obs_shape(hc) if A == 1 else (A, *_abi.obs_shape(hc))
         if _gym is not None:
             self.single_action_space = _gym.spaces.Discrete(_abi.num_actions(hc))  # len(self.actions), action.py:252-253
-            self.single_observation_space = _gym.spaces.Box(-np.inf, np.inf, self.single_observation_shape, np.float32)
+            image = bool(hc.flags & _abi.C_GRID_IMAGE)  # observation.py:330-331: Box(0, 255, uint8)
+            self.single_observation_space = (_gym.spaces.Box(0, 255, self.single_observation_shape, np.uint8) if image else
+                                             _gym.spaces.Box(-np.inf, np.inf, self.single_observation_shape, np.float32))
         else:
             self.single_action_space = _Discrete(_abi.num_actions(hc))
-            self.single_observation_space = _Box(self.single_observation_shape)
+            self.single_observation_space = _Box(self.single_observation_shape, np.uint8 if hc.flags & _abi.C_GRID_IMAGE else np.float32)
         self.action_space, self.observation_space = self.single_action_space, self.single_observation_space
 
     def _ensure_engine(self):
@@ -233,6 +236,8 @@ class BatchedHighwayEnv:
                     self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
                 for a in range(self._hcfg.num_agents):
                     self.np_random[e].shuffle(obs[e, a, 1:])
+        if self._hcfg.flags & _abi.C_GRID_IMAGE:  # OccupancyGrid(as_image=True): the engine wrote the uint8 values as f32
+            obs = obs.astype(np.uint8)
         return obs[:, 0] if self._hcfg.num_agents == 1 else obs
 
     # ---- inspection --------------------------------------------------------------------------------

@@ -94,6 +94,9 @@ enum {
   HWY_C_OBS_INTENTIONS = 4096, /* KinematicObservation(observe_intentions=True) (observation.py:171,253): the cos_d / sin_d features
                                 (Vehicle.destination_direction, kinematics.py:211-235) of the OTHER vehicles too, not only the
                                 observer's own; only vehicles with a route have a destination (HWY_SCENARIO_INTERSECTION) */
+  HWY_C_GRID_IMAGE = 8192,    /* OccupancyGridObservation(as_image=True) (observation.py:296,408-409): every cell holds
+                                 uint8(((clip(value, -1, 1) + 1) / 2) * 255) -- written as an integer-valued f32, 0 for an empty
+                                 (NaN) cell -- instead of the value */
   HWY_C_HOST_TRAFFIC = 256    /* HWY_SCENARIO_INTERSECTION: the HOST clears / spawns vehicles between policy steps (the
                                  reference-stream mode of highwayenv_amd/intersection.py); otherwise the step kernel does
                                  it on Philox draws */

@@ -76,6 +76,7 @@ typedef struct {
   double grid_min[2], grid_step[2];
   int32_t num_agents;      /* controlled_vehicles: MultiAgentIntersectionEnv (intersection_env.py:348-399) */
   int32_t obs_intentions;  /* KinematicObservation.observe_intentions (observation.py:171,253) */
+  int32_t grid_image, pad_; /* OccupancyGridObservation.as_image (observation.py:296,408-409) */
   ix_lane lanes[IX_MAX_LANES];
 } ix_config;
 
@@ -843,6 +844,8 @@ static void observe_grid_agent(const road_t *r, int ego_idx, float *obs) {
   for (int k = 0; k < F * W * H; k++) {
     double v = grid[k];
     if (c->obs_clip) v = isnan(v) ? v : clipd(v, -1, 1);
+    /* as_image (observation.py:408-409): ((clip(obs, -1, 1) + 1) / 2 * 255).astype(uint8); an empty (NaN) cell casts to 0 */
+    if (c->grid_image) v = isnan(v) ? 0.0 : (double)(uint8_t)((clipd(v, -1, 1) + 1) / 2 * 255);
     obs[k] = isnan(v) ? 0.0f : (float)v; /* np.nan_to_num */
   }
   free(grid);

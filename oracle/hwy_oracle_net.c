@@ -669,6 +669,8 @@ static void observe_grid_agent(const net_t *r, int ego_idx, float *obs) {
   for (int k = 0; k < F * W * H; k++) {
     double v = grid[k];
     if (c->flags & HWY_C_OBS_CLIP) v = isnan(v) ? v : clipd(v, -1, 1);
+    /* as_image (observation.py:408-409): ((clip(obs, -1, 1) + 1) / 2 * 255).astype(uint8); an empty (NaN) cell casts to 0 */
+    if (c->flags & HWY_C_GRID_IMAGE) v = isnan(v) ? 0.0 : (double)(uint8_t)((clipd(v, -1, 1) + 1) / 2 * 255);
     obs[k] = isnan(v) ? 0.0f : (float)v;
   }
   free(grid);

@@ -44,7 +44,7 @@ class IxConfig(C.Structure):
                 + [("spawn_probability", C.c_double), ("access_lane", C.c_int32 * 4), ("outer_node", C.c_int32 * 4),
                    ("obs_type", C.c_int32), ("grid_align", C.c_int32), ("grid_shape", C.c_int32 * 2),
                    ("grid_min", C.c_double * 2), ("grid_step", C.c_double * 2),
-                   ("num_agents", C.c_int32), ("obs_intentions", C.c_int32),
+                   ("num_agents", C.c_int32), ("obs_intentions", C.c_int32), ("grid_image", C.c_int32), ("pad_", C.c_int32),
                    ("lanes", IxLane * IX_MAX_LANES)])
 
 
@@ -95,6 +95,7 @@ def make_config(config: dict, lane_tab: dict, node_names, num_envs: int, n_slots
         step = np.array(obs.get("grid_step") or [5, 5], np.float64)
         shape = np.asarray(np.floor((gs[:, 1] - gs[:, 0]) / step), dtype=np.intp)
         c.obs_type, c.grid_align = 1, int(obs.get("align_to_vehicle_axes", False))
+        c.grid_image = int(bool(obs.get("as_image", False)))
         c.grid_shape[0], c.grid_shape[1] = int(shape[0]), int(shape[1])
         c.grid_min[0], c.grid_min[1] = float(gs[0, 0]), float(gs[1, 0])
         c.grid_step[0], c.grid_step[1] = float(step[0]), float(step[1])

@@ -133,6 +133,12 @@ SCENARIOS = [
                                  "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
                                  "clip": False}},
          seeds=[3, 4], steps=8, action_seed=12, frames_for=0, action_p=[0.3, 0.1, 0.3, 0.2, 0.1]),
+    # ... as_image: uint8 cells, ((clip(v, -1, 1) + 1) / 2 * 255).astype(uint8), an empty cell 0 (observation.py:408-409)
+    dict(name="grid_image", cls=HighwayEnvFast,
+         config={"vehicles_count": 30, "lanes_count": 4,
+                 "observation": {"type": "OccupancyGrid", "as_image": True,
+                                 "features": ["presence", "vx", "vy", "cos_h", "sin_h", "on_road"]}},
+         seeds=[6, 7, 8], steps=8, action_seed=14, frames_for=0),
     # ... x/y in features_range (the reference normalises then de-normalises the coordinates)
     dict(name="grid_xy_range", cls=HighwayEnv,
          config={"vehicles_count": 25, "lanes_count": 4, "simulation_frequency": 5, "duration": 12,

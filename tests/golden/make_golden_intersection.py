@@ -162,6 +162,9 @@ SCENARIOS = [
                                  "grid_step": [4, 4], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"],
                                  "features_range": {"x": [-40, 40], "y": [-40, 40], "vx": [-20, 20], "vy": [-20, 20]}}},
          seeds=[31, 32], steps=12, action_seed=44, frames_for=0, n_slots=24),
+    # OccupancyGrid as_image (uint8 cells)
+    dict(name="intersection_grid_image", config={"observation": {"type": "OccupancyGrid", "as_image": True}}, seeds=[24, 25, 26],
+         steps=10, action_seed=52, frames_for=0, n_slots=24),
     # config["destination"] = None: "o" + str(np_random.integers(1, 4)) per episode (intersection_env.py:295-297)
     dict(name="intersection_random_destination", config={"destination": None}, seeds=list(range(51, 59)), steps=8,
          action_seed=46, frames_for=0, n_slots=24),

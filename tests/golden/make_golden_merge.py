@@ -191,6 +191,8 @@ SCENARIOS = [
     # SineLane waypoints (observation.py:454-484); world-aligned default grid and a vehicle-aligned finer one
     dict(name="merge_grid", cls=MergeEnv, config={"observation": {"type": "OccupancyGrid"}},
          seeds=list(range(30, 34)), steps=10, action_seed=38, frames_for=0, n_slots=6),
+    dict(name="merge_grid_image", cls=MergeEnv, config={"observation": {"type": "OccupancyGrid", "as_image": True}},
+         seeds=list(range(34, 37)), steps=8, action_seed=39, frames_for=0, n_slots=6),
     dict(name="merge_generic_grid_aligned", cls=MergeGenericEnv,
          config={"lanes_count": 3, "vehicles_count": 15,
                  "observation": {"type": "OccupancyGrid", "align_to_vehicle_axes": True, "grid_size": [[-24, 48], [-12, 12]],

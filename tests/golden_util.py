@@ -10,7 +10,7 @@ from highwayenv_amd import _abi
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-GRID = ["grid_default", "grid_aligned_fine", "grid_xy_range"]
+GRID = ["grid_default", "grid_aligned_fine", "grid_xy_range", "grid_image"]
 ALL = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
        "fast_idle_long", "fast_offroad_terminal", "fast_lateral_only", "v0_longitudinal_only"]
 WITH_FRAMES = ["cfg1_fast_default", "cfg2_fast_n50_l4", "v0_default", "cfg3_v0_n100", "dense_crash",
@@ -98,7 +98,7 @@ def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
 # --------------------------------------------------------------------------- merge scenarios
 MERGE = ["merge_default", "merge_generic_l3", "merge_generic_sections", "merge_ma4", "merge_v1", "merge_generic_v1",
          "merge_no_obstacles"]
-MERGE_GRID = ["merge_grid", "merge_generic_grid_aligned"]  # per-step fixtures with the OccupancyGrid observation
+MERGE_GRID = ["merge_grid", "merge_generic_grid_aligned", "merge_grid_image"]  # per-step fixtures with the OccupancyGrid observation
 
 
 class GoldenMerge:
@@ -163,7 +163,7 @@ def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
 
 
 INTERSECTION = ["intersection_default", "intersection_dense", "intersection_v2"]   # per-frame fixtures (Kinematics observation)
-INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned"]  # per-step fixtures, OccupancyGrid observation
+INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned", "intersection_grid_image"]  # per-step fixtures, OccupancyGrid observation
 # MultiAgentIntersectionEnv (2 agents with per-frame states; 3 agents with random destinations, per-step states only)
 INTERSECTION_MA = ["intersection_multi_agent", "intersection_multi_agent3"]
 INTERSECTION_MA_FRAMES = ["intersection_multi_agent"]

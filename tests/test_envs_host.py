@@ -534,3 +534,16 @@ def test_destination_features_replay_the_reference(real, name):
                 break
         env.close()
     assert n_rows > g.E if g.config["observation"]["observe_intentions"] else n_rows == g.E
+
+
+def test_occupancy_grid_as_image_is_uint8_like_the_reference():
+    """OccupancyGridObservation(as_image=True): Box(0, 255, uint8) cells, ((clip(v, -1, 1) + 1) / 2 * 255).astype(uint8), an
+    empty cell 0 (observation.py:330-331, 408-409) -- reset(seed=s) gives the reference's first image."""
+    g = Golden("grid_image")
+    env = EmuFast(g.config, num_envs=g.E)
+    obs, _ = env.reset(seed=[int(s) for s in g.seeds])
+    assert obs.dtype == np.uint8 and env.single_observation_space.dtype == np.uint8
+    np.testing.assert_array_equal(obs, g.z["obs0"])
+    obs, *_ = env.step(g.actions[0])
+    np.testing.assert_array_equal(obs, g.z["obs"][0])
+    env.close()

@@ -102,7 +102,7 @@ def random_intersection_config(rng):
     cfg = hix.intersection_default_config()
     kind = int(rng.integers(3))
     if kind == 1:
-        cfg["observation"] = {"type": "OccupancyGrid"}
+        cfg["observation"] = {"type": "OccupancyGrid", "as_image": bool(rng.integers(2))}
     elif kind == 2:
         cfg["observation"] = {"type": "OccupancyGrid", "align_to_vehicle_axes": bool(rng.integers(2)),
                               # (cell borders that are whole multiples of the waypoint spacing away from the observer put
