@@ -29,7 +29,7 @@ def random_config(rng):
         gfeats = [["presence", "vx", "vy", "on_road"], ["presence", "x", "y", "vx", "vy", "cos_h", "sin_h", "on_road"]][int(rng.integers(2))]
         obs = {"type": "OccupancyGrid", "features": gfeats, "grid_size": [[-31.3, 28.7], [-13.3, 11.7]],
                "grid_step": [float(rng.choice([2.5, 5]))] * 2, "align_to_vehicle_axes": bool(rng.integers(2)),
-               "clip": bool(rng.integers(2))}
+               "clip": bool(rng.integers(2)), "as_image": bool(rng.integers(2))}
     cfg.update({"lanes_count": lanes, "vehicles_count": int(rng.integers(0, 70)), "controlled_vehicles": agents,
                 "simulation_frequency": sim, "policy_frequency": int(rng.choice([1, 5]) if sim % 5 == 0 else 1),
                 "duration": int(rng.integers(4, 12)), "vehicles_density": float(rng.uniform(0.8, 2.0)),
@@ -77,7 +77,7 @@ def random_merge_config(rng):
     obs = kin
     if rng.integers(4) == 0:  # OccupancyGrid on the merge network (borders off the waypoint lattice)
         obs = {"type": "OccupancyGrid", "grid_size": [[-31.3, 28.7], [-13.3, 11.7]], "grid_step": [float(rng.choice([2.5, 5]))] * 2,
-               "align_to_vehicle_axes": bool(rng.integers(2)), "clip": bool(rng.integers(2))}
+               "align_to_vehicle_axes": bool(rng.integers(2)), "clip": bool(rng.integers(2)), "as_image": bool(rng.integers(2))}
     cfg["observation"] = obs
     if agents > 1:
         cfg["action"] = {"type": "MultiAgentAction", "action_config": {"type": "DiscreteMetaAction"}}
