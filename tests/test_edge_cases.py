@@ -6,7 +6,7 @@ import pytest
 from highwayenv_amd import _abi, spawn
 from oracle import oracle
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import assert_state_close
+from tests.golden_util import assert_obs_close, assert_state_close
 
 
 def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, compare_wrecks=False):
@@ -29,7 +29,7 @@ def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, com
         what = f"step {t}"
         np.testing.assert_array_equal(term[live], te2[live], err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
-        np.testing.assert_allclose(obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=what)
+        assert_obs_close(obs[ok], o2[ok], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
         np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
         assert_state_close({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in ref.items()}, atol=1e-7, what=what)

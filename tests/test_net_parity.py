@@ -12,7 +12,7 @@ import pytest
 from highwayenv_amd import _abi, merge
 from oracle import oracle
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import MERGE, MERGE_GRID, GoldenMerge, assert_net_state_close
+from tests.golden_util import MERGE, MERGE_GRID, GoldenMerge, assert_net_state_close, assert_obs_close
 
 
 def _sub(st, sel):
@@ -115,7 +115,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed):
         np.testing.assert_array_equal(term, te2, err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
         np.testing.assert_array_equal(info["crashed"], i2["crashed"], err_msg=what)
-        np.testing.assert_allclose(obs[ok], o2[ok], rtol=0, atol=1e-6, err_msg=what)
+        assert_obs_close(obs[ok], o2[ok], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
         np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
         assert_net_state_close(_sub(got, ok), _sub(ref, ok), atol=1e-7, what=what)
