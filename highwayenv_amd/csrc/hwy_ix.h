@@ -236,7 +236,8 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double 
 
 // ---- pair work: `trips` = the partner slots to visit (wave-uniform mask; with helper lanes bit j stands for the slots j and
 //      j + 1, one per half), cand(j) = "my vehicle and slot j are a candidate pair" (asked with my vehicle as the LOWER slot
-//      only: every unordered pair once), proc(pair) = the expensive evaluation of ONE pair per thread (pair < 0: none).
+//      only: every unordered pair once), proc(pair, more) = the expensive evaluation of ONE pair per thread (pair < 0:
+//      none; more = another pass follows).
 //      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
 //      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
 template <typename SH, typename Cand, typename Proc>
@@ -260,7 +261,7 @@ __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand ca
     const int pair = i < count ? (int)sh.plist[i] : -1;
     const int left = n_list - count;  // < width
     const int carry = i < left ? (int)sh.plist[count + i] : 0;
-    proc(pair);
+    proc(pair, trips != 0 || left != 0);  // (more passes follow: wave-uniform)
     HWY_WAVE_LDS_FENCE();
     if (i < left) sh.plist[i] = (unsigned short)carry;
     n_list = left;
@@ -346,7 +347,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           const double m = fmax(r.e, bd) + 1e-9, lo = r.c - m, hi = r.c + m;
           return (lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi;
         },
-        [&](int pair) {
+        [&](int pair, bool more) {
           const int v = pair & 255;
           unsigned long long key = 0;
           int L = 0;
@@ -373,20 +374,28 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           HWY_WAVE_LDS_FENCE();
           if (pair >= 0 && dmin[v] == key)
             __hip_atomic_fetch_min(&sh.jmax[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          HWY_WAVE_LDS_FENCE();
-          // the owners fold THIS pass's closest arc into their running minimum and clear the slots: a later pass (more than
-          // 64 candidate pairs) starts over, so "lowest index among the arcs at the minimum" never mixes two passes
-          const unsigned long long akey = dmin[vi];
-          if (present && akey != ~0ull) {
-            const double ad = __longlong_as_double((long long)akey);
-            const int aL = sh.jmax[vi];
-            if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+          if (more) {  // wave-uniform, rare: more candidate pairs than one pass holds
+            // the owners fold THIS pass's closest arc into their running minimum and clear the slots: the next pass starts
+            // over, so "lowest index among the arcs at the minimum" never mixes two passes
+            HWY_WAVE_LDS_FENCE();
+            const unsigned long long akey = dmin[vi];
+            if (present && akey != ~0ull) {
+              const double ad = __longlong_as_double((long long)akey);
+              const int aL = sh.jmax[vi];
+              if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+            }
+            HWY_WAVE_LDS_FENCE();
+            if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; }
           }
-          HWY_WAVE_LDS_FENCE();
-          if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; }
         });
     HWY_WAVE_LDS_FENCE();
     if (present) {
+      const unsigned long long akey = dmin[vi];  // (the last pass)
+      if (akey != ~0ull) {
+        const double ad = __longlong_as_double((long long)akey);
+        const int aL = sh.jmax[vi];
+        if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+      }
       bits |= sh.flag[vi];
       if (sh.vlane[vi]) { lat_t = sh.bcy[vi]; has_lat = true; }
     }
@@ -725,7 +734,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
             const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
             return bdx * bdx + bdy * bdy <= reach * reach;
           },
-          [&](int pair) {
+          [&](int pair, bool) {
             if (pair < 0) return;
             const int a = pair & 255, b = pair >> 8;  // a < b: v1 = a, v2 = b
             bool conflict = false;
@@ -817,7 +826,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
             if (!(dx * dx + dy * dy <= lim * lim)) return false;  // objects.py:124-127
             return !surely_apart(mine, other, p.dt);  // (hwy_device.h: provably (False, False) without the SAT)
           },
-          [&](int pair) {
+          [&](int pair, bool) {
             const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
             int r = 0;
             double tx = 0.0, ty = 0.0;
