@@ -184,6 +184,9 @@ VARIANTS = {
     "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
+    # (timing only) the in-loop table walk without its closest-lane half / without the whole walk's arithmetic
+    "nnoclosest": [(NET, sub("      net_lane_pass<true>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new);",
+                             "      net_lane_pass<false>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new); cl_new = me.lane;"))],
     # wave timeline: every wavefront of hwy_step_wave_kernel writes its start / end s_memrealtime (100 MHz) and HW_ID /
     # XCC_ID over the first four observation words of its environment (tools/wave_timeline.py reads them)
     "wtimeline": [(W, sub("  typedef EnvBlock<1> B;\n  __shared__ WaveShared sh;\n  const int e = blockIdx.x, i = threadIdx.x;\n  const int N = p.N;",
