@@ -525,29 +525,40 @@ __device__ inline void net_spawn_env(const NetParams &np, NetShared &sh, uint64_
   const int n_traffic = N - 3;
   const bool generic = np.generic != 0;
   const double w = 4.0;
-  // traffic positions: thread 0 replays the sequential rejection sampling (each try consumes one Philox block)
+  // traffic positions: the rejection sampling is sequential over the VEHICLES (a candidate is tested against everything placed
+  // before it, merge_env.py:307-331) but not over a vehicle's 10 tries: thread 6 t + part draws try t (its own Philox block,
+  // like the serial replay) and tests it against every sixth placed vehicle; the first try that no thread of its group
+  // objects to is the one the serial loop would have accepted.  (One thread replaying all of it took longer than a whole
+  // 15-frame policy step, and a fifth of the wavefronts of a merge launch are re-spawning: profiles/r02_history.md.)
   double *pos = sh.scratch;  // [n_traffic] longitudinal or -1 (gave up)
   int *lane_of = sh.idx;     // [n_traffic]
-  if (generic && i == 0) {
+  if (generic) {
     const double max_pos = sh.lx0[2 * lanes] + sh.llen[2 * lanes];  // pre + converge + parallel
-    for (int k = 0; k < n_traffic; ++k) {
-      pos[k] = -1.0;
-      lane_of[k] = 0;
-      for (int t = 0; t < 10; ++t) {
+    const int t = i / 6, part = i - 6 * t;
+    for (int k = 0; k < n_traffic; ++k) {  // wave-uniform
+      bool conflict = false;
+      int L = 0;
+      double lon = 0.0;
+      if (t < 10) {
         double u_lane, u_pos;
         philox_uniform2(seed, (uint32_t)(k + 1), episode, (uint32_t)t, &u_lane, &u_pos);
-        int L = (int)(u_lane * lanes);
+        L = (int)(u_lane * lanes);
         L = L > lanes - 1 ? lanes - 1 : L;
-        const double lon = 0.0 + (max_pos - 0.0) * u_pos;
-        bool ok = !(L == lanes - 1) || fabs(lon - 30.0) > 15.0;  // the ego sits at 30 m on the last lane
-        for (int q = 0; q < k && ok; ++q)
-          if (pos[q] >= 0 && lane_of[q] == L && !(fabs(lon - pos[q]) > 15.0)) ok = false;
-        if (ok) {
-          pos[k] = lon;
-          lane_of[k] = L;
-          break;
-        }
+        lon = 0.0 + (max_pos - 0.0) * u_pos;
+        conflict = part == 0 && (L == lanes - 1) && !(fabs(lon - 30.0) > 15.0);  // the ego sits at 30 m on the last lane
+        for (int q = part; q < k; q += 6)
+          if (pos[q] >= 0 && lane_of[q] == L && !(fabs(lon - pos[q]) > 15.0)) conflict = true;
       }
+      const u64 cm = __ballot(conflict);
+      int chosen = -1;
+      for (int tt = 9; tt >= 0; --tt)
+        if (((cm >> (6 * tt)) & 0x3f) == 0) chosen = tt;  // the FIRST acceptable try
+      HWY_WAVE_LDS_FENCE();  // every test of this vehicle has read the table
+      if (chosen >= 0 ? i == 6 * chosen : i == 0) {
+        pos[k] = chosen >= 0 ? lon : -1.0;
+        lane_of[k] = chosen >= 0 ? L : 0;
+      }
+      HWY_WAVE_LDS_FENCE();
     }
   }
   __syncthreads();

@@ -184,6 +184,16 @@ VARIANTS = {
     "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
+    # the auto-reset wavefronts of the merge step kernel stamp their lifetime (clock64 ticks) into observation word 0, -1 into word 15
+    "nresetticks": [(NET, net_ticks),
+                    (NET, sub("  if (p.autoreset && p.st.done[e]) {\n    Veh me;\n    const uint32_t episode = p.st.episode[e] + 1u;\n    net_spawn_env(",
+                              "  if (p.autoreset && p.st.done[e]) {\n    const long long rt0 = clock64();\n    Veh me;\n    const uint32_t episode = p.st.episode[e] + 1u;\n    net_spawn_env(")),
+                    (NET, sub("      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n    return;\n  }\n\n  WaveTurn turn;",
+                              "      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n"
+                              "    if (i == 0 && p.obs) { float *o = p.obs + (size_t)e * p.A * p.V * p.F; o[0] = (float)(clock64() - rt0); o[15] = -1.0f; }\n"
+                              "    return;\n  }\n\n  WaveTurn turn;"))],
+    "nnocoll": [(NET, sub("      for (int k = 1; k < n_present; ++k) {\n        const int ra = rank - k, rb = rank + k;", "      for (int k = 1; k < 1; ++k) {\n        const int ra = rank - k, rb = rank + k;"))],
+    "nnosat": [(NET, sub("          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "          r = 0;"))],
     # (timing only) the in-loop table walk without its closest-lane half / without the whole walk's arithmetic
     "nnoclosest": [(NET, sub("      net_lane_pass<true>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new);",
                              "      net_lane_pass<false>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new); cl_new = me.lane;"))],
