@@ -93,6 +93,7 @@ typedef struct {
   double x, y, heading, speed, timer, target_speed, delta, impact_x, impact_y, act_steering, act_accel;
   int lane, target_lane, speed_index, crashed, has_impact, controlled, is_yielding, yield_timer, route_len;
   int route_from[IX_MAX_ROUTE], route_to[IX_MAX_ROUTE], route_id[IX_MAX_ROUTE];
+  double impact_margin; /* test diagnostics only: min |d.normal| over the impacts assigned in this call */
 } veh_t;
 
 typedef struct {
@@ -324,6 +325,10 @@ static void project_polygon(double p[5][2], const double axis[2], double *mn, do
 static double interval_distance(double min_a, double max_a, double min_b, double max_b) { /* utils.py:188-193 */
   return min_a < min_b ? min_b - max_a : min_a - max_b;
 }
+/* Test diagnostics (as in hwy_oracle.c): |d.normal| of the axis that oriented the last translation (utils.py:232-236);
+ * orc_set_margin_buffer (hwy_oracle.c) hands out the per-slot minimum over the impacts assigned during a call. */
+static __thread double g_axis_dn = INFINITY;
+extern double *orc_margin_buf;
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {
@@ -355,6 +360,7 @@ static void are_polygons_intersecting(double a[5][2], double b[5][2], const doub
         double d0 = ca[0] / 4 - cb[0] / 4, d1 = ca[1] / 4 - cb[1] / 4;
         if (d0 * normal[0] + d1 * normal[1] > 0) { axis[0] = normal[0]; axis[1] = normal[1]; }
         else { axis[0] = -normal[0]; axis[1] = -normal[1]; }
+        g_axis_dn = fabs(d0 * normal[0] + d1 * normal[1]);
       }
     }
   }
@@ -379,6 +385,8 @@ static void handle_collisions(veh_t *self, veh_t *other, double dt) {
   if (will_intersect) {
     self->impact_x = t[0] / 2; self->impact_y = t[1] / 2; self->has_impact = 1;
     other->impact_x = -t[0] / 2; other->impact_y = -t[1] / 2; other->has_impact = 1;
+    self->impact_margin = fmin(self->impact_margin, g_axis_dn);
+    other->impact_margin = fmin(other->impact_margin, g_axis_dn);
   }
   if (intersecting) {
     self->crashed = 1;
@@ -892,6 +900,7 @@ static int load_env(const ix_config *c, const ix_state *st, int e, veh_t *v) {
     o->lane = st->lane[k]; o->target_lane = st->target_lane[k]; o->speed_index = st->speed_index[k];
     o->crashed = st->crashed[k]; o->has_impact = st->has_impact[k]; o->controlled = st->controlled[k];
     o->is_yielding = st->is_yielding[k]; o->yield_timer = st->yield_timer[k]; o->route_len = st->route_len[k];
+    o->impact_margin = INFINITY;
     for (int q = 0; q < R && q < IX_MAX_ROUTE; q++) {
       o->route_from[q] = st->route_from[k * R + q];
       o->route_to[q] = st->route_to[k * R + q];
@@ -905,6 +914,7 @@ static void store_env(const ix_config *c, ix_state *st, int e, const veh_t *v, i
   for (int i = 0; i < C; i++) {
     size_t k = (size_t)e * C + i;
     st->present[k] = i < n;
+    if (orc_margin_buf) orc_margin_buf[k] = i < n ? v[i].impact_margin : INFINITY;
     if (i >= n) continue;
     const veh_t *o = &v[i];
     st->x[k] = o->x; st->y[k] = o->y; st->heading[k] = o->heading; st->speed[k] = o->speed;

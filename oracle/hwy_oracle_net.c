@@ -59,6 +59,7 @@ typedef struct {
   double act_steering, act_accel;
   int lane, target_lane, speed_index;
   int crashed, has_impact, check_collisions, controlled, obstacle, present;
+  double impact_margin; /* test diagnostics only: min |d.normal| over the impacts assigned in this call */
 } ent_t;
 
 typedef struct {
@@ -207,6 +208,10 @@ static void project_polygon(double p[5][2], const double axis[2], double *mn, do
 static double interval_distance(double min_a, double max_a, double min_b, double max_b) { /* utils.py:188-193 */
   return min_a < min_b ? min_b - max_a : min_a - max_b;
 }
+/* Test diagnostics (as in hwy_oracle.c): |d.normal| of the axis that oriented the last translation (utils.py:232-236);
+ * orc_set_margin_buffer (hwy_oracle.c) hands out the per-slot minimum over the impacts assigned during a call. */
+static __thread double g_axis_dn = INFINITY;
+extern double *orc_margin_buf;
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {
@@ -238,6 +243,7 @@ static void are_polygons_intersecting(double a[5][2], double b[5][2], const doub
         double d0 = ca[0] / 4 - cb[0] / 4, d1 = ca[1] / 4 - cb[1] / 4;
         if (d0 * normal[0] + d1 * normal[1] > 0) { axis[0] = normal[0]; axis[1] = normal[1]; }
         else { axis[0] = -normal[0]; axis[1] = -normal[1]; }
+        g_axis_dn = fabs(d0 * normal[0] + d1 * normal[1]);
       }
     }
   }
@@ -280,6 +286,8 @@ static void handle_collisions(ent_t *self, ent_t *other, double dt) {
       self->impact_x = t[0] / 2; self->impact_y = t[1] / 2; self->has_impact = 1;
       other->impact_x = -t[0] / 2; other->impact_y = -t[1] / 2; other->has_impact = 1;
     }
+    self->impact_margin = fmin(self->impact_margin, g_axis_dn);
+    other->impact_margin = fmin(other->impact_margin, g_axis_dn);
   }
   if (intersecting) {
     self->crashed = 1;
@@ -713,6 +721,7 @@ static void load_env(const hwy_config *c, const hwy_state *st, int e, ent_t *v) 
     o->crashed = !!(f & HWY_F_CRASHED); o->has_impact = !!(f & HWY_F_HAS_IMPACT);
     o->check_collisions = !!(f & HWY_F_CHECK_COLLISIONS); o->controlled = !!(f & HWY_F_CONTROLLED);
     o->obstacle = !!(f & HWY_F_OBSTACLE); o->present = !(f & HWY_F_ABSENT);
+    o->impact_margin = INFINITY;
   }
 }
 static void store_env(const hwy_config *c, hwy_state *st, int e, const ent_t *v) {
@@ -727,6 +736,7 @@ static void store_env(const hwy_config *c, hwy_state *st, int e, const ent_t *v)
     st->flags[k] = (o->crashed ? HWY_F_CRASHED : 0) | (o->has_impact ? HWY_F_HAS_IMPACT : 0) |
                    (o->check_collisions ? HWY_F_CHECK_COLLISIONS : 0) | (o->controlled ? HWY_F_CONTROLLED : 0) |
                    (o->obstacle ? HWY_F_OBSTACLE : 0) | (o->present ? 0 : HWY_F_ABSENT);
+    if (orc_margin_buf) orc_margin_buf[k] = o->impact_margin;
   }
 }
 

@@ -95,13 +95,14 @@ def step(cfg: _abi.HwyConfig, st: dict, actions) -> tuple:
 
 
 class impact_margins:
-    """Context manager (test diagnostics): while active, every ``frames`` / ``step`` call of the straight-road oracle
-    fills ``self.margin`` [E, N] with the smallest ``|d . normal|`` (utils.py:232-236) among the impacts assigned to each
+    """Context manager (test diagnostics): while active, every ``frames`` / ``step`` call of the oracle (all three
+    families: straight road, merge networks, and -- with an ``oracle_ix.IxConfig`` -- the intersection, indexed by list position) fills ``self.margin`` [E, N] with the smallest ``|d . normal|`` (utils.py:232-236) among the impacts assigned to each
     vehicle during that call (+inf where none was).  A margin at rounding-noise level marks a collision whose push
     direction is decided by the last bit of the libm in use (two cars on one lane centre, lateral axis)."""
 
     def __init__(self, cfg: _abi.HwyConfig):
-        self.margin = np.full((cfg.num_envs, cfg.num_vehicles), np.inf)
+        n = cfg.num_vehicles if hasattr(cfg, "num_vehicles") else cfg.n_slots
+        self.margin = np.full((cfg.num_envs, n), np.inf)
 
     def __enter__(self):
         lib().orc_set_margin_buffer(self.margin.ctypes.data_as(C.POINTER(C.c_double)))

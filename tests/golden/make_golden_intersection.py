@@ -200,6 +200,14 @@ SCENARIOS = [
     dict(name="intersection_v2", cls="ConnectedLaneIntersectionEnv",
          config={"initial_vehicle_count": 12, "spawn_probability": 0.8, "duration": 16},
          seeds=[41, 42, 43, 44], steps=15, action_seed=45, frames_for=2, n_slots=32),
+    # crash-rich (round 3): dense traffic and an ego that mostly accelerates through the junction -- many FIRST crashes, i.e. the
+    # observation / reward a user sees WITH terminated=True, plus per-frame states (signed impacts) for the first environments
+    dict(name="intersection_crash", config={"initial_vehicle_count": 16, "spawn_probability": 0.9, "duration": 20},
+         seeds=list(range(300, 332)), steps=9, action_seed=61, frames_for=6, n_slots=32, action_p=[0.1, 0.2, 0.7]),
+    # the same with three agents (any crashed agent terminates the episode, intersection_env.py:100-106)
+    dict(name="intersection_crash_ma3", cls="MultiAgentIntersectionEnv",
+         config={"controlled_vehicles": 3, "initial_vehicle_count": 12, "spawn_probability": 0.9, "duration": 20},
+         seeds=list(range(340, 356)), steps=8, action_seed=62, frames_for=2, n_slots=32, action_p=[0.1, 0.2, 0.7]),
 ]
 
 
@@ -212,7 +220,9 @@ def run_scenario(sc: dict) -> dict:
     A = int(dict(cls.default_config(), **sc["config"])["controlled_vehicles"])
     r_max = R_MAX_MA if multi else R_MAX
     rng = np.random.default_rng(sc["action_seed"])
-    actions = rng.integers(0, 3, size=(steps, E, A)).astype(np.int32)
+    p = sc.get("action_p")
+    actions = (rng.choice(3, size=(steps, E, A), p=p) if p is not None
+               else rng.integers(0, 3, size=(steps, E, A))).astype(np.int32)
     out: dict = {"seeds": np.asarray(seeds, np.int64), "actions": actions}
     per_env, tab0 = [], None
     for e, seed in enumerate(seeds):

@@ -67,6 +67,33 @@ class MergeGenericMultiAgent(MergeGenericEnv):
         self.controlled_vehicles = agents
 
 
+class MergeRampEgo(MergeEnv):
+    """MergeEnv whose ego starts ON the acceleration lane ("b", "c", 2), which ends at the ``Obstacle`` (merge_env.py:160), and
+    whose merging IDM vehicle is placed at speed a few car lengths behind it: the vehicle-vs-``Obstacle`` branch of
+    ``handle_collisions`` (objects.py:215-222 via :101-113: the vehicle takes the WHOLE translation) with a terminal observation.
+    Only the initial placement differs; everything that steps, observes and rewards is the reference's code."""
+
+    def _make_vehicles(self) -> None:
+        super()._make_vehicles()
+        road, rng = self.road, self.np_random
+        lane = road.network.get_lane(("b", "c", 2))
+        ego, merging = self.vehicle, road.vehicles[-1]
+        s_ego = rng.uniform(5.0, 45.0)
+        fresh = self.action_type.vehicle_class(road, lane.position(s_ego, rng.uniform(-0.4, 0.4)), heading=lane.heading_at(s_ego),
+                                               speed=rng.uniform(24.0, 30.0))
+        road.vehicles[0] = fresh
+        self.vehicle = fresh
+        self.controlled_vehicles = [fresh]
+        s_m = s_ego - rng.uniform(12.0, 30.0)
+        src = road.network.get_lane(("k", "b", 0))
+        pos = lane.position(s_m, 0.0) if s_m >= 0 else src.position(src.length + s_m, 0.0)
+        m = type(merging)(road, pos, heading=(lane.heading_at(s_m) if s_m >= 0 else src.heading_at(src.length + s_m)),
+                          speed=rng.uniform(22.0, 30.0))
+        m.target_speed = 30.0
+        road.vehicles[-1] = m
+        del ego
+
+
 F64_FIELDS = ["x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y"]
 I8_FIELDS = ["lane", "target_lane", "speed_index", "crashed", "has_impact", "check_collisions", "controlled",
              "obstacle", "present"]
@@ -199,6 +226,22 @@ SCENARIOS = [
                                  "grid_step": [3, 3], "features": ["presence", "x", "y", "vx", "vy", "cos_h", "on_road"],
                                  "features_range": {"x": [-60, 60], "y": [-20, 20], "vx": [-20, 20], "vy": [-10, 10]}}},
          seeds=[40, 41, 42], steps=9, action_seed=39, frames_for=0, n_slots=18, action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),
+    # crash-rich (round 3): FIRST crashes on the merge networks -- what a user sees WITH terminated=True.  Dense generic traffic
+    # with a weaving / accelerating ego; the 4-agent BASELINE config-5 shape; and vehicle-vs-Obstacle hits (MergeRampEgo)
+    dict(name="merge_crash_generic", cls=MergeGenericEnv, config={"lanes_count": 3, "vehicles_count": 30},
+         seeds=list(range(400, 432)), steps=9, action_seed=71, frames_for=6, n_slots=33,
+         action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
+    dict(name="merge_crash_ma4", cls=MergeGenericMultiAgent,
+         config=dict(MA_CFG, lanes_count=4, vehicles_count=40, controlled_vehicles=4),
+         seeds=list(range(440, 452)), steps=8, action_seed=72, frames_for=2, n_slots=43,
+         action_p=[0.25, 0.05, 0.25, 0.4, 0.05]),
+    # (features_range explicit: by default KinematicObservation freezes its y range from the side lanes of the road the ego
+    # STARTS on, observation.py:211-226 -- three lanes on b -> c, two on a -> b)
+    dict(name="merge_crash_obstacle", cls=MergeRampEgo,
+         config={"observation": {"type": "Kinematics",
+                                 "features_range": {"x": [-200, 200], "y": [-12, 12], "vx": [-80, 80], "vy": [-80, 80]}}},
+         seeds=list(range(460, 484)), steps=5, action_seed=73,
+         frames_for=8, n_slots=6, action_p=[0.1, 0.35, 0.15, 0.35, 0.05]),
     dict(name="merge_generic_v1", cls=ConnectedLaneMergeGenericEnv, config={"lanes_count": 3, "vehicles_count": 20},
          seeds=list(range(5)), steps=13, action_seed=36, frames_for=2, n_slots=23,
          action_p=[0.2, 0.2, 0.3, 0.2, 0.1]),

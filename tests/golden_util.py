@@ -80,6 +80,21 @@ class Golden:
         return st
 
 
+KNIFE = 1e-9  # |d.normal| below which the SIGN of a collision push is decided by the last bit of the libm in use
+
+
+def _assert_impacts(got, want, rows, atol, what, signed=None):
+    """Pending impacts on `rows` [E, N]: SIGNED where `signed` [E, N] says the collision is well conditioned (oracle.impact_margins
+    >= KNIFE), otherwise up to a global sign.  The reference orients the minimum-translation vector with `d.dot(normal) > 0`
+    (utils.py:232-236); for two cars tracking the same lane centre d.normal is rounding noise (~1e-16) and its sign differs
+    between any two libm implementations."""
+    for k in ["impact_x", "impact_y"]:
+        np.testing.assert_allclose(np.abs(got[k][rows]), np.abs(want[k][rows]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+        if signed is not None:
+            m = rows & signed
+            np.testing.assert_allclose(got[k][m], want[k][m], rtol=0, atol=atol, err_msg=f"{what}: signed {k}")
+
+
 def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
     for k in ["lane", "target_lane", "flags"]:
         np.testing.assert_array_equal(got[k], want[k], err_msg=f"{what}: {k}")
@@ -110,6 +125,9 @@ def assert_obs_close(got, want, image: bool, what=""):
 MERGE = ["merge_default", "merge_generic_l3", "merge_generic_sections", "merge_ma4", "merge_v1", "merge_generic_v1",
          "merge_no_obstacles"]
 MERGE_GRID = ["merge_grid", "merge_generic_grid_aligned", "merge_grid_image"]  # per-step fixtures with the OccupancyGrid observation
+# crash-rich (round 3): dense merge-generic traffic, the 4-agent config-5 shape, vehicle-vs-Obstacle hits (an ego placed on the
+# acceleration lane: its reset is the generator's, not MergeEnv's)
+MERGE_CRASH = ["merge_crash_generic", "merge_crash_ma4", "merge_crash_obstacle"]
 
 
 class GoldenMerge:
@@ -157,8 +175,8 @@ class GoldenMerge:
         return st
 
 
-def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
-    """assert_state_close for the road-network scenarios (absent slots ignored)."""
+def assert_net_state_close(got: dict, want: dict, atol=1e-9, what="", signed=None):
+    """assert_state_close for the road-network scenarios (absent slots ignored); `signed` [E, N]: see _assert_impacts."""
     pres = (want["flags"] & _abi.F_ABSENT) == 0
     np.testing.assert_array_equal((got["flags"] & _abi.F_ABSENT) == 0, pres, err_msg=f"{what}: present")
     for k in ["lane", "target_lane", "flags"]:
@@ -168,12 +186,12 @@ def assert_net_state_close(got: dict, want: dict, atol=1e-9, what=""):
     np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
     for k in ["x", "y", "heading", "speed", "target_speed"]:
         np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
-    for k in ["impact_x", "impact_y"]:  # up to a global sign (see assert_state_close)
-        np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+    _assert_impacts(got, want, pres, atol, what, signed)
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
 
 
 INTERSECTION = ["intersection_default", "intersection_dense", "intersection_v2"]   # per-frame fixtures (Kinematics observation)
+INTERSECTION_CRASH = ["intersection_crash", "intersection_crash_ma3"]  # crash-rich (round 3), per-frame states for the first envs
 INTERSECTION_GRID = ["intersection_grid", "intersection_grid_aligned", "intersection_grid_image"]  # per-step fixtures, OccupancyGrid observation
 # MultiAgentIntersectionEnv (2 agents with per-frame states; 3 agents with random destinations, per-step states only)
 INTERSECTION_MA = ["intersection_multi_agent", "intersection_multi_agent3"]
@@ -223,7 +241,7 @@ class GoldenIntersection:
         return st
 
 
-def assert_ix_state_close(got: dict, want: dict, atol=1e-9, what=""):
+def assert_ix_state_close(got: dict, want: dict, atol=1e-9, what="", signed=None):
     pres = want["present"] != 0
     np.testing.assert_array_equal(got["present"] != 0, pres, err_msg=f"{what}: present")
     for k in ["lane", "target_lane", "crashed", "has_impact", "controlled", "is_yielding", "route_len"]:
@@ -235,8 +253,7 @@ def assert_ix_state_close(got: dict, want: dict, atol=1e-9, what=""):
     np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
     for k in ["x", "y", "heading", "speed", "target_speed"]:
         np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
-    for k in ["impact_x", "impact_y"]:
-        np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+    _assert_impacts(got, want, pres, atol, what, signed)
     idm = pres & (want["controlled"] == 0)
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
 
@@ -267,7 +284,7 @@ def ix_engine_state(g: "GoldenIntersection", gst: dict, cfg) -> dict:
     return st
 
 
-def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what=""):
+def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what="", signed=None):
     """Two hwy_state dicts of the intersection scenario (absent slots ignored)."""
     pres = (want["flags"] & _abi.F_ABSENT) == 0
     np.testing.assert_array_equal((got["flags"] & _abi.F_ABSENT) == 0, pres, err_msg=f"{what}: present")
@@ -277,8 +294,7 @@ def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what=""):
     np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
     for k in ["x", "y", "heading", "speed", "target_speed"]:
         np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
-    for k in ["impact_x", "impact_y"]:
-        np.testing.assert_allclose(np.abs(got[k][pres]), np.abs(want[k][pres]), rtol=0, atol=atol, err_msg=f"{what}: |{k}|")
+    _assert_impacts(got, want, pres, atol, what, signed)
     idm = pres & ~ctrl
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")
     np.testing.assert_array_equal(got["road_steps"], want["road_steps"], err_msg=f"{what}: road_steps")

@@ -11,7 +11,8 @@ import pytest
 
 from highwayenv_amd import _abi
 from tests.backends import BACKENDS, make_engine
-from tests.golden_util import (INTERSECTION, INTERSECTION_GRID, INTERSECTION_INTENTIONS, INTERSECTION_MA, INTERSECTION_MA_FRAMES,
+from oracle import oracle
+from tests.golden_util import (KNIFE, INTERSECTION_CRASH, INTERSECTION, INTERSECTION_GRID, INTERSECTION_INTENTIONS, INTERSECTION_MA, INTERSECTION_MA_FRAMES,
                                GoldenIntersection,
                                assert_ix_engine_state_close,
                                ix_engine_state)
@@ -29,10 +30,11 @@ def _sub(st, sel):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES + INTERSECTION_CRASH)
 def test_teacher_forced_frames_vs_reference(backend, name):
     """Each simulation frame (meta-action on the first frame of a step, Road.act, RegulatedRoad.step incl. the
-    regulation every 7th frame) from the reference's own state; all recorded frames batched into two engine calls."""
+    regulation every 7th frame) from the reference's own state; all recorded frames batched into two engine calls.
+    Impacts are compared SIGNED wherever the collision is well conditioned (the C oracle's |d.normal| >= KNIFE)."""
     g = GoldenIntersection(name)
     Ef, T = g.frames_for, g.T
     K = g.steps * T
@@ -55,7 +57,7 @@ def test_teacher_forced_frames_vs_reference(backend, name):
     cat = lambda sts: {f: np.concatenate([s[f] for s in sts]) for f in sts[0]}  # noqa: E731
     start, want = cat(starts), cat(wants)
     acts, has_act = np.concatenate(acts), np.concatenate(has_act)
-    n_yield = 0
+    n_yield = n_hit = n_signed = 0
     for sel, with_actions in ((has_act, True), (~has_act, False)):
         idx = np.nonzero(sel)[0]
         cfg = _hwy_config(g, len(idx))
@@ -63,20 +65,34 @@ def test_teacher_forced_frames_vs_reference(backend, name):
         eng.set_state(ix_engine_state(g, _sub(start, idx), cfg))
         eng.step_frames(acts[idx] if with_actions else None, 1)
         w = ix_engine_state(g, _sub(want, idx), cfg)
-        assert_ix_engine_state_close(eng.get_state(), w, atol=1e-9, what=f"{name} actions={with_actions}")
+        oc, ost = g.ix_config(len(idx)), _sub(start, idx)
+        ost.pop("vid", None)
+        with oracle.impact_margins(oc) as m:
+            g.ix.frames(oc, ost, acts[idx] if with_actions else None, 1)
+        n_hit += int(np.isfinite(m.margin).sum())
+        n_signed += int((np.isfinite(m.margin) & (m.margin >= KNIFE)).sum())
+        assert_ix_engine_state_close(eng.get_state(), w, atol=1e-9, what=f"{name} actions={with_actions}",
+                                     signed=m.margin >= KNIFE)
         n_yield += int(((w["flags"] & _abi.F_YIELDING) != 0).sum())
         eng.close()
     assert n_yield > 0
+    print(f"\n{name} [{backend}]: signed impact of {n_signed} / {n_hit} hit vehicle-frames compared with the reference "
+          f"({n_hit - n_signed} on the knife edge)")
+    if name in INTERSECTION_CRASH:
+        assert n_signed >= 0.9 * n_hit > 10
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS)
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS + INTERSECTION_CRASH)
 def test_policy_steps_vs_reference(backend, name):
     """Whole policy steps from the reference's state at the start of each step (host-traffic mode: the kernel does not
     clear / spawn): state, obs, reward, terminated / truncated, info -- all steps of all envs in one engine call.
     The *_grid fixtures carry BASELINE config 4's OccupancyGrid observation (on-road layer over straight lanes of any
     direction and circular arcs, world- and vehicle-aligned cells); the *intentions fixtures the cos_d / sin_d features
-    (Vehicle.destination_direction) with and without observe_intentions."""
+    (Vehicle.destination_direction) with and without observe_intentions.
+    Steps WITH a collision are compared like any other -- the observation and reward returned with terminated=True, positions
+    (1e-6: the frames after the first contact resolve the overlap again and each resolution doubles a difference) and SIGNED
+    impacts -- unless the C oracle, run from the same state, reports a collision on the knife edge (|d.normal| < KNIFE)."""
     g = GoldenIntersection(name)
     E, S = g.E, g.steps
     steps0 = g.z["road_steps0"]
@@ -92,18 +108,29 @@ def test_policy_steps_vs_reference(backend, name):
     eng.set_state(ix_engine_state(g, cat(starts), cfg))
     obs, reward, term, trunc, info = eng.step(g.actions.reshape(E * S, g.A))
     got = eng.get_state()
+    oc, ost = g.ix_config(E * S), cat(starts)
+    ost.pop("vid", None)
+    with oracle.impact_margins(oc) as m:
+        g.ix.step(oc, ost, g.actions.reshape(E * S, g.A))
     live = np.ones(E, bool)
+    n_wreck = n_full = 0
     for t in range(S):
         rows = slice(t * E, (t + 1) * E)
         want = g.state("step", t)
         want["road_steps"][...] = steps0 + (t + 1) * g.T
         want["time"][...] = float(t + 1)
         wreck = ((want["present"] != 0) & ((want["crashed"] != 0) | (want["has_impact"] != 0))).any(1)
-        clean = live & ~wreck
+        well = m.margin[rows] >= KNIFE
+        clean = live & well.all(1)
+        n_wreck += int((live & wreck).sum())
+        n_full += int((clean & wreck).sum())
         what = f"{name} step {t}"
-        sub_cfg = _hwy_config(g, int(clean.sum()))
-        assert_ix_engine_state_close(_sub(_sub(got, rows), clean), ix_engine_state(g, _sub(want, clean), sub_cfg), atol=1e-8,
-                                     what=what)
+        for sel, atol in ((clean & ~wreck, 1e-8), (clean & wreck, 1e-6)):
+            sub_cfg = _hwy_config(g, int(sel.sum()))
+            signed = np.zeros((int(sel.sum()), sub_cfg.num_vehicles), bool)
+            signed[:, :g.N] = well[sel]
+            assert_ix_engine_state_close(_sub(_sub(got, rows), sel), ix_engine_state(g, _sub(want, sel), sub_cfg), atol=atol,
+                                         what=what, signed=signed)
         np.testing.assert_array_equal(term[rows][live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[rows][live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(info["crashed"][rows][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
@@ -119,6 +146,9 @@ def test_policy_steps_vs_reference(backend, name):
         np.testing.assert_allclose(info["speed"][rows][clean, 0], g.z["info_speed"][t][clean], rtol=0, atol=1e-9, err_msg=what)
         live &= ~g.z["terminated"][t].astype(bool)
     eng.close()
+    print(f"\n{name} [{backend}]: {n_wreck} env-steps with a wreck on the road, {n_full} compared in full")
+    if name in INTERSECTION_CRASH:
+        assert n_full >= 0.9 * n_wreck > 0
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -10,10 +10,10 @@ import pytest
 
 from highwayenv_amd import _abi, merge
 from oracle import oracle
-from tests.golden_util import MERGE, MERGE_GRID, GoldenMerge, assert_net_state_close
+from tests.golden_util import KNIFE, MERGE, MERGE_CRASH, MERGE_GRID, GoldenMerge, assert_net_state_close
 
 
-@pytest.mark.parametrize("name", MERGE)
+@pytest.mark.parametrize("name", MERGE + MERGE_CRASH)
 def test_lane_table_is_the_reference_network(name):
     """hwy_config.net built by highwayenv_amd.merge == the reference's RoadNetwork, bit for bit, in
     get_closest_lane_index order (road.py:55-71)."""
@@ -26,7 +26,7 @@ def test_lane_table_is_the_reference_network(name):
     assert c.merge_end_x == float(g.z["end_position"])
 
 
-@pytest.mark.parametrize("name", MERGE)
+@pytest.mark.parametrize("name", MERGE + ["merge_crash_generic", "merge_crash_ma4"])
 def test_reset_replays_the_reference_stream(name):
     """merge.spawn_reference_stream(seed) == the reference's reset(seed=seed), bit for bit (the reference
     appends vehicles compactly; the engine leaves HWY_F_ABSENT slots where the spawn gave up)."""
@@ -42,9 +42,10 @@ def test_reset_replays_the_reference_stream(name):
             np.testing.assert_array_equal(st[k][e][a], want[k][e][b], err_msg=f"{name} env {e}: {k}")
 
 
-@pytest.mark.parametrize("name", MERGE)
+@pytest.mark.parametrize("name", MERGE + MERGE_CRASH)
 def test_oracle_teacher_forced_frames(name):
-    """Every single frame, started from the reference's own state: Road.act + Road.step."""
+    """Every single frame, started from the reference's own state: Road.act + Road.step.  Impacts are compared SIGNED wherever
+    the collision is well conditioned (oracle.impact_margins >= KNIFE), incl. the vehicle-vs-Obstacle branch."""
     g = GoldenMerge(name)
     Ef = g.frames_for
     cfg = g.hwy_config(Ef)
@@ -54,11 +55,13 @@ def test_oracle_teacher_forced_frames(name):
             k = step * g.T + fr
             st = g.state("init", envs=envs) if k == 0 else g.state("frame", k - 1)
             acts = g.actions[step, :Ef] if fr == 0 else None
-            oracle.frames(cfg, st, acts, 1)
-            assert_net_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}")
+            with oracle.impact_margins(cfg) as m:
+                oracle.frames(cfg, st, acts, 1)
+            assert_net_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}",
+                                   signed=m.margin >= KNIFE)
 
 
-@pytest.mark.parametrize("name", MERGE + MERGE_GRID)
+@pytest.mark.parametrize("name", MERGE + MERGE_GRID + MERGE_CRASH)
 def test_oracle_free_running_steps(name):
     """Whole episodes from the reset state, compared while the episode is live (up to and including the
     terminal step; see DESIGN.md section 4 on post-termination wrecks)."""
@@ -68,7 +71,8 @@ def test_oracle_free_running_steps(name):
     np.testing.assert_allclose(oracle.observe(cfg, st), g.z["obs0"], rtol=0, atol=1e-6)
     live = np.ones(g.E, bool)
     for t in range(g.steps):
-        obs, reward, term, trunc, info = oracle.step(cfg, st, g.actions[t])
+        with oracle.impact_margins(cfg) as m:
+            obs, reward, term, trunc, info = oracle.step(cfg, st, g.actions[t])
         what = f"{name} step {t}"
         np.testing.assert_array_equal(term[live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
@@ -80,7 +84,7 @@ def test_oracle_free_running_steps(name):
         np.testing.assert_array_equal(info["crashed"][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
         want = g.state("step", t)
         sub = lambda d: {k: v[live] for k, v in d.items()}  # noqa: E731
-        assert_net_state_close(sub(st), sub(want), atol=1e-8, what=what)
+        assert_net_state_close(sub(st), sub(want), atol=1e-8, what=what, signed=(m.margin >= KNIFE)[live])
         live &= ~g.z["terminated"][t].astype(bool)
     assert not live.all() or g.steps < 12  # the fixtures do reach termination
 
