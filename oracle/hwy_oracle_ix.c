@@ -93,7 +93,7 @@ typedef struct {
   double x, y, heading, speed, timer, target_speed, delta, impact_x, impact_y, act_steering, act_accel;
   int lane, target_lane, speed_index, crashed, has_impact, controlled, is_yielding, yield_timer, route_len;
   int route_from[IX_MAX_ROUTE], route_to[IX_MAX_ROUTE], route_id[IX_MAX_ROUTE];
-  double impact_margin; /* test diagnostics only: min |d.normal| over the impacts assigned in this call */
+  double impact_margin, flag_margin; /* test diagnostics only (hwy_oracle.c: orc_set_margin_buffer, orc_set_flag_margin_buffer) */
 } veh_t;
 
 typedef struct {
@@ -328,11 +328,13 @@ static double interval_distance(double min_a, double max_a, double min_b, double
 /* Test diagnostics (as in hwy_oracle.c): |d.normal| of the axis that oriented the last translation (utils.py:232-236);
  * orc_set_margin_buffer (hwy_oracle.c) hands out the per-slot minimum over the impacts assigned during a call. */
 static __thread double g_axis_dn = INFINITY;
-extern double *orc_margin_buf;
+static __thread double g_flag_dn = INFINITY; /* smallest |interval distance| behind an intersecting / will_intersect decision */
+extern double *orc_margin_buf, *orc_flag_margin_buf;
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {
   *intersecting = *will_intersect = 1;
+  g_flag_dn = INFINITY;
   double min_distance = INFINITY;
   double axis[2] = {0, 0};
   double(*polys[2])[2] = {a, b};
@@ -348,10 +350,12 @@ static void are_polygons_intersecting(double a[5][2], double b[5][2], const doub
       project_polygon(a, normal, &min_a, &max_a);
       project_polygon(b, normal, &min_b, &max_b);
       if (interval_distance(min_a, max_a, min_b, max_b) > 0) *intersecting = 0;
+      g_flag_dn = fmin(g_flag_dn, fabs(interval_distance(min_a, max_a, min_b, max_b)));
       double vp = normal[0] * (da[0] - db[0]) + normal[1] * (da[1] - db[1]);
       if (vp < 0) min_a += vp; else max_a += vp;
       double distance = interval_distance(min_a, max_a, min_b, max_b);
       if (distance > 0) *will_intersect = 0;
+      g_flag_dn = fmin(g_flag_dn, fabs(distance));
       if (!*intersecting && !*will_intersect) break;
       if (fabs(distance) < min_distance) {
         min_distance = fabs(distance);
@@ -382,6 +386,8 @@ static void handle_collisions(veh_t *self, veh_t *other, double dt) {
   double da[2] = {self->speed * cos(self->heading) * dt, self->speed * sin(self->heading) * dt};
   double db[2] = {other->speed * cos(other->heading) * dt, other->speed * sin(other->heading) * dt};
   are_polygons_intersecting(pa, pb, da, db, &intersecting, &will_intersect, t);
+  self->flag_margin = fmin(self->flag_margin, g_flag_dn);
+  other->flag_margin = fmin(other->flag_margin, g_flag_dn);
   if (will_intersect) {
     self->impact_x = t[0] / 2; self->impact_y = t[1] / 2; self->has_impact = 1;
     other->impact_x = -t[0] / 2; other->impact_y = -t[1] / 2; other->has_impact = 1;
@@ -900,7 +906,7 @@ static int load_env(const ix_config *c, const ix_state *st, int e, veh_t *v) {
     o->lane = st->lane[k]; o->target_lane = st->target_lane[k]; o->speed_index = st->speed_index[k];
     o->crashed = st->crashed[k]; o->has_impact = st->has_impact[k]; o->controlled = st->controlled[k];
     o->is_yielding = st->is_yielding[k]; o->yield_timer = st->yield_timer[k]; o->route_len = st->route_len[k];
-    o->impact_margin = INFINITY;
+    o->impact_margin = o->flag_margin = INFINITY;
     for (int q = 0; q < R && q < IX_MAX_ROUTE; q++) {
       o->route_from[q] = st->route_from[k * R + q];
       o->route_to[q] = st->route_to[k * R + q];
@@ -915,6 +921,7 @@ static void store_env(const ix_config *c, ix_state *st, int e, const veh_t *v, i
     size_t k = (size_t)e * C + i;
     st->present[k] = i < n;
     if (orc_margin_buf) orc_margin_buf[k] = i < n ? v[i].impact_margin : INFINITY;
+    if (orc_flag_margin_buf) orc_flag_margin_buf[k] = i < n ? v[i].flag_margin : INFINITY;
     if (i >= n) continue;
     const veh_t *o = &v[i];
     st->x[k] = o->x; st->y[k] = o->y; st->heading[k] = o->heading; st->speed[k] = o->speed;

@@ -59,7 +59,7 @@ typedef struct {
   double act_steering, act_accel;
   int lane, target_lane, speed_index;
   int crashed, has_impact, check_collisions, controlled, obstacle, present;
-  double impact_margin; /* test diagnostics only: min |d.normal| over the impacts assigned in this call */
+  double impact_margin, flag_margin; /* test diagnostics only (hwy_oracle.c: orc_set_margin_buffer, orc_set_flag_margin_buffer) */
 } ent_t;
 
 typedef struct {
@@ -211,11 +211,13 @@ static double interval_distance(double min_a, double max_a, double min_b, double
 /* Test diagnostics (as in hwy_oracle.c): |d.normal| of the axis that oriented the last translation (utils.py:232-236);
  * orc_set_margin_buffer (hwy_oracle.c) hands out the per-slot minimum over the impacts assigned during a call. */
 static __thread double g_axis_dn = INFINITY;
-extern double *orc_margin_buf;
+static __thread double g_flag_dn = INFINITY; /* smallest |interval distance| behind an intersecting / will_intersect decision */
+extern double *orc_margin_buf, *orc_flag_margin_buf;
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {
   *intersecting = *will_intersect = 1;
+  g_flag_dn = INFINITY;
   double min_distance = INFINITY;
   double axis[2] = {0, 0};
   double(*polys[2])[2] = {a, b};
@@ -231,10 +233,12 @@ static void are_polygons_intersecting(double a[5][2], double b[5][2], const doub
       project_polygon(a, normal, &min_a, &max_a);
       project_polygon(b, normal, &min_b, &max_b);
       if (interval_distance(min_a, max_a, min_b, max_b) > 0) *intersecting = 0;
+      g_flag_dn = fmin(g_flag_dn, fabs(interval_distance(min_a, max_a, min_b, max_b)));
       double vp = normal[0] * (da[0] - db[0]) + normal[1] * (da[1] - db[1]);
       if (vp < 0) min_a += vp; else max_a += vp;
       double distance = interval_distance(min_a, max_a, min_b, max_b);
       if (distance > 0) *will_intersect = 0;
+      g_flag_dn = fmin(g_flag_dn, fabs(distance));
       if (!*intersecting && !*will_intersect) break;
       if (fabs(distance) < min_distance) {
         min_distance = fabs(distance);
@@ -276,7 +280,10 @@ static void handle_collisions(ent_t *self, ent_t *other, double dt) {
   if (other == self || !(self->check_collisions || other->check_collisions)) return;
   int intersecting, will_intersect;
   double t[2];
+  g_flag_dn = INFINITY;
   is_colliding(self, other, dt, &intersecting, &will_intersect, t);
+  self->flag_margin = fmin(self->flag_margin, g_flag_dn);
+  other->flag_margin = fmin(other->flag_margin, g_flag_dn);
   if (will_intersect) {
     if (other->obstacle) {
       self->impact_x = t[0]; self->impact_y = t[1]; self->has_impact = 1;
@@ -721,7 +728,7 @@ static void load_env(const hwy_config *c, const hwy_state *st, int e, ent_t *v) 
     o->crashed = !!(f & HWY_F_CRASHED); o->has_impact = !!(f & HWY_F_HAS_IMPACT);
     o->check_collisions = !!(f & HWY_F_CHECK_COLLISIONS); o->controlled = !!(f & HWY_F_CONTROLLED);
     o->obstacle = !!(f & HWY_F_OBSTACLE); o->present = !(f & HWY_F_ABSENT);
-    o->impact_margin = INFINITY;
+    o->impact_margin = o->flag_margin = INFINITY;
   }
 }
 static void store_env(const hwy_config *c, hwy_state *st, int e, const ent_t *v) {
@@ -737,6 +744,7 @@ static void store_env(const hwy_config *c, hwy_state *st, int e, const ent_t *v)
                    (o->check_collisions ? HWY_F_CHECK_COLLISIONS : 0) | (o->controlled ? HWY_F_CONTROLLED : 0) |
                    (o->obstacle ? HWY_F_OBSTACLE : 0) | (o->present ? 0 : HWY_F_ABSENT);
     if (orc_margin_buf) orc_margin_buf[k] = o->impact_margin;
+    if (orc_flag_margin_buf) orc_flag_margin_buf[k] = o->flag_margin;
   }
 }
 

@@ -103,11 +103,20 @@ class impact_margins:
     def __init__(self, cfg: _abi.HwyConfig):
         n = cfg.num_vehicles if hasattr(cfg, "num_vehicles") else cfg.n_slots
         self.margin = np.full((cfg.num_envs, n), np.inf)
+        # smallest |interval distance| behind an `intersecting` / `will_intersect` decision (utils.py:222-229) of any SAT the
+        # vehicle took part in: ~0 once a wreck, pushed back by its impact, rests exactly touching what it hit
+        self.flag_margin = np.full((cfg.num_envs, n), np.inf)
 
     def __enter__(self):
         lib().orc_set_margin_buffer(self.margin.ctypes.data_as(C.POINTER(C.c_double)))
+        lib().orc_set_flag_margin_buffer(self.flag_margin.ctypes.data_as(C.POINTER(C.c_double)))
         return self
 
     def __exit__(self, *exc):
         lib().orc_set_margin_buffer(None)
+        lib().orc_set_flag_margin_buffer(None)
         return False
+
+    def well(self, knife: float = 1e-9) -> np.ndarray:
+        """[E]: every collision decision of the call is well conditioned (push direction AND flags)."""
+        return (self.margin.min(1) >= knife) & (self.flag_margin.min(1) >= knife)

@@ -199,3 +199,113 @@ def test_fast_bodies_on_the_merge_network(backend):
         n_hit += int(((ref["flags"] & _abi.F_HAS_IMPACT) != 0)[pres].sum())
     eng.close()
     assert n_hit > 0
+
+
+# ---- the road-network families (round 3): merge (incl. vehicle-vs-Obstacle) and intersection -----------------------------
+# The whole-step comparisons live next to the other parity tests of each family (test_net_parity.py::
+# test_free_running_episodes_vs_reference / _rollout_vs_oracle, test_ix_parity.py::test_policy_steps_vs_reference: every
+# collision step in full unless a push is on the knife edge); here: the per-FRAME signed-impact agreement rate with the
+# reference's recorded frames, one number per family, like test_impact_sign_agreement_rate above.
+
+def _cat(sts):
+    return {f: np.concatenate([s[f] for s in sts]) for f in sts[0]}
+
+
+def _sub(st, sel):
+    return {k: np.ascontiguousarray(v[sel]) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_impact_sign_agreement_rate_merge(backend):
+    """Every recorded frame of the crash-rich merge traces, teacher-forced from the reference's own state: the SIGNED impact of
+    every vehicle hit in that frame, engine vs reference (objects.py:101-113: halves for two vehicles, the whole translation
+    for a vehicle against the Obstacle).  A disagreement is allowed only on the knife edge (|d.normal| < KNIFE)."""
+    from tests.golden_util import MERGE_CRASH, GoldenMerge
+    total = agree = knife = vs_obstacle = 0
+    for name in MERGE_CRASH:
+        g = GoldenMerge(name)
+        Ef, T = g.frames_for, g.T
+        for with_actions in (True, False):
+            ks = [k for k in range(g.steps * T) if (k % T == 0) == with_actions]
+            ks = [k for k in ks if g.z["frame_has_impact"][k].any()]   # frames in which the reference recorded a hit
+            if not ks:
+                continue
+            start = _cat([g.state("init", envs=slice(0, Ef)) if k == 0 else g.state("frame", k - 1) for k in ks])
+            want = _cat([g.state("frame", k) for k in ks])
+            acts = np.concatenate([g.actions[k // T, :Ef] for k in ks]).astype(np.int32)
+            cfg = g.hwy_config(len(ks) * Ef)
+            eng = make_engine(backend, cfg)
+            eng.set_state(start)
+            eng.step_frames(acts if with_actions else None, 1)
+            got = eng.get_state()
+            eng.close()
+            ref = _abi.copy_state(start)
+            with oracle.impact_margins(cfg) as m:
+                oracle.frames(cfg, ref, acts if with_actions else None, 1)
+            hit = (want["flags"] & _abi.F_HAS_IMPACT) != 0
+            np.testing.assert_array_equal((got["flags"] & _abi.F_HAS_IMPACT) != 0, hit, err_msg=name)
+            same = _signed_impacts_equal(got, want, hit)
+            mg = m.margin[hit]
+            total += int(hit.sum())
+            agree += int(same.sum())
+            knife += int((mg < KNIFE).sum())
+            # a vehicle whose impact is the WHOLE translation: its partner was the Obstacle (which never gets one)
+            obst = ((want["flags"] & _abi.F_OBSTACLE) != 0) & np.isfinite(m.margin)
+            vs_obstacle += int((hit & obst.any(1)[:, None]).sum())
+            assert (same | (mg < KNIFE)).all(), f"{name}: impact sign differs on a well-conditioned collision"
+    print(f"\nimpact sign agreement, merge family [{backend}]: {agree} / {total} hit vehicle-frames agree with the reference "
+          f"({100.0 * agree / max(total, 1):.1f} %), {knife} on the knife edge, {vs_obstacle} in frames where the Obstacle was hit")
+    assert total > 100 and vs_obstacle > 20
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_impact_sign_agreement_rate_intersection(backend):
+    """The same for the intersection kernel on the crash-rich IntersectionEnv / MultiAgentIntersectionEnv traces."""
+    from tests.golden_util import INTERSECTION_CRASH, GoldenIntersection, ix_engine_state
+    total = agree = knife = 0
+    for name in INTERSECTION_CRASH + ["intersection_dense"]:
+        g = GoldenIntersection(name)
+        Ef, T = g.frames_for, g.T
+        steps0 = g.z["road_steps0"][:Ef]
+        envs = slice(0, Ef)
+        for with_actions in (True, False):
+            ks = [k for k in range(g.steps * T) if (k % T == 0) == with_actions and g.z["frame_has_impact"][k].any()]
+            if not ks:
+                continue
+            starts, wants = [], []
+            for k in ks:
+                step, fr = divmod(k, T)
+                s0 = (g.state("init", envs=envs) if step == 0 else g.state("next", step - 1, envs=envs)) if fr == 0 \
+                    else g.state("frame", k - 1)
+                s0["road_steps"][...] = steps0 + k
+                w = g.state("frame", k)
+                w["road_steps"][...] = steps0 + k + 1
+                starts.append(s0)
+                wants.append(w)
+            start, want = _cat(starts), _cat(wants)
+            acts = np.concatenate([g.actions[k // T, :Ef] for k in ks]).astype(np.int32)
+            cfg_d = dict(g.config, max_vehicles=g.N, host_traffic=True)
+            cfg = _abi.make_config(cfg_d, len(ks) * Ef, scenario="intersection")
+            eng = make_engine(backend, cfg)
+            eng.set_state(ix_engine_state(g, start, cfg))
+            eng.step_frames(acts if with_actions else None, 1)
+            got = eng.get_state()
+            eng.close()
+            oc = g.ix_config(len(ks) * Ef)
+            ost = {k_: v for k_, v in start.items() if k_ != "vid"}
+            with oracle.impact_margins(oc) as m:
+                g.ix.frames(oc, ost, acts if with_actions else None, 1)
+            w = ix_engine_state(g, want, cfg)
+            hit = (w["flags"] & _abi.F_HAS_IMPACT) != 0
+            np.testing.assert_array_equal(((got["flags"] & _abi.F_HAS_IMPACT) != 0) & ((w["flags"] & _abi.F_ABSENT) == 0), hit,
+                                          err_msg=name)
+            same = _signed_impacts_equal(got, w, hit)
+            mg = np.full(hit.shape, np.inf)
+            mg[:, :g.N] = m.margin
+            total += int(hit.sum())
+            agree += int(same.sum())
+            knife += int((mg[hit] < KNIFE).sum())
+            assert (same | (mg[hit] < KNIFE)).all(), f"{name}: impact sign differs on a well-conditioned collision"
+    print(f"\nimpact sign agreement, intersection family [{backend}]: {agree} / {total} hit vehicle-frames agree with the "
+          f"reference ({100.0 * agree / max(total, 1):.1f} %), {knife} on the knife edge")
+    assert total > 100

@@ -23,16 +23,20 @@ def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, com
     for t in range(steps):
         acts = (rng.integers(0, _abi.num_actions(cfg), size=(E, cfg.num_agents)) if actions is None else np.full((E, cfg.num_agents), actions[t % len(actions)])).astype(np.int32)
         obs, reward, term, trunc, info = eng.step(acts)
-        o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
+        with oracle.impact_margins(cfg) as m:
+            o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
         wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
-        ok = live & (~wreck | compare_wrecks)
+        # the step of an env's first collision is compared like any other (terminal observation, reward, positions) unless a
+        # push direction sits on the knife edge (|d.normal| < 1e-9, utils.py:232-236); assert_state_close compares |impact|
+        ok = live & (~wreck | compare_wrecks | (m.margin.min(1) >= 1e-9))
         what = f"step {t}"
         np.testing.assert_array_equal(term[live], te2[live], err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
         assert_obs_close(obs[ok], o2[ok], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
         np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
-        assert_state_close({k: v[ok] for k, v in got.items()}, {k: v[ok] for k, v in ref.items()}, atol=1e-7, what=what)
+        for rows, atol in ((ok & ~wreck, 1e-7), (ok & wreck, 1e-6)):
+            assert_state_close({k: v[rows] for k, v in got.items()}, {k: v[rows] for k, v in ref.items()}, atol=atol, what=what)
         live &= ~wreck
         if not live.all():  # keep dead envs in lock-step with the oracle so that live ones stay comparable
             for k in got:

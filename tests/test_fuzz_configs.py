@@ -12,6 +12,9 @@ from tests.test_edge_cases import rollout
 
 pytestmark = pytest.mark.gpu
 
+# whole-step coverage of the intersection fuzz (printed per chunk): the rest are env-steps in which some car is below 1 m/s
+INTERSECTION_WHOLE_STEP_FLOOR = 0.15
+
 
 def random_config(rng):
     fast = bool(rng.integers(2))
@@ -128,14 +131,36 @@ def random_intersection_config(rng):
     return cfg
 
 
+def _unmatched_rows(h, o, tol=1e-6):
+    """Rows of `h` [V, F] with no partner in `o` within `tol` (each row of `o` used once): the two observations as SETS."""
+    free = list(range(len(o)))
+    miss = 0
+    for r in h:
+        j = next((j for j in free if np.abs(r - o[j]).max() <= tol), None)
+        if j is None:
+            miss += 1
+        else:
+            free.remove(j)
+    return miss
+
+
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))
 def test_random_intersection_configurations_vs_oracle(chunk):
-    """Device-traffic engine drives the episodes (reset, clear, spawn, auto-reset on Philox); every step is replayed from
-    its own state on a host-traffic engine and on the oracle and compared (wreck-free, no vehicle near standstill)."""
+    """Device-traffic engine drives the episodes (reset, clear, spawn, auto-reset on Philox); every step is replayed from its
+    own state on a host-traffic engine and on the oracle.  Two comparisons, and the fraction each covers is PRINTED and asserted:
+
+    * the FIRST FRAME of every env-step (meta-action, Road.act, Road.step incl. collisions) at 1e-9 -- every environment,
+      whatever its speeds and wrecks;
+    * the WHOLE policy step (15 frames + observation + reward + termination) wherever 15 frames of one trajectory are
+      comparable between two libms: no vehicle below 1 m/s (steering_control divides by not_zero(speed) twice, so last-bit
+      differences grow 1e2..1e4 x per frame there -- at an intersection cars yield and queue, so this is the bulk of the
+      exclusions), no lane-index knife edge, and -- steps WITH a collision are compared like any other -- no push on the
+      knife edge (|d.normal| < 1e-9)."""
     from highwayenv_amd.engine import Engine
-    from oracle import oracle_ix
+    from oracle import oracle, oracle_ix
     from tests.golden_util import assert_obs_close, ix_oracle_config, ix_oracle_state
     rng = np.random.default_rng(5000 + chunk)
+    tot_steps = tot_checked = tot_frames = tot_col = tot_col_full = tot_img_cells = 0
     for k in range(4):
         cfg = random_intersection_config(rng)
         E = 12
@@ -146,26 +171,46 @@ def test_random_intersection_configurations_vs_oracle(chunk):
             oc = ix_oracle_config(dict(cfg, host_traffic=True), ch, E)
             dev.reset(base_seed=chunk * 1000 + k)
             dev.set_autoreset(True, base_seed=chunk * 1000 + k)
-            checked = n_flip = n_cut = 0
+            checked = n_flip = n_cut = n_live = 0
             feats = list(cfg["observation"].get("features") or [])
             done_prev = np.zeros(E, bool)
             for t in range(10):
                 st = dev.get_state()
                 acts = rng.integers(0, 3, size=(E, c.num_agents)).astype(np.int32)
+                pres = (st["flags"] & _abi.F_ABSENT) == 0
+                # -- first frame, every environment ------------------------------------------------------------------
+                ost1 = ix_oracle_state(st, ch)
+                host.set_state(st)
+                host.step_frames(acts, 1)
+                with oracle.impact_margins(oc) as m1:
+                    oracle_ix.frames(oc, ost1, acts, 1)
+                g1 = host.get_state()
+                fine = ~done_prev & (m1.margin.min(1) >= 1e-9)
+                for f in ("x", "y", "heading", "speed"):
+                    np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
+                for f in ("impact_x", "impact_y"):  # signed
+                    np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
+                np.testing.assert_array_equal(((g1["flags"] & _abi.F_HAS_IMPACT) != 0)[fine], (ost1["has_impact"] != 0)[fine])
+                np.testing.assert_array_equal(((g1["flags"] & _abi.F_YIELDING) != 0)[fine], (ost1["is_yielding"] != 0)[fine])
+                tot_frames += int(fine.sum())
+                # -- the whole policy step -----------------------------------------------------------------------------
                 ost = ix_oracle_state(st, ch)
                 host.set_state(st)
                 h_obs, h_rew, h_term, h_trunc, _ = host.step(acts)
-                o_obs, _, o_term, o_trunc, o_info = oracle_ix.step(oc, ost, acts)
+                with oracle.impact_margins(oc) as m:
+                    o_obs, _, o_term, o_trunc, o_info = oracle_ix.step(oc, ost, acts)
                 o_rew = o_info["agents_rewards"]
                 rows = lambda o: o.reshape(-1, *o.shape[-2:])  # noqa: E731  ([n, A, V, F] or [n, V, F] -> agent rows)
-                pres = (st["flags"] & _abi.F_ABSENT) == 0
-                bad = (pres & ((st["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
                 # (steering_control divides by not_zero(speed) twice: below ~1 m/s last-bit differences grow fast)
                 # (and a car that IDM has pushed into REVERSE behind a leader a few centimetres away -- seen with the connected-lane
                 #  search, which finds leaders across segment ends -- multiplies differences ~8x per frame through 1 / d**2)
-                bad |= (pres & (st["speed"] < 1.0)).any(1) | ((ost["present"] != 0) & (ost["speed"] < 1.0)).any(1)
-                bad |= ((ost["present"] != 0) & ((ost["crashed"] != 0) | (ost["has_impact"] != 0))).any(1)
+                bad = (pres & (st["speed"] < 1.0)).any(1) | ((ost["present"] != 0) & (ost["speed"] < 1.0)).any(1)
+                wreck = ((ost["present"] != 0) & ((ost["crashed"] != 0) | (ost["has_impact"] != 0))).any(1)
+                tot_col += int((wreck & ~bad & ~done_prev).sum())
+                bad |= m.margin.min(1) < 1e-9      # a push direction on the knife edge (utils.py:232-236)
+                tot_col_full += int((wreck & ~bad & ~done_prev).sum())
                 ok = ~bad & ~done_prev  # (a finished episode is re-spawned by the device engine in this very step)
+                n_live += int((~done_prev).sum())
                 got = host.get_state()
                 # Knife edge of the reference itself: where three lanes leave an "ir" node together (same start point, same
                 # heading) a vehicle is equally close to all of them, and get_closest_lane_index is decided by the last bit
@@ -179,17 +224,14 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                 if c.obs_type == _abi.OBS_KINEMATICS:
                     # second knife edge of the reference: cars queued on a road PERPENDICULAR to the observer's lane all have
                     # the same longitudinal coordinate on that lane up to rounding, and close_objects_to sorts by it
-                    # (road.py:446) -- the row order among them is noise; rows are compared as a set
-                    def canon(o):
-                        o = np.round(o.astype(np.float64), 5)
-                        return np.stack([r[np.lexsort(r.T[::-1])] for r in o]) if len(o) else o
+                    # (road.py:446) -- the row order among them is noise: first the rows in order at 1e-6, and only where
+                    # that fails as a SET at 1e-6 (no rounding) ...
                     # ... and when more vehicles are eligible than the observation has rows, the same tie decides WHICH of the
                     # queued cars make the cut: an agent's observation may differ in rows that share their x or their y
                     # (the queue's coordinate) with another observed row -- tolerated, and counted
-                    hr, orr = canon(rows(h_obs[ok])), canon(rows(o_obs[ok]))
                     ix_x, ix_y = feats.index("x"), feats.index("y")
-                    for hq, oq in zip(hr, orr):
-                        if np.abs(hq - oq).max() <= 2e-5:
+                    for hq, oq in zip(rows(h_obs[ok]).astype(np.float64), rows(o_obs[ok]).astype(np.float64)):
+                        if np.abs(hq - oq).max() <= 1e-6 or _unmatched_rows(hq, oq) == 0:
                             continue
                         seen = oq[oq[:, 0] > 0]
                         queued = any((np.abs(seen[:, col][:, None] - seen[:, col][None, :]) < 1e-4).sum() > len(seen)
@@ -198,15 +240,28 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                         n_cut += 1
                     np.testing.assert_allclose(rows(h_obs[ok])[:, 0], rows(o_obs[ok])[:, 0], rtol=0, atol=1e-6, err_msg=f"step {t}: ego row")
                 else:
-                    assert_obs_close(h_obs[ok].reshape(o_obs[ok].shape), o_obs[ok], bool(c.flags & _abi.C_GRID_IMAGE), f"step {t}")
+                    image = bool(c.flags & _abi.C_GRID_IMAGE)
+                    assert_obs_close(h_obs[ok].reshape(o_obs[ok].shape), o_obs[ok], image, f"step {t}")
+                    if image:
+                        tot_img_cells += int((h_obs[ok].reshape(o_obs[ok].shape) != o_obs[ok]).sum())
                 np.testing.assert_allclose(h_rew[ok], o_rew[ok], rtol=0, atol=1e-9, err_msg=f"step {t}")
-                np.testing.assert_allclose(got["x"][ok], ost["x"][ok], rtol=0, atol=1e-7, err_msg=f"step {t}")
+                np.testing.assert_allclose(got["x"][ok & ~wreck], ost["x"][ok & ~wreck], rtol=0, atol=1e-7, err_msg=f"step {t}")
+                np.testing.assert_allclose(got["x"][ok], ost["x"][ok], rtol=0, atol=1e-6, err_msg=f"step {t}")
                 checked += int(ok.sum())
                 d_obs, d_rew, d_term, d_trunc, _ = dev.step(acts)
                 np.testing.assert_array_equal(d_term[ok], h_term[ok])  # same dynamics with device traffic switched on
                 done_prev = d_term | d_trunc
-            assert checked > 20 and n_flip <= 0.05 * checked + 2 and n_cut <= 0.05 * checked * c.num_agents + 2
+            assert n_flip <= 0.05 * checked + 2 and n_cut <= 0.05 * checked * c.num_agents + 2
+            tot_steps += n_live
+            tot_checked += checked
             for e_ in (dev, host):
                 e_.close()
         except AssertionError as ex:
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
+    frac = tot_checked / max(tot_steps, 1)
+    print(f"\nintersection fuzz chunk {chunk}: {tot_steps} live env-steps; first frame compared at 1e-9 on {tot_frames} "
+          f"({100.0 * tot_frames / max(tot_steps, 1):.1f} %), whole step on {tot_checked} ({100.0 * frac:.1f} %); "
+          f"{tot_col} fast-enough steps with a wreck, {tot_col_full} of them in full; as_image cells off by one: {tot_img_cells}")
+    assert tot_frames >= 0.97 * tot_steps, "the first-frame comparison must cover (nearly) every live env-step"
+    assert frac >= INTERSECTION_WHOLE_STEP_FLOOR, f"only {100 * frac:.1f} % of the env-steps were compared as whole steps"
+    assert tot_col_full >= 0.9 * tot_col
