@@ -5,12 +5,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started WITHOUT a torch.distributed environment (no WORLD_SIZE) and with --gpus N > 1, bench.py
+re-launches itself under torch.distributed.run with N ranks on 127.0.0.1 (a free port) and still prints ONE JSON line.
+
+    python bench.py --gpus 8 --scaling strong                               # 4096 envs in TOTAL, 512 per GPU
+    python bench.py --gpus 8 --workload v0_n100 --envs-per-gpu 1024         # BASELINE config 3: 8192 x 101 over 8 GPUs
+
 Workload (BASELINE.json configs[1]): highway-fast-v0 semantics, 4096 batched envs x 50 IDM
 vehicles (+1 ego = 51) per GPU, 4 lanes, DiscreteMetaAction (uniform random actions, pre-generated
 and resident in HBM), Kinematics 5x5 observation, device-side spawn + auto-reset on
 terminated/truncated.  One "step" == one batched policy step of every env == ONE launch of
-hwy_step_kernel (5 simulation frames + observe + reward + done).  Weak scaling: every rank owns
-4096 envs; with N>1 ranks the (obs, reward, terminated, truncated) blocks of every rank are gathered
+hwy_step_kernel (5 simulation frames + observe + reward + done).  Weak scaling (default): every rank owns
+4096 envs (--scaling strong: --envs-per-gpu is the TOTAL, block-partitioned over the ranks); with N>1 ranks the (obs, reward, terminated, truncated) blocks of every rank are gathered
 to rank 0 over RCCL, --gather-every (16) steps per collective, overlapped with the following steps.
 
 Timing protocol: W untimed warm-up steps, then --repeats (5) timed regions of EXACTLY K = --steps
@@ -62,15 +68,17 @@ def _load_counters(name: str, workload: str):
     """A committed rocprofv3 PMC summary (profiles/<name>) -- returned ONLY if it was recorded for the kernel build
     being timed (its `kernel_source_sha16` equals this build's) and for this workload: counters of another build
     say nothing about this one, and PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    d = d.get(workload, d) if isinstance(d.get(workload), dict) else d
-    if d.get("kernel_source_sha16") is None or d.get("kernel_source_sha16") != _kernel_build_id():
-        return None
-    return d
+    for rnd in ("r03", "r02"):  # the newest round's file first
+        path = os.path.join(ROOT, "profiles", name.replace("RND", rnd))
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        d = d.get(workload, d) if isinstance(d.get(workload), dict) else d
+        if d.get("kernel_source_sha16") is not None and d.get("kernel_source_sha16") == _kernel_build_id():
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d
+    return None
 
 
 def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
@@ -78,7 +86,7 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     flops per launch from the committed SQ instruction counts (tools/pmc_sq.sh: add / mul = 1 flop, fma = 2, x 64 lanes x
     one wave per environment) over the launch duration measured in THIS run, against the 78.6 TFLOP/s f64 vector peak of
     MI355X, and the measured VALU issue utilisation.  None unless the counters belong to this kernel build."""
-    d = _load_counters("r02_pmc_sq.json", workload)
+    d = _load_counters("RND_pmc_sq.json", workload)
     if d is None or d.get("envs") != envs_per_gpu:
         return None
     c = d["per_wave_per_step"]
@@ -87,7 +95,7 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
             "valu_instructions_per_env_step": c["SQ_INSTS_VALU"], "salu_instructions_per_env_step": c["SQ_INSTS_SALU"],
             "valu_issue_utilisation_while_resident": c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"],
-            "source": "profiles/r02_pmc_sq.json (SQ counters of this kernel build and config)"}
+            "source": d["_file"] + " (SQ counters of this kernel build and config)"}
 
 
 def measured_traffic(workload: str, envs_per_gpu: int):
@@ -95,37 +103,42 @@ def measured_traffic(workload: str, envs_per_gpu: int):
     passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
     tools/traffic_report.py -> profiles/traffic_r02.json).  None if absent, recorded for another kernel build, or for
     another batch size."""
-    d = _load_counters("traffic_r02.json", workload)
+    d = _load_counters("traffic_RND.json", workload)
     if d is None or d.get("envs") != envs_per_gpu:
         return None
     return d["traffic_bytes_per_launch_calibrated"]
 
 
 def cpu_baseline(workload: str, cfg_dict, fast: bool, scenario: str, have_gpu: bool = True):
-    """The CPU leg.  With the reference package on this box: the unmodified reference, timed here (kind "reference"),
-    plus the C port for comparison.  Without it: the C port (kind "port") plus the committed reference measurement of
-    the build container, labelled as another box's."""
+    """The CPU leg, >= 30 s of host work.  Top level = what was timed ON THIS BOX IN THIS RUN: the unmodified
+    reference where the package exists (kind "reference"), else the C port of the oracle (kind "port").  Next to it, always:
+    ``"reference"`` -- the unmodified reference's figure as a first-class object with ``same_box: true`` (this run) or
+    ``false`` (the committed build-container measurement, profiles/reference_cpu_baseline.json) -- and ``"port"``."""
     from oracle import ref_bench
     port = None
     if have_gpu or scenario != "intersection":  # (the intersection port takes its start states from the engine)
         port = cpu_baseline_port(cfg_dict, fast, scenario=scenario)
     if ref_bench.available():
-        out = ref_bench.measure(workload)
+        out = ref_bench.measure(workload, budget_s=20.0, all_cores_budget_s=10.0)
+        out["reference"] = dict({k: v for k, v in out.items() if k != "all_cores"}, same_box=True, all_cores=out.get("all_cores"))
         if port is not None:
             out["port"] = port
         return out
-    out = port
+    out = dict(port)
+    out["port"] = port
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu_baseline.json")))[workload]
+        rec = {k: v for k, v in rec.items() if k not in ("port", "reference")}
+        rec["same_box"] = False
         rec["note"] = ("NOT THE SAME BOX: the unmodified reference timed in the build container (the reference package does "
                        "not exist on this box); committed by `python bench.py --cpu-baseline-only --save-cpu-baseline`")
-        out["reference_elsewhere"] = rec
+        out["reference"] = rec
     except Exception:
-        out["reference_elsewhere"] = None
+        out["reference"] = None
     return out
 
 
-def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 12.0, scenario: str = "highway"):
+def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 20.0, scenario: str = "highway"):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
     from highwayenv_amd import _abi, merge, spawn
@@ -162,7 +175,7 @@ def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 12.0, scena
     n_thr = min(64, os.cpu_count() or 1)
     if n_thr > 1:
         counts = [0] * n_thr
-        stop_at = time.perf_counter() + 5.0
+        stop_at = time.perf_counter() + 10.0
 
         def worker(k):
             st_k = _abi.copy_state(st0)
@@ -187,7 +200,7 @@ def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 12.0, scena
     return out
 
 
-def cpu_baseline_intersection(cfg_dict, budget_s: float = 12.0):
+def cpu_baseline_intersection(cfg_dict, budget_s: float = 30.0):
     """oracle/hwy_oracle_ix.c (1 thread) on the same workload: start states from the engine's device reset, random
     actions, clearing and spawning with numpy draws in the reference's format."""
     from highwayenv_amd import _abi
@@ -255,13 +268,45 @@ def workload_config(workload: str):
     return cfg_dict, fast, scenario
 
 
+def launcher_command(argv, n_gpus: int, port: int):
+    """`python bench.py --gpus N ...` started without a torch.distributed environment: the command it re-launches itself with
+    (one rank per GPU of this node, rendezvous on 127.0.0.1 -- the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv, n_gpus: int) -> int:
+    """Re-exec under torch.distributed.run and pass the ranks' stdout (rank 0's ONE JSON line) and stderr through."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        raise SystemExit(f"--gpus {n_gpus}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = launcher_command(argv, n_gpus, _free_port())
+    print("bench.py: no torch.distributed environment, launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed steps PER REGION (SURVEY 8d: >= 1000)")
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU,
+                    help="environments per GPU (weak scaling, the default); with --scaling strong: the TOTAL over all GPUs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every GPU steps --envs-per-gpu environments; strong: that many in TOTAL, block-partitioned "
+                         "over the ranks like highwayenv_amd.dist.shard_range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="run only the CPU leg (needs no GPU): the unmodified reference where it is installed, else the C port")
@@ -279,8 +324,11 @@ def main() -> None:
                          "(intersection-v0, 30 vehicle slots, OccupancyGrid 4 x 11 x 11 obs; use --envs-per-gpu 2048); intersection_kin = "
                          "the same with intersection-v0's default Kinematics 15 x 7 observation")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds); repeatable")
+                    help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds, prio_shift, "
+                         "ix_prewarm_frames: highwayenv_amd._abi.TUNING_KEYS); selects a kernel variant, never changes a result; repeatable")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
     cfg_dict, fast, scenario = workload_config(args.workload)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner through C
@@ -313,8 +361,7 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -331,6 +378,12 @@ def main() -> None:
     from highwayenv_amd.dist import PackedStepOutputs
 
     E = args.envs_per_gpu
+    if args.scaling == "strong":  # --envs-per-gpu environments in TOTAL: this rank's block (remainders to the lowest ranks)
+        from highwayenv_amd.dist import shard_range
+        if args.envs_per_gpu % world:
+            raise SystemExit(f"--scaling strong: {args.envs_per_gpu} environments do not split evenly over {world} ranks "
+                             "(the packed gather needs equal blocks)")
+        E = len(shard_range(args.envs_per_gpu, world, rank))
     cfg = _abi.make_config(cfg_dict, E, fast=fast, scenario=scenario, tuning=tuning)
     N, A = cfg.num_vehicles, cfg.num_agents
     spawn_kw = ({"ego_spacing": cfg_dict["ego_spacing"], "vehicles_density": cfg_dict["vehicles_density"]}
@@ -452,8 +505,12 @@ def main() -> None:
         env_steps = args.steps * E * world
         value = env_steps / elapsed
         b_env = algorithmic_bytes_per_env_step(N, A, int(np.prod(_abi.obs_shape(cfg))))
-        # without HIP events (HWY_BENCH_NO_EVENTS=1, a developer knob) fall back to the wall-clock step time
-        avg_kernel_s = kernel_ms / 1e3 / launches if launches else elapsed / args.steps
+        # The dominant kernel's launch duration: HIP events on the launch stream around every 8th launch, MINUS what an empty
+        # event pair alone measures on that stream (~5 us), and never more than the wall-clock step that contains the launch
+        # (a kernel cannot take longer than its step).  Without events (HWY_BENCH_NO_EVENTS=1, a developer knob): the wall step.
+        wall_step_s = elapsed / args.steps
+        event_kernel_s = (kernel_ms / 1e3 / launches - event_pair_us * 1e-6) if launches else None
+        avg_kernel_s = min(event_kernel_s, wall_step_s) if event_kernel_s and event_kernel_s > 0 else wall_step_s
         achieved = b_env * E / avg_kernel_s / 1e9
         line = {
             "metric": "env-steps/s",
@@ -467,7 +524,7 @@ def main() -> None:
             "ms_per_step_repeats": [x / args.steps * 1e3 for x in region_s],
             "timing": f"median of {R} regions of {args.steps} steps (barrier + synchronize on both sides, max over ranks)",
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -502,6 +559,8 @@ def main() -> None:
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
+                         "avg_kernel_us_method": "min(HIP-event bracket - empty event pair, wall ms_per_step)",
+                         "event_bracket_us": (kernel_ms / launches * 1e3) if launches else None,
                          "empty_event_pair_us": event_pair_us,
                          "algorithmic_bytes_per_launch": b_env * E,
                          "valu": valu_view(E, avg_kernel_s, args.workload)},

@@ -457,7 +457,8 @@ def make_config(config: dict, num_envs: int, fast: bool = False, scenario: str =
     if ix:
         for name in feats:
             if name not in ("presence", "x", "y", "vx", "vy", "heading", "cos_h", "sin_h") + (("on_road",) if grid else ("cos_d", "sin_d", "long_off", "lat_off", "ang_off")):
-                raise NotImplementedError(f"feature {name!r} is out of scope for the intersection scenario's OccupancyGrid")
+                raise NotImplementedError(f"feature {name!r} is out of scope for the intersection scenario's "
+                                          f"{'OccupancyGrid' if grid else 'Kinematics'} observation")
         if cfg.get("host_traffic", False):
             flags |= C_HOST_TRAFFIC
     if merge:

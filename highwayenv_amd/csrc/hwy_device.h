@@ -120,7 +120,7 @@ struct StepParams {
   // one-wavefront kernel multiplies by them instead of running an IEEE f64 division (~30 instructions) per observed
   // feature and per reward term -- at most 1 ulp (f64) away from the quotient, far below the f32 observation's own
   // rounding and the 1e-9 reward tolerance
-  double inv_rx, inv_ry, inv_rvx, inv_rvy, inv_rs, inv_reward_span, inv_lanes;
+  double inv_rx, inv_ry, inv_rvx, inv_rvy;  // reciprocals of the observation feature ranges (f32 outputs only)
   // OccupancyGridObservation (obs_type == HWY_OBS_OCCUPANCY_GRID)
   int32_t obs_type, gW, gH, g_nwp;  // grid shape; waypoints per lane of the on-road layer
   double gmin_x, gmin_y, gstep_x, gstep_y, g_spacing;

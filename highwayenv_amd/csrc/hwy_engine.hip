@@ -126,6 +126,7 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->tune_extra_lds < 0 || c->tune_extra_lds > 65536) BAD("tune_extra_lds must be in [0,65536]");
   if (c->tune_ix_prewarm_frames < 0) BAD("tune_ix_prewarm_frames must be >= 0");
   if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
+  if (c->tune_prio_shift < -1 || c->tune_prio_shift > 30) BAD("tune_prio_shift must be in [-1,30] (a shift of the 64-bit clock)");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
   if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");
   if (c->obs_type == HWY_OBS_OCCUPANCY_GRID) {

@@ -1304,7 +1304,17 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
     const double dx = me.x - ex, dy = me.y - ey;
     const bool keep = present && ((me.flags & HWY_F_CONTROLLED) || !(sqrt(dx * dx + dy * dy) < 20));
     ix_compact(me, keep);
-    const int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
+    int slot = __popcll(__ballot(!(me.flags & HWY_F_ABSENT)));
+    if (slot >= p.N) {
+      // every slot is taken (the reference's list is unbounded, intersection_env.py:302-311): a controlled vehicle is never
+      // the one that is dropped -- it replaces the most recently spawned traffic vehicle, counted as a dropped spawn
+      // (N >= A is validated at hwy_create, so there is one)
+      const unsigned long long traffic = __ballot(!(me.flags & HWY_F_ABSENT) && !(me.flags & HWY_F_CONTROLLED));
+      const int victim = 63 - __clzll(traffic);
+      ix_compact(me, !(me.flags & HWY_F_ABSENT) && i != victim);
+      if (ip.counters && i == 0) atomicAdd(&ip.counters[HWY_CTR_IX_SPAWNS_DROPPED], 1ull);
+      slot = p.N - 1;
+    }
     const double eh = ix_heading_at(sh, access, 60.0);
     const int best = ix_closest_lane_uniform(ip, sh, ex, ey, eh);
     if (i == slot && slot < p.N) {

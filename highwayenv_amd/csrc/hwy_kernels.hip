@@ -1,6 +1,6 @@
 // hwy_kernels.hip -- gfx950 translation unit: instantiates the fused step / reset /
 // observe kernels of hwy_device.h and exposes plain launch functions to the C-ABI host
-// (hwy_engine.cpp).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
+// (hwy_engine.hip).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
 #define HWY_HAVE_SETPRIO 1  // s_setprio / s_memtime / s_getreg exist on the device (not in the CPU emulation of tests/emu)

@@ -32,9 +32,6 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.rvx0 = c.obs_range_vx[0]; p.rvx1 = c.obs_range_vx[1]; p.rvy0 = c.obs_range_vy[0]; p.rvy1 = c.obs_range_vy[1];
   p.inv_rx = 1.0 / (p.rx1 - p.rx0); p.inv_ry = 1.0 / (p.ry1 - p.ry0);
   p.inv_rvx = 1.0 / (p.rvx1 - p.rvx0); p.inv_rvy = 1.0 / (p.rvy1 - p.rvy0);
-  p.inv_rs = 1.0 / (p.rs1 - p.rs0);
-  p.inv_reward_span = 1.0 / ((p.high_speed_reward + p.right_lane_reward) - p.collision_reward);
-  p.inv_lanes = 1.0 / (double)(p.L - 1 > 1 ? p.L - 1 : 1);
   p.prio_shift = c.tune_prio_shift > 0 ? c.tune_prio_shift : 0;  // the engine turns the default on where it pays (hwy_create)
   p.obs_type = c.obs_type;
   if (c.obs_type == HWY_OBS_OCCUPANCY_GRID) {

@@ -265,14 +265,17 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
       const bool on_road = fabs(me.y - me.lane * p.lane_width) <= p.lane_width / 2 + 0.0 && -5.0 <= me.x &&
                            me.x < p.road_length + 5.0;
       const double forward_speed = me.v * me.ch;
-      const double scaled_speed = lmap_inv(forward_speed, p.rs0, p.inv_rs, 0.0, 1.0);
+      // true divisions like the reference, the oracle and the workgroup kernel (one thread per agent and step): the host-computed
+      // reciprocals are for the f32 observation features only -- a reward at its maximum must come out as exactly 1.0
+      const double scaled_speed = lmap(forward_speed, p.rs0, p.rs1, 0.0, 1.0);
+      const int nl = p.L - 1 > 1 ? p.L - 1 : 1;
       double reward = 0.0;
       reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
-      reward = reward + p.right_lane_reward * ((double)me.tgt * p.inv_lanes);
+      reward = reward + p.right_lane_reward * ((double)me.tgt / (double)nl);
       reward = reward + p.high_speed_reward * clipd(scaled_speed, 0.0, 1.0);
       reward = reward + 0.0 * (on_road ? 1.0 : 0.0);
       if (p.flags & HWY_C_NORMALIZE_REWARD)
-        reward = lmap_inv(reward, p.collision_reward, p.inv_reward_span, 0.0, 1.0);
+        reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
       reward *= (on_road ? 1.0 : 0.0);
       p.reward[(size_t)e * p.A + a] = reward;
       if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;

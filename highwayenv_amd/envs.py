@@ -39,6 +39,22 @@ class _Discrete:
         return int(np.random.randint(self.n))
 
 
+class _Tuple:
+    """gymnasium.spaces.Tuple stand-in (MultiAgentAction.space, action.py:336-340): one sub-space per agent."""
+
+    def __init__(self, spaces):
+        self.spaces = tuple(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def contains(self, x):
+        return len(x) == len(self.spaces) and all(sp.contains(v) for sp, v in zip(self.spaces, x))
+
+    def sample(self):
+        return tuple(sp.sample() for sp in self.spaces)
+
+
 class _Box:
     def __init__(self, shape, dtype=np.float32):
         self.shape, self.dtype = tuple(shape), np.dtype(dtype)
@@ -103,10 +119,20 @@ class BatchedHighwayEnv:
         self.configure(config)
         self._engine = None
         self._engine_key = None
-        self.np_random = [None] * self.num_envs  # per-env Generator == reference env.np_random
+        self._np_randoms = [None] * self.num_envs  # per-env Generator == reference env.np_random
         self.time = np.zeros(self.num_envs)
         self.steps = 0
         self._define_spaces()
+
+    @property
+    def np_random(self):
+        """Batched classes: the list of per-environment Generators (env e's == the reference env's ``np_random`` after
+        ``reset(seed=seeds[e])``).  The single-environment drop-ins return THE Generator (``_SingleEnvMixin``)."""
+        return self._np_randoms
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_randoms = list(value) if isinstance(value, (list, tuple)) else [value] * self.num_envs
 
     # ---- config (abstract.py:101-144) ------------------------------------------------------
     @classmethod
@@ -157,11 +183,11 @@ class BatchedHighwayEnv:
             if len(seeds) != E:
                 raise ValueError("one seed per env expected")
         for e, s in enumerate(seeds):
-            if s is not None or self.np_random[e] is None:
+            if s is not None or self._np_randoms[e] is None:
                 # gymnasium.utils.seeding.np_random(seed): Generator(PCG64(SeedSequence(seed)))
-                self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+                self._np_randoms[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
         if self.spawn_mode == "reference":
-            eng.set_state(self._spawn_reference(self.np_random))
+            eng.set_state(self._spawn_reference(self._np_randoms))
             obs = eng.observe()
         else:
             sd = np.array([np.random.SeedSequence(s).generate_state(1, np.uint64)[0] if s is None else s
@@ -232,10 +258,10 @@ class BatchedHighwayEnv:
         if self._hcfg.flags & _abi.C_OBS_UNSORTED:
             obs = np.array(obs, copy=True)
             for e in range(self.num_envs):
-                if self.np_random[e] is None:
-                    self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
+                if self._np_randoms[e] is None:
+                    self._np_randoms[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
                 for a in range(self._hcfg.num_agents):
-                    self.np_random[e].shuffle(obs[e, a, 1:])
+                    self._np_randoms[e].shuffle(obs[e, a, 1:])
         if self._hcfg.flags & _abi.C_GRID_IMAGE:  # OccupancyGrid(as_image=True): the engine wrote the uint8 values as f32
             obs = obs.astype(np.uint8)
         return obs[:, 0] if self._hcfg.num_agents == 1 else obs
@@ -369,7 +395,7 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
             # observation.py:727-731); the observations come stacked as ONE [A, 15, 7] array instead of a tuple of A
             self.single_action_space = one if A == 1 else _gym.spaces.Tuple([one] * A)
         else:
-            self.single_action_space = _Discrete(3)
+            self.single_action_space = _Discrete(3) if A == 1 else _Tuple([_Discrete(3)] * A)
         self.action_space = self.single_action_space
 
     def _device_spawn_args(self) -> dict:
@@ -388,10 +414,10 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
         E = self.num_envs
         seeds = [None] * E if seed is None else ([int(seed) + e for e in range(E)] if np.ndim(seed) == 0 else list(seed))
         for e, s in enumerate(seeds):
-            if s is not None or self.np_random[e] is None:
-                self.np_random[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+            if s is not None or self._np_randoms[e] is None:
+                self._np_randoms[e] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
         eng.set_autoreset(False)
-        st = _ix.reset_reference_stream(eng, self._hcfg, self.config, self.np_random)
+        st = _ix.reset_reference_stream(eng, self._hcfg, self.config, self._np_randoms)
         obs = eng.observe()
         self.time[:] = 0
         self.steps = 0
@@ -413,7 +439,7 @@ class BatchedIntersectionEnv(BatchedHighwayEnv):
         info["agents_rewards"] = agents_rewards
         info["agents_terminated"] = agents["crashed"] | agents["arrived"]
         if self.spawn_mode == "reference":  # IntersectionEnv.step: _clear_vehicles, _spawn_vehicle (:136-140)
-            _ix.clear_and_spawn_reference_stream(self._engine, self._hcfg, self.config, self.np_random)
+            _ix.clear_and_spawn_reference_stream(self._engine, self._hcfg, self.config, self._np_randoms)
         return obs, reward, term, trunc, info
 
     def rewards(self, env_index: int = 0) -> dict:
@@ -460,6 +486,17 @@ class _SingleEnvMixin:
     def __init__(self, config: dict | None = None, render_mode=None, device: int = 0):
         super().__init__(config, num_envs=1, device=device, render_mode=render_mode)
         self.reset()  # AbstractEnv.__init__ resets (abstract.py:89)
+
+    @property
+    def np_random(self):
+        """gymnasium.Env.np_random: ONE Generator (wrappers and check_env call .integers / .bit_generator on it)."""
+        if self._np_randoms[0] is None:
+            self._np_randoms[0] = np.random.Generator(np.random.PCG64(np.random.SeedSequence(None)))
+        return self._np_randoms[0]
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_randoms = [value]
 
     def reset(self, *, seed=None, options=None):
         obs, info = super().reset(seed=seed, options=options)

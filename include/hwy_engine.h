@@ -172,8 +172,13 @@ typedef struct hwy_lane {
 enum { HWY_LANE_LEFT = 0, HWY_IDLE = 1, HWY_LANE_RIGHT = 2, HWY_FASTER = 3, HWY_SLOWER = 4 };
 /* hwy_config.action_set: ACTIONS_ALL / ACTIONS_LONGI / ACTIONS_LAT (action.py:204-210) */
 enum { HWY_ACTIONS_ALL = 0, HWY_ACTIONS_LONGI = 1, HWY_ACTIONS_LAT = 2 };
-/* id in the configured table -> id in ACTIONS_ALL (what the kernels and the oracle act on) */
-#define HWY_ACTION_TO_ALL(set, a) ((set) == HWY_ACTIONS_LONGI ? ((a) == 0 ? HWY_SLOWER : ((a) == 2 ? HWY_FASTER : HWY_IDLE)) : (a))
+/* id in the configured table -> id in ACTIONS_ALL (what the kernels and the oracle act on).  An id outside the table maps
+ * to HWY_IDLE in all three tables: hwy_step (host pointers) rejects such ids with HWY_ERR_ACTION before any launch -- the
+ * reference's KeyError (action.py:260) -- but hwy_step_device cannot look at device memory without a synchronisation, so an
+ * on-GPU policy that emits an out-of-table id gets IDLE, never another table's action. */
+#define HWY_ACTION_TO_ALL(set, a)                                                                          \
+  ((set) == HWY_ACTIONS_LONGI ? ((a) == 0 ? HWY_SLOWER : ((a) == 2 ? HWY_FASTER : HWY_IDLE))                \
+                              : ((unsigned)(a) <= ((set) == HWY_ACTIONS_LAT ? 2u : 4u) ? (a) : HWY_IDLE))
 #define HWY_NUM_ACTIONS(set) ((set) == HWY_ACTIONS_ALL ? 5 : 3)
 
 /*
@@ -346,7 +351,9 @@ int hwy_reset(hwy_engine *eng, const uint8_t *mask, const uint64_t *seeds, doubl
  * hwy_step takes HOST pointers (H2D actions, kernels, D2H results, synchronises).
  * hwy_step_device takes DEVICE pointers, only enqueues on the engine's stream
  * and does not synchronise -- the path for on-GPU policies, RCCL gathers and
- * the benchmark's HBM-resident timing.
+ * the benchmark's HBM-resident timing.  It does NOT validate the action ids
+ * (hwy_step does: HWY_ERR_ACTION): an id outside the configured table acts as
+ * IDLE (HWY_ACTION_TO_ALL), where the reference raises KeyError.
  */
 int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward,
              uint8_t *terminated, uint8_t *truncated, double *info_speed, uint8_t *info_crashed);

@@ -259,3 +259,30 @@ def test_spawn_counters_report_what_the_slot_cap_drops():
         eng.close()
     print(f"\nintersection-v0 spawn drop rate by slot capacity: " + ", ".join(f"{k} slots: {100 * v:.3f} %" for k, v in rates.items()))
     assert rates[6] > 0.05 and rates[48] == 0.0 and rates[30] <= rates[6]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("agents,slots", [(1, 4), (3, 5), (4, 4)])
+def test_a_controlled_vehicle_is_never_the_dropped_spawn(backend, agents, slots):
+    """With fewer slots than the initial traffic fills, the device reset must still create EVERY controlled vehicle (it
+    replaces the most recent traffic vehicle; the reference's list is unbounded, intersection_env.py:302-311) -- otherwise
+    the agent's observation / reward rows would be unwritten and an episode without an ego would never terminate."""
+    E = 6 if backend == "emu" else 64
+    over = {"max_vehicles": slots, "initial_vehicle_count": 12, "controlled_vehicles": agents, "spawn_probability": 1.0}
+    if agents > 1:
+        d = hix.intersection_default_config()
+        over.update({"action": {"type": "MultiAgentAction", "action_config": d["action"]},
+                     "observation": {"type": "MultiAgentObservation", "observation_config": d["observation"]}})
+    cfg_d, cfg = _config(E, **over)
+    eng = make_engine(backend, cfg)
+    eng.reset(base_seed=17)
+    eng.set_autoreset(True, base_seed=18)
+    for t in range(4):
+        st = eng.get_state()
+        pres = (st["flags"] & _abi.F_ABSENT) == 0
+        ctrl = pres & ((st["flags"] & _abi.F_CONTROLLED) != 0)
+        assert ctrl.sum(1).tolist() == [agents] * E, f"step {t}: controlled vehicles per env"
+        assert (pres.sum(1) <= slots).all() and (pres == (np.arange(slots)[None, :] < pres.sum(1)[:, None])).all()
+        obs, reward, term, trunc, info = eng.step(np.ones((E, agents), np.int32))
+        assert np.isfinite(obs).all() and np.isfinite(reward).all()
+    eng.close()
