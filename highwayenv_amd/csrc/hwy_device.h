@@ -120,9 +120,11 @@ struct StepParams {
   // one-wavefront kernel multiplies by them instead of running an IEEE f64 division (~30 instructions) per observed
   // feature and per reward term -- at most 1 ulp (f64) away from the quotient, far below the f32 observation's own
   // rounding and the 1e-9 reward tolerance
+  double inv_lane_width;
   double inv_rx, inv_ry, inv_rvx, inv_rvy;  // reciprocals of the observation feature ranges (f32 outputs only)
   // OccupancyGridObservation (obs_type == HWY_OBS_OCCUPANCY_GRID)
   int32_t obs_type, gW, gH, g_nwp;  // grid shape; waypoints per lane of the on-road layer
+  int32_t obs_std5;  // Kinematics with features == [presence, x, y, vx, vy] (the default): observe_wave's straight-line path
   double gmin_x, gmin_y, gstep_x, gstep_y, g_spacing;
   int32_t *grid_ws;  // [E][A][2][W*H] cell owner (lowest vehicle index) / on-road flag
   DevState st;
@@ -143,12 +145,14 @@ struct StepParams {
 };
 
 // ---- utils.py ---------------------------------------------------------------------------
-// utils.py:50-56
+// utils.py:50-56: x if |x| > eps else (eps if x >= 0 else -eps).  For every x but NaN that is max(|x|, eps) carrying the sign
+// of (x < 0) -- -0.0 counts as >= 0, like in the reference: a max, a compare and a sign flip instead of two compares and two
+// 64-bit selects.
 __device__ inline double not_zero(double x) {
-  const double eps = 1e-2;
-  if (fabs(x) > eps) return x;
-  return x >= 0 ? eps : -eps;
+  const double t = fmax(fabs(x), 1e-2);
+  return x < 0 ? -t : t;
 }
+__device__ inline double abs_not_zero(double x) { return fmax(fabs(x), 1e-2); }  // == fabs(not_zero(x))
 // utils.py:59-60: ((x + pi) % (2 pi)) - pi with Python's floor-mod (hwy_math.h: py_mod_pos)
 __device__ inline double wrap_to_pi(double x) { return py_mod_pos(x + HWY_PI, 2 * HWY_PI) - HWY_PI; }
 __device__ inline double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
@@ -381,7 +385,7 @@ struct EnvBlock {
   // MOBIL caller evaluating its would-be follower needs one exp, not a second pow.
   __device__ static inline double idm_log_ratio(const StepParams &p, double v, double ts) {
     const double v0 = clipd(ts, 0.0, p.speed_limit);
-    const double r = fmax(v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+    const double r = fmax(v, 0.0) * fast_rcp(abs_not_zero(v0));
     return r > 0.0 ? log_pos(r) : -__builtin_inf();  // r == 0 -> exp(-inf) = 0 == pow(0, delta)
   }
   __device__ static inline double idm_free_from_log(double log_ratio, double delta) {
@@ -437,7 +441,9 @@ struct EnvBlock {
     // nearest in y: k0 = round(y / width), clamped.  Unless y sits within 1e-9 of a lane boundary (where
     // the reference's rounded sums decide, ties -> lowest id) that is provably the argmin; otherwise run
     // the literal loop.
-    const double k0 = rint(y / p.lane_width);
+    // (y * (1 / width) instead of the division: the two quotients differ by an ulp at most, which can move rint() only when y
+    // is within ~1e-15 of a lane boundary -- and then `off` fails the test below and the literal loop decides)
+    const double k0 = rint(y * p.inv_lane_width);
     const double off = fabs(y - k0 * p.lane_width);
     if (off < p.lane_width / 2 - 1e-9) {
       const int k = (int)k0;

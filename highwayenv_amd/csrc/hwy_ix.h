@@ -640,7 +640,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         // IDM (behavior.py:150-217) on the current lane, and on the target lane while they differ;
         // (v / v0) ** delta == exp(delta * log(v / v0)) with the bounded-domain routines of hwy_math.h
         const double v0 = clipd(me.ts, 0.0, sh.lim[me.lane]);
-        const double ratio = fmax(me.v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+        const double ratio = fmax(me.v, 0.0) * fast_rcp(abs_not_zero(v0));
         const double powr = ratio > 0.0 ? exp_bounded(fmin(me.delta * log_pos(ratio), 40.0)) : 0.0;
         const double free_acc = ip.a_max * (1 - powr);
         const double inv_ab2 = fast_rcp(2 * sqrt(-ip.a_max * ip.b_min));

@@ -136,7 +136,7 @@ __device__ inline double net_gap_term(double d, double ve, double ce, double se,
 }
 __device__ inline double net_log_ratio(double v, double ts, double limit) {
   const double v0 = clipd(ts, 0.0, limit);
-  const double r = fmax(v, 0.0) * fast_rcp(fabs(not_zero(v0)));
+  const double r = fmax(v, 0.0) * fast_rcp(abs_not_zero(v0));
   return r > 0.0 ? log_pos(r) : -__builtin_inf();
 }
 // steering_control (controller.py:145-187) folded with the slip / bicycle chain like EnvBlock::steer_tan_beta,

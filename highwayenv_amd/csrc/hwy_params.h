@@ -30,10 +30,13 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.perception = c.perception_distance;
   p.rx0 = c.obs_range_x[0]; p.rx1 = c.obs_range_x[1]; p.ry0 = c.obs_range_y[0]; p.ry1 = c.obs_range_y[1];
   p.rvx0 = c.obs_range_vx[0]; p.rvx1 = c.obs_range_vx[1]; p.rvy0 = c.obs_range_vy[0]; p.rvy1 = c.obs_range_vy[1];
+  p.inv_lane_width = 1.0 / p.lane_width;
   p.inv_rx = 1.0 / (p.rx1 - p.rx0); p.inv_ry = 1.0 / (p.ry1 - p.ry0);
   p.inv_rvx = 1.0 / (p.rvx1 - p.rvx0); p.inv_rvy = 1.0 / (p.rvy1 - p.rvy0);
   p.prio_shift = c.tune_prio_shift > 0 ? c.tune_prio_shift : 0;  // the engine turns the default on where it pays (hwy_create)
   p.obs_type = c.obs_type;
+  p.obs_std5 = c.obs_type == HWY_OBS_KINEMATICS && c.obs_features == 5;
+  for (int f = 0; f < 5; ++f) p.obs_std5 = p.obs_std5 && c.obs_feature_ids[f] == f;  // presence, x, y, vx, vy
   if (c.obs_type == HWY_OBS_OCCUPANCY_GRID) {
     p.gW = c.grid_shape[0]; p.gH = c.grid_shape[1];
     p.gmin_x = c.grid_min[0]; p.gmin_y = c.grid_min[1]; p.gstep_x = c.grid_step[0]; p.gstep_y = c.grid_step[1];

@@ -237,7 +237,24 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
     if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
       float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
-      if (active && row >= 0) {
+      if (p.obs_std5) {  // wave-uniform
+        // features == [presence, x, y, vx, vy] (KinematicObservation's default): the same arithmetic as the generic loop
+        // below (Vehicle.to_dict, origin subtraction, lmap with the host-computed reciprocal, clip), written out per feature
+        // instead of five trips through the feature switch
+        if (active && row >= 0) {
+          double fx = me.x, fy = me.y, fvx = me.v * me.ch, fvy = me.v * me.sh;
+          if (row > 0 && !(p.flags & HWY_C_OBS_ABSOLUTE)) { fx -= ex; fy -= ey; fvx -= ev * ec; fvy -= ev * es; }
+          if (p.flags & HWY_C_OBS_NORMALIZE) {
+            const bool clip = (p.flags & HWY_C_OBS_CLIP) != 0;
+            if (p.rx0 > -__builtin_inf()) { fx = lmap_inv(fx, p.rx0, p.inv_rx, -1.0, 1.0); fx = clip ? clipd(fx, -1.0, 1.0) : fx; }
+            if (p.ry0 > -__builtin_inf()) { fy = lmap_inv(fy, p.ry0, p.inv_ry, -1.0, 1.0); fy = clip ? clipd(fy, -1.0, 1.0) : fy; }
+            if (p.rvx0 > -__builtin_inf()) { fvx = lmap_inv(fvx, p.rvx0, p.inv_rvx, -1.0, 1.0); fvx = clip ? clipd(fvx, -1.0, 1.0) : fvx; }
+            if (p.rvy0 > -__builtin_inf()) { fvy = lmap_inv(fvy, p.rvy0, p.inv_rvy, -1.0, 1.0); fvy = clip ? clipd(fvy, -1.0, 1.0) : fvy; }
+          }
+          float *o5 = out + row * 5;
+          o5[0] = 1.0f; o5[1] = (float)fx; o5[2] = (float)fy; o5[3] = (float)fvx; o5[4] = (float)fvy;
+        }
+      } else if (active && row >= 0) {
         for (int f = 0; f < F; ++f) {
           const int fid = p.feat[f];
           double val = B::feature(p, fid, me.x, me.y, me.h, me.v, me.ch, me.sh, me.lane);
@@ -466,12 +483,23 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     {
       bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
       while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
-        if (pend_l || pend_r) {
-          const bool left = pend_l;
-          const int rf = left ? rl : rrt;
-          const double a_f = B::idm_free_from_log(sh.lr[rf], delta) -
-                             B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
-          const bool safe = !(a_f < -HWY_LC_MAX_BRAKING);
+        const bool pend = pend_l || pend_r;
+        const bool left = pend_l;
+        const int rf = pend ? (left ? rl : rrt) : 0;
+        const double lr_f = sh.lr[rf];
+        const double g = B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
+        // a_f = 3 (1 - E) - g with E = exp(delta * lr_f) >= 0, so a_f <= 3 - g: g beyond 5 is unsafe whatever E is; and a
+        // follower below its target speed (lr_f < 0, delta > 0) has E <= 1 (+ an ulp), so a_f >= -g: g below 2 is safe
+        // whatever E is.  Both with a 1e-6 margin, far above any rounding of the three operations involved -- the verdicts
+        // are the ones the full expression gives.  The exp runs only if some pending lane falls between the two.
+        const bool sure_unsafe = g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
+        const bool sure_safe = lr_f < 0.0 && delta > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6;
+        bool safe = sure_safe;
+        if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
+          const double a_f = B::idm_free_from_log(lr_f, delta) - g;
+          safe = !(a_f < -HWY_LC_MAX_BRAKING);
+        }
+        if (pend) {
           if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
         }
       }
@@ -482,6 +510,9 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
     {
       u64 cm = __ballot(changer);
+      // A rival is ANOTHER vehicle on its way to another lane (with the target it had at the start of the frame or the one it
+      // has now): most frames hold a single such vehicle -- the changer itself -- and then no link can block
+      if (cm && __popcll(__ballot(active && (me.lane != tgt_old || me.lane != me.tgt))) <= 1) cm = 0;
       while (cm) {  // wave-uniform
         const int ci = ctz64(cm);
         cm &= cm - 1;

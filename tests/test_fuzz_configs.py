@@ -13,7 +13,7 @@ from tests.test_edge_cases import rollout
 pytestmark = pytest.mark.gpu
 
 # whole-step coverage of the intersection fuzz (printed per chunk): the rest are env-steps in which some car is below 1 m/s
-INTERSECTION_WHOLE_STEP_FLOOR = 0.15
+INTERSECTION_WHOLE_STEP_FLOOR = 0.40
 
 
 def random_config(rng):

@@ -219,7 +219,7 @@ VARIANTS = {
                   (W, sub("              r = pair_collide(A, Bb, p.dt, &tx, &ty);", "              atomicAdd(&sh.cnt[0], 1); r = pair_collide(A, Bb, p.dt, &tx, &ty);")),
                   (W, sub("            if (!surely_apart(A, Bb, p.dt)) {", "            atomicAdd(&sh.cnt[1], 1);\n            if (!surely_apart(A, Bb, p.dt)) {")),
                   (W, sub("        if (__ballot(rival) == 0) continue;", "        if (i == 0) atomicAdd(&sh.cnt[2], 1);\n        if (__ballot(rival) == 0) continue;\n        if (i == 0) atomicAdd(&sh.cnt[3], 1);")),
-                  (W, sub("        if (pend_l || pend_r) {", "        if (i == 0) atomicAdd(&sh.cnt[4], 1);\n        if (pend_l || pend_r) {")),
+                  (W, sub("        const bool pend = pend_l || pend_r;", "        if (i == 0) atomicAdd(&sh.cnt[4], 1);\n        const bool pend = pend_l || pend_r;")),
                   (W, sub("o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u;",
                           "o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u; for (int k = 0; k < 5; ++k) o[5 + k] = (unsigned)sh.cnt[k];")),
                   (W, sub("      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n    return;",
