@@ -323,6 +323,9 @@ def main() -> None:
                          "per env); merge = merge-v0 defaults; intersection = BASELINE config 4's world model "
                          "(intersection-v0, 30 vehicle slots, OccupancyGrid 4 x 11 x 11 obs; use --envs-per-gpu 2048); intersection_kin = "
                          "the same with intersection-v0's default Kinematics 15 x 7 observation")
+    ap.add_argument("--rollout-k", type=int, default=16,
+                    help="also time hwy_rollout_device with this many policy steps per launch (reported as rollout_k<K> next to the "
+                         "headline; 0 / 1 = skip)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds, prio_shift, "
                          "ix_prewarm_frames: highwayenv_amd._abi.TUNING_KEYS); selects a kernel variant, never changes a result; repeatable")
@@ -486,6 +489,40 @@ def main() -> None:
         per_step_gather = {"steps": n1, "ms_per_step": el1.item() / n1 * 1e3, "value": n1 * E * world / el1.item(),
                            "unit": "env-steps/s", "gather": "one RCCL gather per step"}
 
+    # K policy steps per launch with pre-staged actions (hwy_rollout_device: open-loop rollouts / action repeat): reported NEXT TO
+    # the headline, never instead of it -- `value` stays one launch per step
+    rollout = None
+    if world == 1 and args.rollout_k > 1:
+        Kr = args.rollout_k
+        n_calls = max(1, args.steps // Kr)
+        r_obs = torch.empty((Kr, E, A, *_abi.obs_shape(cfg)), dtype=torch.float32, device=dev)
+        r_rew = torch.empty((Kr, E, A), dtype=torch.float64, device=dev)
+        r_term = torch.empty((Kr, E), dtype=torch.uint8, device=dev)
+        r_trunc = torch.empty((Kr, E), dtype=torch.uint8, device=dev)
+        r_speed = torch.empty((Kr, E, A), dtype=torch.float64, device=dev)
+        r_crashed = torch.empty((Kr, E, A), dtype=torch.uint8, device=dev)
+
+        def roll(c):
+            t0_ = args.warmup + (c * Kr) % (R * args.steps - Kr)
+            eng.rollout_device(Kr, actions[t0_].data_ptr(), r_obs.data_ptr(), r_rew.data_ptr(), r_term.data_ptr(),
+                               r_trunc.data_ptr(), r_speed.data_ptr(), r_crashed.data_ptr())
+        for c in range(2):
+            roll(c)
+        torch.cuda.synchronize(dev)
+        reg = []
+        for r in range(R):
+            t0 = time.perf_counter()
+            for c in range(n_calls):
+                roll(r * n_calls + c)
+            torch.cuda.synchronize(dev)
+            reg.append(time.perf_counter() - t0)
+        el = float(np.median(reg))
+        rollout = {"k_steps_per_launch": Kr, "launches_per_region": n_calls, "ms_per_step": el / (n_calls * Kr) * 1e3,
+                   "value": n_calls * Kr * E / el, "unit": "env-steps/s",
+                   "ms_per_step_repeats": [x / (n_calls * Kr) * 1e3 for x in reg],
+                   "what": "hwy_rollout_device: K policy steps per launch with pre-staged actions, every step's outputs written; "
+                           "bit-identical to K one-step launches (tests/test_rollout.py)"}
+
     # PCIe-inclusive rate of the host-pointer entry point (hwy_step: H2D actions, kernel, D2H results, sync);
     # reported for DESIGN.md, never as `value`
     host_rate = None
@@ -549,6 +586,7 @@ def main() -> None:
                                   if use_dist else "none (single rank)"),
                        "world_size_reported_by_the_process_group": dist.get_world_size() if use_dist else 1},
             "gather_every_1": per_step_gather,
+            f"rollout_k{args.rollout_k}": rollout,
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -17,7 +17,7 @@ _lib = None
 EXPORTS = [
     "hwy_abi_version", "hwy_config_size", "hwy_device_count", "hwy_status_string", "hwy_create",
     "hwy_destroy", "hwy_last_error", "hwy_set_state", "hwy_get_state", "hwy_reset", "hwy_step",
-    "hwy_step_device", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
+    "hwy_step_device", "hwy_rollout_device", "hwy_rollout", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
     "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math", "hwy_get_counters",
     "hwy_comm_unique_id", "hwy_comm_init", "hwy_gather", "hwy_comm_destroy",
 ]
@@ -52,6 +52,8 @@ def load() -> C.CDLL:
     lib.hwy_reset.argtypes = [vp, vp, vp, f64, f64, i32, vp]
     lib.hwy_step.argtypes = [vp] + [vp] * 7
     lib.hwy_step_device.argtypes = [vp] + [vp] * 7
+    lib.hwy_rollout_device.argtypes = [vp, i32] + [vp] * 7
+    lib.hwy_rollout.argtypes = [vp, i32] + [vp] * 7
     lib.hwy_step_frames.argtypes = [vp, vp, i32]
     lib.hwy_observe.argtypes = [vp, vp]
     lib.hwy_set_autoreset.argtypes = [vp, i32, C.c_uint64, f64, f64, i32]
@@ -68,7 +70,7 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name.startswith(("hwy_create", "hwy_destroy", "hwy_set", "hwy_get", "hwy_reset",
-                                                      "hwy_step", "hwy_observe", "hwy_sync", "hwy_profile", "hwy_debug", "hwy_comm", "hwy_gather")):
+                                                      "hwy_step", "hwy_rollout", "hwy_observe", "hwy_sync", "hwy_profile", "hwy_debug", "hwy_comm", "hwy_gather")):
             if name not in ("hwy_status_string", "hwy_last_error", "hwy_config_size"):
                 fn.restype = C.c_int
     if lib.hwy_abi_version() != _abi.HWY_ABI_VERSION:

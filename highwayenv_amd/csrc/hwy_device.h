@@ -129,6 +129,9 @@ struct StepParams {
   int32_t *grid_ws;  // [E][A][2][W*H] cell owner (lowest vehicle index) / on-road flag
   DevState st;
   // per-call
+  int32_t k_steps;        // hwy_rollout_device on the one-wavefront kernel: policy steps per launch (outputs / actions of step k in
+                          // rows k * num_envs + e); 0 / 1 elsewhere
+  int32_t num_envs;
   int32_t n_frames;       // frames to simulate (T for a policy step)
   int32_t full_step;      // 1: advance time, observe, reward, done flags; 0: frames only
   int32_t autoreset;      // 1: envs with done[e] are re-spawned instead of stepped
@@ -580,15 +583,17 @@ __device__ inline void grid_cell(const StepParams &p, double px, double py, doub
   *cj = (int)floor((py - p.gmin_y) / p.gstep_y);
 }
 
+// eo: the row of the output planes this environment writes (== e except in a multi-step launch, hwy_rollout_device)
 template <int NW>
 __device__ inline void observe_grid(const StepParams &p, int e, int a, const Veh &me, double ex, double ey, double ev,
-                                    double ec, double es) {
+                                    double ec, double es, int eo = -1) {
+  eo = eo < 0 ? e : eo;
   typedef EnvBlock<NW> B;
   const int i = threadIdx.x, NT = NW * 64;
   const bool active = i < p.N;
   const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
   int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
-  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)F * WH;
   for (int t = i; t < WH; t += NT) {
     grid_ws_store(own + t, 0x7fffffff);
     grid_ws_store(road + t, 0);

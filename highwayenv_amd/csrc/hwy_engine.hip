@@ -29,6 +29,7 @@ struct hwy_engine {
   int pitch = 0;
   bool force_block_kernel = false;  // hwy_config.tune_block_kernel: use the generic workgroup kernel even for N <= 64
   int waves_per_eu = 3;  // register-allocation variant of the step kernel (hwy_config.tune_waves_per_eu)
+  int rollout_waves_per_eu = 3;  // ... and of the multi-step kernel (hwy_rollout_device)
   int prio_shift = 0;    // issue-priority turns of the one-wavefront kernels (hwy_config.tune_prio_shift; 0 = off)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
@@ -48,6 +49,8 @@ struct hwy_engine {
   // step outputs of the host-pointer entry points live in ONE device block (reward | speed | obs | term | trunc |
   // crashed) mirrored by one pinned host block, so that hwy_step needs a single D2H copy
   char *d_out = nullptr;
+  char *d_roll = nullptr;  // hwy_rollout (host pointers): K blocks of actions + outputs, grown on demand
+  size_t roll_bytes = 0;
   size_t out_bytes = 0, off_reward = 0, off_speed = 0, off_obs = 0, off_term = 0, off_trunc = 0, off_crashed = 0;
   float *d_obs = nullptr;
   double *d_reward = nullptr, *d_info_speed = nullptr;
@@ -288,6 +291,14 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     eng->waves_per_eu = cfg->num_envs > 3 * simds ? 4 : 3;
   }
   if (cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4) eng->waves_per_eu = cfg->tune_waves_per_eu;
+  // the multi-step kernel keeps a few more registers across the steps (129 VGPRs against 118, ego-only build): beyond 3 resident
+  // wavefronts per SIMD the 4-wave allocation (2 spilled) is the one that holds the whole grid
+  eng->rollout_waves_per_eu = eng->waves_per_eu;
+  if (cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !(cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4)) {
+    hipDeviceProp_t prop;
+    const int simds = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * 4;
+    if (cfg->num_envs > 3 * simds) eng->rollout_waves_per_eu = 4;
+  }
   auto bail = [&](hipError_t e, const char *what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
     hwy_destroy(eng);
@@ -390,7 +401,7 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
   if (eng->comm) { hwy::comm_destroy(eng->comm); eng->comm = nullptr; }
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out,
+  void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out, eng->d_roll,
                   eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet,
                   eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta, eng->d_counters};
   for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -595,6 +606,79 @@ extern "C" int hwy_step_device(hwy_engine *eng, const int32_t *d_actions, float 
   if (eng->profiling && eng->events_used >= 65536)
     if (int rc = drain_events(eng)) return rc;
   return timed_launch(eng, p);
+}
+
+extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_t *d_actions, float *d_obs, double *d_reward,
+                                  uint8_t *d_terminated, uint8_t *d_truncated, double *d_info_speed, uint8_t *d_info_crashed) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (k_steps < 1) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: k_steps must be >= 1");
+  if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: actions/obs/reward/terminated/truncated must be non-NULL");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  const size_t E = eng->cfg.num_envs;
+  StepParams p;
+  fill_params(eng, p);
+  p.n_frames = eng->cfg.frames_per_step;
+  p.full_step = 1;
+  p.actions = d_actions; p.obs = d_obs; p.reward = d_reward; p.terminated = d_terminated; p.truncated = d_truncated;
+  p.info_speed = d_info_speed; p.info_crashed = d_info_crashed;
+  if (!is_ix(eng) && !is_net(eng) && hwy::has_rollout_kernel(p, eng->force_block_kernel)) {
+    p.k_steps = k_steps;
+    p.num_envs = eng->cfg.num_envs;
+    HWY_HIP(eng, hwy::launch_rollout(p, eng->cfg.num_envs, eng->stream, eng->rollout_waves_per_eu, eng->cfg.tune_extra_lds));
+    return HWY_OK;
+  }
+  // the workgroup kernel (N > 64) and the road-network kernels: k launches back to back on the engine's stream, block k of every plane
+  for (int32_t k = 0; k < k_steps; ++k) {
+    p.actions = d_actions + (size_t)k * n_act; p.obs = d_obs + (size_t)k * n_obs; p.reward = d_reward + (size_t)k * n_ea;
+    p.terminated = d_terminated + (size_t)k * E; p.truncated = d_truncated + (size_t)k * E;
+    p.info_speed = d_info_speed ? d_info_speed + (size_t)k * n_ea : nullptr;
+    p.info_crashed = d_info_crashed ? d_info_crashed + (size_t)k * n_ea : nullptr;
+    HWY_HIP(eng, launch_step_any(eng, p));
+  }
+  return HWY_OK;
+}
+
+extern "C" int hwy_rollout(hwy_engine *eng, int32_t k_steps, const int32_t *actions, float *obs, double *reward,
+                           uint8_t *terminated, uint8_t *truncated, double *info_speed, uint8_t *info_crashed) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (k_steps < 1) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout: k_steps must be >= 1");
+  if (!actions || !obs || !reward || !terminated || !truncated)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout: actions/obs/reward/terminated/truncated must be non-NULL");
+  size_t n_act, n_obs, n_ea;
+  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
+  const size_t E = eng->cfg.num_envs, K = (size_t)k_steps;
+  const int max_action = is_ix(eng) ? 2 : HWY_NUM_ACTIONS(eng->cfg.action_set) - 1;
+  for (size_t k = 0; k < K * n_act; ++k)  // the reference's KeyError, before anything is simulated (action.py:260)
+    if (actions[k] < 0 || actions[k] > max_action) return fail(eng, HWY_ERR_ACTION, "meta-action out of range");
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_act = 0, o_rew = up(K * n_act * 4), o_spd = o_rew + up(K * n_ea * 8), o_obs = o_spd + up(K * n_ea * 8),
+               o_term = o_obs + up(K * n_obs * 4), o_trunc = o_term + up(K * E), o_crash = o_trunc + up(K * E),
+               total = o_crash + up(K * n_ea);
+  if (total > eng->roll_bytes) {
+    HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+    if (eng->d_roll) (void)hipFree(eng->d_roll);
+    eng->d_roll = nullptr;
+    eng->roll_bytes = 0;
+    HWY_HIP(eng, hipMalloc((void **)&eng->d_roll, total));
+    eng->roll_bytes = total;
+  }
+  char *d = eng->d_roll;
+  HWY_HIP(eng, hipMemcpyAsync(d + o_act, actions, K * n_act * 4, hipMemcpyHostToDevice, eng->stream));
+  if (int rc = hwy_rollout_device(eng, k_steps, (const int32_t *)(d + o_act), (float *)(d + o_obs), (double *)(d + o_rew),
+                                  (uint8_t *)(d + o_term), (uint8_t *)(d + o_trunc), (double *)(d + o_spd), (uint8_t *)(d + o_crash)))
+    return rc;
+  HWY_HIP(eng, hipMemcpyAsync(obs, d + o_obs, K * n_obs * 4, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(reward, d + o_rew, K * n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(terminated, d + o_term, K * E, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipMemcpyAsync(truncated, d + o_trunc, K * E, hipMemcpyDeviceToHost, eng->stream));
+  if (info_speed) HWY_HIP(eng, hipMemcpyAsync(info_speed, d + o_spd, K * n_ea * 8, hipMemcpyDeviceToHost, eng->stream));
+  if (info_crashed) HWY_HIP(eng, hipMemcpyAsync(info_crashed, d + o_crash, K * n_ea, hipMemcpyDeviceToHost, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  return HWY_OK;
 }
 
 extern "C" int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward, uint8_t *terminated,

@@ -45,6 +45,25 @@ static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t
     hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
+template <int WPE>
+static hipError_t launch_rollout_wpe(const StepParams &p, int num_envs, hipStream_t stream, int lds) {
+  if (p.flags & HWY_C_EGO_ONLY_COLLISIONS)
+    hipLaunchKernelGGL((hwy_rollout_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
+  else
+    hipLaunchKernelGGL((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
+  return hipGetLastError();
+}
+// hwy_rollout_device on the one-wavefront kernel: p.k_steps policy steps in one launch.  False = this engine's step kernel has
+// no multi-step form (N > 64, road networks): the caller launches step by step.
+bool has_rollout_kernel(const StepParams &p, bool force_block_kernel) { return p.N <= 64 && !force_block_kernel; }
+hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds) {
+  switch (waves_per_eu) {
+    case 1: return launch_rollout_wpe<1>(p, num_envs, stream, extra_lds);
+    case 2: return launch_rollout_wpe<2>(p, num_envs, stream, extra_lds);
+    case 3: return launch_rollout_wpe<3>(p, num_envs, stream, extra_lds);
+    default: return launch_rollout_wpe<4>(p, num_envs, stream, extra_lds);
+  }
+}
 // N <= 64: one wavefront per environment (hwy_wave.h); otherwise ceil(N/64) wavefronts per workgroup.
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds) {

@@ -188,8 +188,10 @@ __device__ inline void wave_update_rank(double x, bool active, int N, int &rank,
 
 // KinematicObservation + reward + done for every agent, all cross-lane reads through readlane.
 // BY_RANK: `rank` is the exact rank along the road of every vehicle (wave_update_rank on the CURRENT positions).
+// eo: the row of the output planes (obs, reward, flags, info) this environment writes -- e, or k * num_envs + e for step k of a
+// multi-step launch (hwy_rollout_device).
 template <bool BY_RANK>
-__device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, bool write_reward, int rank = 0) {
+__device__ inline void observe_wave(const StepParams &p, int e, int eo, const Veh &me, bool write_reward, int rank = 0) {
   typedef EnvBlock<1> B;
   const int i = threadIdx.x;
   const bool active = i < p.N;
@@ -233,9 +235,9 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
         pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
       }
     }
-    if (p.obs && p.obs_type != HWY_OBS_KINEMATICS) observe_grid<1>(p, e, a, me, ex, ey, ev, ec, es);
+    if (p.obs && p.obs_type != HWY_OBS_KINEMATICS) observe_grid<1>(p, e, a, me, ex, ey, ev, ec, es, eo);
     if (p.obs && p.obs_type == HWY_OBS_KINEMATICS) {
-      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (p.obs_std5) {  // wave-uniform
         // features == [presence, x, y, vx, vy] (KinematicObservation's default): the same arithmetic as the generic loop
@@ -294,16 +296,16 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
       if (p.flags & HWY_C_NORMALIZE_REWARD)
         reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
       reward *= (on_road ? 1.0 : 0.0);
-      p.reward[(size_t)e * p.A + a] = reward;
-      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
-      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      p.reward[(size_t)eo * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)eo * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = crashed ? 1 : 0;
       if (a == 0) {
         const bool term = crashed || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
         const double t = p.st.time[e] + p.policy_dt;
         const bool trunc = t >= p.duration;
         p.st.time[e] = t;
-        p.terminated[e] = term ? 1 : 0;
-        p.truncated[e] = trunc ? 1 : 0;
+        p.terminated[eo] = term ? 1 : 0;
+        p.truncated[eo] = trunc ? 1 : 0;
         if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
       }
     }
@@ -314,11 +316,11 @@ __device__ inline void observe_wave(const StepParams &p, int e, const Veh &me, b
 // FULL_SCAN = false builds the kernel without the full-pairwise window scan (every checker is handled by
 // the checker loop, which is correct for any set of checkers but O(#checkers)); the engine launches it for
 // highway-fast-v0 style configs (HWY_C_EGO_ONLY_COLLISIONS), where it keeps the frame loop at 173 VGPRs.
-template <int WPE, bool FULL_SCAN>
-__global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams p) {
+// One policy step of environment e by its wavefront; eo = row of the action / output planes (see observe_wave).
+template <bool FULL_SCAN>
+__device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared &sh, const int e, const int eo) {
   typedef EnvBlock<1> B;
-  __shared__ WaveShared sh;
-  const int e = blockIdx.x, i = threadIdx.x;
+  const int i = threadIdx.x;
   const int N = p.N;
   const bool active = i < N;
 
@@ -327,22 +329,22 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
     Veh me = Veh{};
     const uint32_t episode = p.st.episode[e] + 1u;
     spawn_env<1>(p, sh.x, sh.v, e, p.rp.base_seed + (uint64_t)e, episode, me);
-    observe_wave<false>(p, e, me, false);
+    observe_wave<false>(p, e, eo, me, false);
     store_vehicle<1>(p, e, me);
     if (active && (me.flags & HWY_F_CONTROLLED)) {
       for (int a = 0; a < p.A; ++a)
         if (p.agent_index[a] == i) {
-          p.reward[(size_t)e * p.A + a] = 0.0;
-          if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
-          if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = 0;
+          p.reward[(size_t)eo * p.A + a] = 0.0;
+          if (p.info_speed) p.info_speed[(size_t)eo * p.A + a] = me.v;
+          if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = 0;
         }
     }
     if (i == 0) {
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
       p.st.episode[e] = episode;
-      p.terminated[e] = 0;
-      p.truncated[e] = 0;
+      p.terminated[eo] = 0;
+      p.truncated[eo] = 0;
     }
     return;
   }
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   WaveTurn turn;
   wave_turn_init(turn, p.prio_shift);
   // the meta-actions are requested BEFORE the state (lane a fetches agent a's): one HBM round trip instead of two
-  const int act_lane = (p.actions && i < p.A) ? p.actions[(size_t)e * p.A + i] : HWY_IDLE;
+  const int act_lane = (p.actions && i < p.A) ? p.actions[(size_t)eo * p.A + i] : HWY_IDLE;
   Veh me;
   load_vehicle<1>(p, e, me);
   const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
@@ -712,11 +714,37 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   HWY_RELOAD_PARAMS(q, p);
   if (q.full_step) {
     wave_update_rank(me.x, active, N, rank, has_tie);  // positions moved in the last frame
-    observe_wave<true>(q, e, me, true, rank);
+    observe_wave<true>(q, e, eo, me, true, rank);
   }
   me.rank = rank;
   me.timer = sh.timer[i]; me.ts = sh.ts[i]; me.delta = sh.delta[i]; me.impx = sh.impx[i]; me.impy = sh.impy[i];
   store_vehicle<1>(q, e, me, false);
+}
+
+template <int WPE, bool FULL_SCAN>
+__global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams p) {
+  __shared__ WaveShared sh;
+  wave_policy_step<FULL_SCAN>(p, sh, blockIdx.x, blockIdx.x);
+}
+
+// hwy_rollout_device: p.k_steps consecutive policy steps of every environment in ONE launch (actions of step k in row
+// k * num_envs + e of the action plane, outputs likewise).  Each step is the code of the one-step kernel, state through the
+// same HBM planes (a wavefront re-reads what it has just written), auto-reset in between like in consecutive launches: the results
+// are those of k_steps launches, bit for bit.  What the launch saves is everything a launch pays once: the dispatch, the
+// wait for the slowest of 1024 SIMDs at the end of EVERY step (the expensive paths hit different SIMDs in different steps, so
+// over k steps the loads even out) and the empty issue slots while the first loads and the last stores are in flight.
+template <int WPE, bool FULL_SCAN>
+__global__ void __launch_bounds__(64, WPE) hwy_rollout_wave_kernel(const StepParams p) {
+  __shared__ WaveShared sh;
+  const int e = blockIdx.x;
+  for (int k = 0; k < p.k_steps; ++k) {  // wave-uniform
+    // a fresh, opaque view of the kernel arguments per step: nothing of a step's parameter set (or what was derived from it)
+    // stays live -- in SGPRs spilled to VGPR lanes -- across the steps
+    HWY_RELOAD_PARAMS(pk, p);
+    wave_policy_step<FULL_SCAN>(pk, sh, e, k * pk.num_envs + e);
+    HWY_WAVE_LDS_FENCE();
+    __threadfence_block();  // the next step's loads follow this step's stores (same wavefront, same addresses)
+  }
 }
 
 // Reset / observe kernels for N <= 64 reuse the generic ones (not on the per-step path).

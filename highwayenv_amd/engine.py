@@ -107,6 +107,30 @@ class Engine:
         self._check(self._lib.hwy_step_device(self._h, vp(d_actions), vp(d_obs), vp(d_reward), vp(d_terminated),
                                               vp(d_truncated), vp(d_info_speed or None), vp(d_info_crashed or None)))
 
+    def rollout_device(self, k_steps: int, d_actions: int, d_obs: int, d_reward: int, d_terminated: int, d_truncated: int,
+                       d_info_speed: int = 0, d_info_crashed: int = 0):
+        """Enqueue ``k_steps`` consecutive policy steps with pre-staged actions (hwy_rollout_device: block k of every plane
+        belongs to step k; ONE launch on the one-wavefront kernel); does not synchronise.  Same results as ``k_steps`` calls
+        of ``step_device``, bit for bit."""
+        vp = C.c_void_p
+        self._check(self._lib.hwy_rollout_device(self._h, int(k_steps), vp(d_actions), vp(d_obs), vp(d_reward),
+                                                 vp(d_terminated), vp(d_truncated), vp(d_info_speed or None),
+                                                 vp(d_info_crashed or None)))
+
+    def rollout(self, actions):
+        """hwy_rollout (host arrays): actions [K, E, A] -> (obs [K, E, A, ...], reward [K, E, A], terminated [K, E],
+        truncated [K, E], info).  Raises KeyError for an action id outside the table, like ``step``."""
+        acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(-1, self.E, self.A))
+        K, E, A = acts.shape[0], self.E, self.A
+        obs = np.empty((K, E, A, *_abi.obs_shape(self.cfg)), np.float32)
+        reward = np.empty((K, E, A), np.float64)
+        term, trunc = np.empty((K, E), np.uint8), np.empty((K, E), np.uint8)
+        speed, crashed = np.empty((K, E, A), np.float64), np.empty((K, E, A), np.uint8)
+        self._check(self._lib.hwy_rollout(self._h, K, _ptr(acts), _ptr(obs), _ptr(reward), _ptr(term), _ptr(trunc),
+                                          _ptr(speed), _ptr(crashed)))
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": (crashed & 1).astype(bool),
+                                                                    "arrived": (crashed & 2).astype(bool)}
+
     def step_frames(self, actions, n_frames: int):
         acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(self.E, self.A))
         self._check(self._lib.hwy_step_frames(self._h, _ptr(acts), int(n_frames)))

@@ -128,6 +128,35 @@ class EmuEngine:
     def observe(self):
         return self._run(2, 0, None)[0]
 
+    def rollout(self, actions):
+        """hwy_rollout_device: actions [K, E, A] -> (obs [K, E, A, ...], reward [K, E, A], terminated [K, E], truncated [K, E],
+        info) -- ONE multi-step launch where the engine has one (the one-wavefront kernel), else K steps."""
+        acts = np.ascontiguousarray(np.asarray(actions, np.int32).reshape(-1, self.E, self.A))
+        K = acts.shape[0]
+        if not lib().emu_has_rollout_kernel(C.byref(self.cfg)):
+            outs = [self.step(acts[k]) for k in range(K)]
+            info = {key: np.stack([o[4][key] for o in outs]) for key in outs[0][4]}
+            return tuple(np.stack([o[j] for o in outs]) for j in range(4)) + (info,)
+        E, A = self.E, self.A
+        obs = np.zeros((K, E, A, *_abi.obs_shape(self.cfg)), np.float32)
+        reward = np.zeros((K, E, A))
+        term, trunc = np.zeros((K, E), np.uint8), np.zeros((K, E), np.uint8)
+        speed, crashed = np.zeros((K, E, A)), np.zeros((K, E, A), np.uint8)
+        s = _abi.state_struct(self.st)
+        ar = self.autoreset
+        lib().emu_set_rollout(C.c_int(K))
+        try:
+            rc = lib().emu_run(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
+                               C.c_int(1), C.c_int(self.cfg.frames_per_step), _p(acts, C.c_int32), _p(obs, C.c_float),
+                               _p(reward, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(speed, C.c_double),
+                               _p(crashed, C.c_uint8), C.c_int(ar[0]), C.c_uint64(ar[1]), C.c_double(ar[2]),
+                               C.c_double(ar[3]), C.c_int(ar[4]))
+        finally:
+            lib().emu_set_rollout(C.c_int(0))
+        assert rc == 0
+        return obs, reward, term.astype(bool), trunc.astype(bool), {"speed": speed, "crashed": (crashed & 1).astype(bool),
+                                                                    "arrived": (crashed & 2).astype(bool)}
+
     def debug_math(self, op, x):
         xin = np.ascontiguousarray(x, np.float64).ravel()
         out = np.empty_like(xin)

@@ -66,6 +66,7 @@ struct HostImage {
 
 enum Which { STEP, RESET, OBSERVE };
 bool g_force_block = false;
+int g_k_steps = 0;  // > 0: the next STEP dispatch of the one-wavefront kernel is a multi-step launch (hwy_rollout_device)
 const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road-network scenarios need the lane table)
 hwy_state *g_st = nullptr;          // host state of the call (intersection scenario: route / road_steps planes)
 // intersection scenario, next-episode pre-warming: shadow planes owned by the Python side (emu_set_shadow)
@@ -128,6 +129,14 @@ void dispatch(Which which, const StepParams &p, int E) {
     return;
   }
   if (which == STEP && nw == 1 && !g_force_block && !g_cfg->tune_block_kernel) {  // same dispatch rule as hwy_kernels.hip
+    if (g_k_steps > 0) {
+      StepParams pk = p;
+      pk.k_steps = g_k_steps;
+      pk.num_envs = E;
+      if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_rollout_wave_kernel<1, false>(q); }, E, 64, pk);
+      else emu::launch([](const StepParams &q) { hwy::hwy_rollout_wave_kernel<1, true>(q); }, E, 64, pk);
+      return;
+    }
     if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, false>(q); }, E, 64, p);
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
     return;
@@ -151,6 +160,11 @@ void dispatch(Which which, const StepParams &p, int E) {
 extern "C" {
 
 size_t emu_config_size(void) { return sizeof(hwy_config); }
+// k > 0: emu_run(mode 1) on the one-wavefront kernel runs k policy steps in one launch; the action / output arrays hold k blocks
+void emu_set_rollout(int k) { g_k_steps = k; }
+int emu_has_rollout_kernel(const hwy_config *cfg) {
+  return cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !g_force_block && !cfg->tune_block_kernel;
+}
 
 // mode: 0 = frames only (hwy_step_frames), 1 = full policy step (hwy_step), 2 = observe only
 static std::vector<int32_t> g_grid_ws;

@@ -21,6 +21,7 @@
 #define __host__
 #define __shared__ static
 #define __launch_bounds__(...)
+#define __forceinline__ inline
 #define HWY_FMA_K(a, b, c) fma((a), (b), (c))
 #define HWY_RELOAD_PARAMS(q, p) const StepParams &q = p  // hwy_wave.h: re-read of the kernel-argument segment
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
@@ -84,6 +85,7 @@ inline void wave_barrier() {
 
 inline void __syncthreads() { emu::barrier(); }
 inline void __threadfence() {}  // fibers of one OS thread: program order is memory order
+inline void __threadfence_block() {}
 
 namespace emu {
 inline unsigned long long g_ballot[2][16];
