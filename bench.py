@@ -392,7 +392,11 @@ def main() -> None:
     spawn_kw = ({"ego_spacing": cfg_dict["ego_spacing"], "vehicles_density": cfg_dict["vehicles_density"]}
                 if scenario == "highway" else {})
 
-    stream = torch.cuda.current_stream(dev)
+    # ONE stream for everything: the engine's launches, torch's tensor ops and the event torch.distributed records before it
+    # hands a buffer to RCCL.  It must be a real stream object: the handle of torch's default stream is NULL, which hwy_create
+    # reads as "create your own" -- and an engine-owned stream is not ordered with torch's.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng = Engine(cfg, device=local_rank, stream=stream.cuda_stream)
     eng.reset(base_seed=1_000_003 * (rank + 1), **spawn_kw)
     eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), **spawn_kw)

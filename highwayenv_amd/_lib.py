@@ -27,11 +27,29 @@ class EngineLibraryMissing(RuntimeError):
     pass
 
 
+def _share_the_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (same SONAME as /opt/rocm's).  If the engine library is loaded
+    first it binds to the system copy, torch later loads its own, and the SECOND runtime in the process finds no GPU ("No HIP
+    GPUs are available").  Loading torch's copy first -- when torch is installed at all -- makes both bind to one runtime,
+    whatever the import order; engine streams and torch tensors (bench.py, dist.py, vector.py's output="torch") then mix."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # no torch / an unusual layout: the system runtime is used
+        pass
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
     path = os.environ.get("HWY_ENGINE_LIB", LIB_PATH)  # developer knob: alternative build of the same library
+    _share_the_hip_runtime_with_torch()
     if not os.path.exists(path):
         raise EngineLibraryMissing(
             f"{path} not found. Build it with `python -m highwayenv_amd.build` (needs hipcc, "

@@ -83,6 +83,10 @@ class PackedStepOutputs:
 
     def gather_async(self):
         """Start the gather of this block to rank 0 and return the ``Work`` handle (None for world 1).
+        ORDERING: torch.distributed orders the collective after torch's CURRENT stream, so the engine that fills this block
+        must run on that stream -- create it with ``stream=torch.cuda.Stream().cuda_stream`` made current
+        (``torch.cuda.set_stream``), as bench.py does; the default stream's handle is NULL, which ``hwy_create`` reads as
+        "engine-owned stream".
         With two alternating ``PackedStepOutputs`` the collective of step t overlaps the kernel of step t+1;
         call ``work.wait()`` before the engine writes into this block again and before reading
         ``rank0_views()``."""

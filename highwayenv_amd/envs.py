@@ -208,6 +208,22 @@ class BatchedHighwayEnv:
                 "action": None}
         return self._shape_obs(obs), info
 
+    def reset_done(self, mask) -> np.ndarray:
+        """Re-spawn the environments of ``mask`` [E] on the device NOW (the "SameStep" autoreset of a vector env: the step that
+        ended an episode also returns the next episode's first observation) and return their observations [k, ...].  Seeds:
+        a counter-based sequence per environment, disjoint from the first episodes' (``spawn_mode="device"`` only)."""
+        if self.spawn_mode != "device":
+            raise NotImplementedError("reset_done (SameStep autoreset) needs spawn_mode='device'")
+        mask = np.asarray(mask, bool)
+        if not hasattr(self, "_episodes") or len(self._episodes) != self.num_envs:
+            self._episodes = np.zeros(self.num_envs, np.uint64)
+        self._episodes[mask] += np.uint64(1)
+        base = np.uint64(getattr(self, "_same_step_base", 0x5EED5EED))
+        seeds = base + np.arange(self.num_envs, dtype=np.uint64) + np.uint64(self.num_envs) * self._episodes
+        obs = self._engine.reset(seeds=seeds, mask=mask.astype(np.uint8), **self._device_spawn_args())
+        self.time[mask] = 0
+        return self._shape_obs(obs)[mask]
+
     def _ego_slots(self, st) -> np.ndarray:
         """Slot of the (first) controlled vehicle of every env."""
         return np.full(self.num_envs, self._hcfg.agent_index[0])
@@ -665,6 +681,11 @@ def register_envs(namespace: str | None = GYM_NAMESPACE) -> list:
         register(id=full, entry_point=f"{__name__}:{single.__name__}")
         done.append(full)
     return done
+
+
+def batched_class(env_id: str):
+    """The ``Batched*Env`` class of an id of REGISTRY (accepts the "highwayenv_amd/" namespace prefix too)."""
+    return REGISTRY[env_id.split("/", 1)[-1]][1]
 
 
 def make(env_id: str, config: dict = None, **kwargs):

@@ -51,7 +51,10 @@ def main():
     cfg_d = _abi.highway_fast_default_config()
     cfg_d.update({"vehicles_count": 20, "lanes_count": 3})
     cfg = _abi.make_config(cfg_d, E, fast=True)
-    stream = torch.cuda.current_stream(dev)
+    # one real stream for the engine, torch and the event torch.distributed records for RCCL (the default stream's handle is
+    # NULL, which hwy_create reads as "create your own": an engine-owned stream would not be ordered with torch's)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng = Engine(cfg, device=local, stream=stream.cuda_stream)
     eng.reset(seeds=np.asarray(list(mine), np.uint64) + 17, ego_spacing=1.5, vehicles_density=1.0)
     eng.set_autoreset(True, base_seed=1234 + mine.start, ego_spacing=1.5, vehicles_density=1.0)
