@@ -316,7 +316,7 @@ struct EnvBlock {
     double aux0[NV], aux1[NV];   // collision translation exchange / observation keys
     int lane[NV], tgt[NV], perm[NV];
     u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
-    u64 bal0[NW], bal1[NW], bal2[NW];
+    u64 bal0[2 * NW], bal1[2 * NW], bal2[2 * NW];  // block_ballot slot pairs
     u64 chk[NW];                  // vehicles with check_collisions (index space)
     // full pairwise collisions: per-wavefront list of candidate pairs (lower index | higher index << 8) and the per-vehicle
     // verdicts they meet in (highest partner with a pending impact, crashed flag, that pair's translation: aux1 / ipy)
@@ -326,16 +326,36 @@ struct EnvBlock {
   };
 
   // ---- workgroup-wide ballot: out[w] = ballot of wave w.  Must be called by ALL threads.
-  __device__ static inline void block_ballot(Shared &sh, bool pred, u64 *slot, u64 out[NW]) {
+  // ONE barrier: every call site owns a slot PAIR and alternates between its halves (`phase`, flipped here), so the next
+  // call's write cannot overtake a late reader of this one, and the write two calls later is at least one barrier behind it.
+  __device__ static inline void block_ballot(Shared &sh, bool pred, u64 *slot_pair, int &phase, u64 out[NW]) {
     const u64 b = __ballot(pred);
     if (NW == 1) {
       out[0] = b;
     } else {
       const int i = threadIdx.x;
+      u64 *slot = slot_pair + phase * NW;
+      phase ^= 1;
       if ((i & 63) == 0) slot[i >> 6] = b;
       __syncthreads();
       for (int w = 0; w < NW; ++w) out[w] = slot[w];
+    }
+  }
+  // two ballots, one barrier (slot pairs A and B advance together)
+  __device__ static inline void block_ballot2(Shared &sh, bool pa, bool pb, u64 *pair_a, u64 *pair_b, int &phase_a, int &phase_b,
+                                              u64 out_a[NW], u64 out_b[NW]) {
+    const u64 a = __ballot(pa), b = __ballot(pb);
+    if (NW == 1) {
+      out_a[0] = a;
+      out_b[0] = b;
+    } else {
+      const int i = threadIdx.x;
+      u64 *sa = pair_a + phase_a * NW, *sb = pair_b + phase_b * NW;
+      phase_a ^= 1;
+      phase_b ^= 1;
+      if ((i & 63) == 0) { sa[i >> 6] = a; sb[i >> 6] = b; }
       __syncthreads();
+      for (int w = 0; w < NW; ++w) { out_a[w] = sa[w]; out_b[w] = sb[w]; }
     }
   }
   __device__ static inline bool any_of(const u64 m[NW]) {
@@ -665,6 +685,7 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
   const int i = threadIdx.x;
   const bool active = i < p.N;
   const int V = p.V, F = p.F;
+  int ph_elig = 0;
   for (int a = 0; a < p.A; ++a) {
     const int ia = p.agent_index[a];
     const double ex = sh.x[ia], ey = sh.y[ia], ev = sh.v[ia], ec = sh.c[ia], es = sh.s[ia];
@@ -678,7 +699,7 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
     sh.aux0[i] = key;
     __syncthreads();
     u64 em[NW];
-    B::block_ballot(sh, elig, sh.bal0, em);
+    B::block_ballot(sh, elig, sh.bal0, ph_elig, em);
     int n_elig = 0;
     for (int w = 0; w < NW; ++w) n_elig += __popcll(em[w]);
     const int m = n_elig < V - 1 ? n_elig : V - 1;  // rows 1..m are filled
@@ -885,7 +906,12 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
 
   // static collision-check membership (index space)
   u64 chk[NW];
-  B::block_ballot(sh, active && (me.flags & HWY_F_CHECK_COLLISIONS), sh.bal0, chk);
+  int ph0 = 0, ph1 = 0, ph2 = 0;  // block_ballot phases of the three slot pairs
+  B::block_ballot(sh, active && (me.flags & HWY_F_CHECK_COLLISIONS), sh.bal0, ph0, chk);
+  // rank along the road, carried from frame to frame and from step to step (hint in the packed word) and merely VERIFIED
+  // (section C); sh.perm = its inverse.  Idle threads keep their own slot so that the table stays a permutation.
+  int rank = active ? me.rank : i;
+  sh.perm[i] = i;
   int n_chk = 0;
   for (int w = 0; w < NW; ++w) n_chk += __popcll(chk[w]);
   const bool all_check = n_chk == N;  // highway-v0: full pairwise; highway-fast-v0: ego only
@@ -909,29 +935,45 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     }
 
     // ---- B. frame-start snapshot -> LDS -----------------------------------------------------------
-    __syncthreads();  // everyone is done reading the previous snapshot
-    publish<NW>(sh, me, active);
-    __syncthreads();
+    // Only for the first frame: nothing the snapshot holds (position, speed, heading, lane, target lane, target speed)
+    // changes between the post-integration publish of section G and the start of the next frame -- collisions only set
+    // flags and pending impacts -- and G ends with a barrier.
+    if (fr == 0) {  // block-uniform
+      __syncthreads();  // (the static ballots above are read)
+      publish<NW>(sh, me, active);
+      if (active && rank >= 0 && rank < N) sh.perm[rank] = i;  // (a stale hint may collide: verified below)
+      __syncthreads();
+    }
 
     // ---- C. rank along the road + lane membership masks ---------------------------------------------
-    // rank = #{j : x_j < x_i} when all x are distinct; a tie (count_le - count_lt > 1, self included)
-    // is resolved by list order, exactly like a stable sort (rare: workgroup-uniform slow path)
-    int cnt_lt = 0, cnt_le = 0;
-#pragma unroll 4
-    for (int j = 0; j < N; ++j) {
-      const double xj = sh.x[j];
-      cnt_lt += (xj < me.x) ? 1 : 0;
-      cnt_le += (xj <= me.x) ? 1 : 0;
+    // The order along the road changes in a few per cent of the frames, so the rank of the previous frame is VERIFIED
+    // instead of recounted: my slot of the inverse table still holds me, and the vehicle of the next rank is strictly
+    // ahead of me.  If that holds for every vehicle the table is the sorted permutation and all x are distinct.
+    bool stale = false;
+    if (active) {
+      stale = rank < 0 || rank >= N || sh.perm[rank] != i;
+      if (!stale && rank + 1 < N) stale = !(me.x < sh.x[sh.perm[rank + 1]]);
     }
-    const bool tie = (cnt_le - cnt_lt) > 1;
-    int rank = cnt_lt;
-    if (tie)
-      for (int j = 0; j < i; ++j) rank += (sh.x[j] == me.x) ? 1 : 0;
-    if (active) sh.perm[rank] = i;
-    u64 tm[NW];
-    B::block_ballot(sh, active && tie, sh.bal1, tm);
-    const bool has_tie = B::any_of(tm);
-    __syncthreads();
+    bool has_tie = false;
+    if (__syncthreads_or(stale)) {  // block-uniform
+      // rank = #{j : x_j < x_i} when all x are distinct; a tie (count_le - count_lt > 1, self included)
+      // is resolved by list order, exactly like a stable sort (rare)
+      int cnt_lt = 0, cnt_le = 0;
+#pragma unroll 4
+      for (int j = 0; j < N; ++j) {
+        const double xj = sh.x[j];
+        cnt_lt += (xj < me.x) ? 1 : 0;
+        cnt_le += (xj <= me.x) ? 1 : 0;
+      }
+      const bool tie = (cnt_le - cnt_lt) > 1;
+      rank = active ? cnt_lt : i;
+      if (active && tie)
+        for (int j = 0; j < i; ++j) rank += (sh.x[j] == me.x) ? 1 : 0;
+      sh.perm[rank] = i;
+      u64 tm[NW];
+      B::block_ballot(sh, active && tie, sh.bal1, ph1, tm);  // (its barrier also publishes the table)
+      has_tie = B::any_of(tm);
+    }
     {
       const int j = active ? sh.perm[i] : 0;
       const double xj = sh.x[j], yj = sh.y[j];
@@ -988,9 +1030,13 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     }
     // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
     {
-      u64 cm[NW];
-      B::block_ballot(sh, changer, sh.bal2, cm);
-      for (int w = 0; w < NW; ++w) {
+      // A rival is ANOTHER vehicle on its way to another lane (with the target it had at the start of the frame or the one
+      // it has now): with at most one such vehicle in the environment no link can block
+      u64 mv[NW], cm[NW];
+      B::block_ballot2(sh, active && (me.lane != tgt_old || me.lane != me.tgt), changer, sh.bal0, sh.bal2, ph0, ph2, mv, cm);
+      int n_movers = 0;
+      for (int w = 0; w < NW; ++w) n_movers += __popcll(mv[w]);
+      for (int w = 0; w < NW && n_movers > 1; ++w) {
         u64 m = cm[w];
         while (m) {  // block-uniform loop
           const int ci = w * 64 + ctz64(m);
@@ -1006,7 +1052,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
             blk = (0 < d) && (d < d_star);
           }
           u64 bm[NW];
-          B::block_ballot(sh, blk, sh.bal1, bm);
+          B::block_ballot(sh, blk, sh.bal1, ph1, bm);
           if (i == ci && B::any_of(bm)) me.tgt = me.lane;  // abort
         }
       }
@@ -1067,7 +1113,12 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     __syncthreads();  // all reads of the frame-start snapshot are done
     publish<NW>(sh, me, active);
     if (active) sh.aux0[i] = x_old;
-    __syncthreads();
+    if (all_check) {  // (block-uniform) per-vehicle verdict slots of the pair pass below
+      sh.jmax[i] = -1;
+      sh.hit[i] = 0;
+    }
+    // the barrier that publishes the snapshot also answers "did any body move further / is any faster than the scan's bound"
+    const bool wide = __syncthreads_or(all_check && active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
     if (all_check) {
       // Full pairwise (highway-v0): outward scan in rank order from my own rank, bounded by the frame-start
       // distance (collision radius + the most two vehicles can move relative to each other in one frame);
@@ -1075,16 +1126,12 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       // sh.x/y/v/c/s now hold the post-integration bodies by index, sh.aux0 the frame-start x by index.
       // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
       // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the scan is the literal all-pairs loop
-      const bool wide = __syncthreads_or(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
       // Every unordered pair once, by the thread of its lower index: the walk only COLLECTS the pairs that pass the sphere
       // pre-check and the provable-separation test (one list per wavefront); the SAT then runs one PAIR per thread, and the
       // verdicts meet per vehicle in LDS -- across wavefronts, hence the workgroup barrier between "highest partner with a
       // pending impact" (ds_max) and the winner's write of its translation (hwy_wave.h has the one-wavefront version).
       unsigned short *const plist = sh.plist[i >> 6];
       const int lane_id_ = i & 63;
-      sh.jmax[i] = -1;
-      sh.hit[i] = 0;
-      __syncthreads();
       const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
       const u64 below = ((u64)1 << lane_id_) - 1;
       const Body mine{me.x, me.y, me.v, me.ch, me.sh};
@@ -1215,6 +1262,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     }
     observe_env<NW>(p, sh, e, me, true);
   }
+  me.rank = rank;  // the hint the next step verifies
   store_vehicle<NW>(p, e, me, false);
 }
 
