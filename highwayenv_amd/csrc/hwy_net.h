@@ -780,15 +780,23 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
       // brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED; its lane distance is measured on ITS current lane
       bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
       while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
-        if (pend_l || pend_r) {
-          const bool left = pend_l;
-          const int rf = left ? rl : rrt;
-          const double oxf = sh.ox[rf];
-          const double a_f = sh.kind[rf] ? EnvBlock<1>::idm_free_from_log(sh.lr[rf], delta) -
-                                               net_gap_term((me.x - oxf) - (sh.x[rf] - oxf), sh.v[rf], sh.c[rf], sh.s[rf],
-                                                            me.v, me.ch, me.sh)
-                                         : 0.0;
-          const bool safe = !(a_f < -HWY_LC_MAX_BRAKING);
+        const bool pend = pend_l || pend_r;
+        const bool left = pend_l;
+        const int rf = pend ? (left ? rl : rrt) : 0;
+        const double oxf = sh.ox[rf], lr_f = sh.lr[rf];
+        const bool is_veh = sh.kind[rf] != 0;
+        const double g = net_gap_term((me.x - oxf) - (sh.x[rf] - oxf), sh.v[rf], sh.c[rf], sh.s[rf], me.v, me.ch, me.sh);
+        // a_f = 3 (1 - E) - g, E = exp(delta * lr_f) >= 0: g beyond 5 is unsafe whatever E is, and a follower below its target
+        // speed (lr_f < 0, delta > 0) has E <= 1, so g below 2 is safe whatever E is (1e-6 margins; hwy_wave.h has the argument):
+        // the exp runs only if some pending lane falls in between
+        const bool sure_unsafe = is_veh && g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
+        const bool sure_safe = !is_veh || (lr_f < 0.0 && delta > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6);
+        bool safe = sure_safe;
+        if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
+          const double a_f = is_veh ? EnvBlock<1>::idm_free_from_log(lr_f, delta) - g : 0.0;
+          safe = !(a_f < -HWY_LC_MAX_BRAKING);
+        }
+        if (pend) {
           if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
         }
       }
@@ -798,10 +806,14 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     // abort rule for ongoing lane changes on the same road: ordered chain over Road.vehicles (behavior.py:229-244)
     {
       u64 cm = __ballot(changer && same_road);
+      // a rival is ANOTHER vehicle on its way to another lane (old or new target): none, no link can block
+      if (cm && __popcll(__ballot(veh && (me.lane != tgt_old || me.lane != me.tgt))) <= 1) cm = 0;
       while (cm) {  // wave-uniform
         const int ci = ctz64(cm);
         cm &= cm - 1;
         const int Tc = wave_bcast_i(tgt_f, ci);
+        // usually nobody else heads for the changer's lane: the link then costs three compares and a ballot
+        if (__ballot(veh && i != ci && me.lane != Tc && ((i < ci) ? me.tgt : tgt_old) == Tc) == 0) continue;
         const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
         const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
         const double oxc = wave_bcast(ox_me, ci);

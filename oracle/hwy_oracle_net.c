@@ -776,11 +776,19 @@ int orc_net_frames(const hwy_config *c, hwy_state *st, const int32_t *actions, i
 int orc_net_neighbours(const hwy_config *c, const hwy_state *st, int32_t e, int32_t slot, int32_t lane, int32_t *front,
                        int32_t *rear) {
   int N = c->num_vehicles;
-  if (e < 0 || e >= c->num_envs || slot < 0 || slot >= N || lane < 0 || lane >= c->net_lanes) return HWY_ERR_INVALID_ARG;
+  if (e < 0 || e >= c->num_envs || slot < 0 || slot >= N || lane >= c->net_lanes) return HWY_ERR_INVALID_ARG;
   ent_t *v = (ent_t *)malloc(sizeof(ent_t) * (size_t)N);
   load_env(c, st, e, v);
   net_t r = {c, v, N};
   int f, b;
+  /* road.py:499-501: lane_index = lane_index or vehicle.lane_index; if not lane_index: return None, None
+   * (lane < 0 == None; a vehicle without a lane index carries lane < 0) */
+  if (lane < 0) lane = v[slot].lane;
+  if (lane < 0 || lane >= c->net_lanes) {
+    *front = *rear = -1;
+    free(v);
+    return 0;
+  }
   neighbour_vehicles(&r, &v[slot], lane, &f, &b);
   *front = f; *rear = b;
   free(v);

@@ -56,8 +56,10 @@ def frames(cfg: _abi.HwyConfig, st: dict, actions, n_frames: int) -> None:
     assert rc == 0, rc
 
 
-def net_neighbours(cfg: _abi.HwyConfig, st: dict, e: int, slot: int, lane: int) -> tuple:
-    """Road.neighbour_vehicles(vehicle, lane_index) on a road-network scenario: (front slot | None, rear slot | None)."""
+def net_neighbours(cfg: _abi.HwyConfig, st: dict, e: int, slot: int, lane) -> tuple:
+    """Road.neighbour_vehicles(vehicle, lane_index) on a road-network scenario: (front slot | None, rear slot | None).
+    ``lane=None`` is the reference's ``lane_index=None``: the vehicle's own lane, or (None, None) when it has none (< 0)."""
+    lane = -1 if lane is None else lane
     f, b = C.c_int32(-1), C.c_int32(-1)
     s = _abi.state_struct(st)
     rc = lib().orc_net_neighbours(C.byref(cfg), C.byref(s), C.c_int32(e), C.c_int32(slot), C.c_int32(lane),

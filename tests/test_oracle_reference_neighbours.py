@@ -157,6 +157,16 @@ def test_vehicle_far_on_next_segment_detected():
 
 
 # ---- test_front_on_curve_segment (:237-247): StraightLane a->b followed by a CircularLane b->c ------------------------------
+def test_lane_index_none_returns_none():
+    """test_neighbour_vehicles.py:358-366: a vehicle without a lane index has no neighbours (road.py:499-501); with
+    lane_index=None and a lane index the vehicle's own lane is searched."""
+    r = NetRoad(straight_connected_road, False)
+    ego, front = r.make_vehicle("ab", 0, 25), r.make_vehicle("ab", 0, 40)
+    assert oracle.net_neighbours(r.cfg, r.st, 0, ego, None) == (front, None)
+    r.st["lane"][0, ego] = -1  # ego.lane_index = None
+    assert oracle.net_neighbours(r.cfg, r.st, 0, ego, None) == (None, None)
+
+
 def test_front_on_curve_segment():
     c = oracle_ix.IxConfig()
     c.num_envs, c.n_slots, c.n_lanes, c.n_route, c.connected_lanes = 1, 4, 2, 4, 1
