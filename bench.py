@@ -94,7 +94,10 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     achieved = flop / avg_kernel_s / 1e12
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
             "valu_instructions_per_env_step": c["SQ_INSTS_VALU"], "salu_instructions_per_env_step": c["SQ_INSTS_SALU"],
-            "valu_issue_utilisation_while_resident": c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"],
+            # (one wavefront per environment and the whole grid resident: the headline workload only)
+            "valu_issue_utilisation_while_resident": (c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"]
+                                                      if workload == "fast" else None),
+            "valu_active_fraction_of_a_wavefront": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
             "source": d["_file"] + " (SQ counters of this kernel build and config)"}
 
 
