@@ -73,8 +73,8 @@ def ticks(text):
             "      n_recount += __ballot(rank != r_before) ? 1.0f : 0.0f; }\n    // lane membership")(t)
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
-    t = sub("    observe_wave<true>(q, e, me, true, rank);\n  }\n  me.rank = rank;",
-            "    observe_wave<true>(q, e, me, true, rank);\n  }\n  TICK(11)\n  me.rank = rank;")(t)
+    t = sub("    observe_wave<true>(q, e, eo, me, true, rank);\n  }\n  me.rank = rank;",
+            "    observe_wave<true>(q, e, eo, me, true, rank);\n  }\n  TICK(11)\n  me.rank = rank;")(t)
     t = sub("  store_vehicle<1>(q, e, me, false);\n}",
             "  store_vehicle<1>(q, e, me, false);\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
@@ -179,7 +179,7 @@ VARIANTS = {
     "wnologexp": NO_LOGEXP,
     "wnosincos": [(W, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))],
     "wnosteer": [(W, sub("    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "    double tb = inv_v * 1e-9;"))],
-    "wnoobs": [(W, sub("    observe_wave<true>(q, e, me, true, rank);\n", ""))],
+    "wnoobs": [(W, sub("    observe_wave<true>(q, e, eo, me, true, rank);\n", ""))],
     "wticks": [(W, ticks)],
     "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
@@ -199,8 +199,8 @@ VARIANTS = {
                              "      net_lane_pass<false>(np, sh, sine_mask, present, me.x, me.y, me.h, &bits_new, &cl_new); cl_new = me.lane;"))],
     # wave timeline: every wavefront of hwy_step_wave_kernel writes its start / end s_memrealtime (100 MHz) and HW_ID /
     # XCC_ID over the first four observation words of its environment (tools/wave_timeline.py reads them)
-    "wtimeline": [(W, sub("  typedef EnvBlock<1> B;\n  __shared__ WaveShared sh;\n  const int e = blockIdx.x, i = threadIdx.x;\n  const int N = p.N;",
-                          "  typedef EnvBlock<1> B;\n  __shared__ WaveShared sh;\n  const int e = blockIdx.x, i = threadIdx.x;\n"
+    "wtimeline": [(W, sub("  typedef EnvBlock<1> B;\n  const int i = threadIdx.x;\n  const int N = p.N;",
+                          "  typedef EnvBlock<1> B;\n  const int i = threadIdx.x;\n"
                           "  const unsigned long long tl_t0 = wall_clock64();\n"
                           "  const unsigned tl_hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), tl_xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
                           "  const int N = p.N;")),
@@ -222,8 +222,8 @@ VARIANTS = {
                   (W, sub("        const bool pend = pend_l || pend_r;", "        if (i == 0) atomicAdd(&sh.cnt[4], 1);\n        const bool pend = pend_l || pend_r;")),
                   (W, sub("o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u;",
                           "o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u; for (int k = 0; k < 5; ++k) o[5 + k] = (unsigned)sh.cnt[k];")),
-                  (W, sub("      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n    return;",
-                          "      p.terminated[e] = 0;\n      p.truncated[e] = 0;\n    }\n"
+                  (W, sub("      p.terminated[eo] = 0;\n      p.truncated[eo] = 0;\n    }\n    return;",
+                          "      p.terminated[eo] = 0;\n      p.truncated[eo] = 0;\n    }\n"
                           "    if (p.obs && i == 0) {\n"
                           "      __builtin_amdgcn_s_waitcnt(0);\n"
                           "      const unsigned long long tl_t1 = wall_clock64();\n"
