@@ -954,6 +954,19 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       stale = rank < 0 || rank >= N || sh.perm[rank] != i;
       if (!stale && rank + 1 < N) stale = !(me.x < sh.x[sh.perm[rank + 1]]);
     }
+    // lane membership masks in rank space (thread r speaks for the vehicle of rank r): written OPTIMISTICALLY from the table as
+    // it stands, so that the barrier of the verification publishes them too; a stale table (rare) redoes them below
+    auto write_masks = [&]() {
+      const int j = active ? sh.perm[i] : 0;
+      const double xj = sh.x[j], yj = sh.y[j];
+      const bool inr = active && (-5.0 <= xj) && (xj < p.road_length + 5.0);
+      for (int L = 0; L < p.L; ++L) {
+        const bool m = inr && (fabs(yj - L * p.lane_width) <= p.lane_width / 2 + 1.0);
+        const u64 b = __ballot(m);
+        if (lane_id == 0) sh.mask[L][wave] = b;
+      }
+    };
+    write_masks();
     bool has_tie = false;
     if (__syncthreads_or(stale)) {  // block-uniform
       // rank = #{j : x_j < x_i} when all x are distinct; a tie (count_le - count_lt > 1, self included)
@@ -973,18 +986,9 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       u64 tm[NW];
       B::block_ballot(sh, active && tie, sh.bal1, ph1, tm);  // (its barrier also publishes the table)
       has_tie = B::any_of(tm);
+      write_masks();
+      __syncthreads();
     }
-    {
-      const int j = active ? sh.perm[i] : 0;
-      const double xj = sh.x[j], yj = sh.y[j];
-      const bool inr = active && (-5.0 <= xj) && (xj < p.road_length + 5.0);
-      for (int L = 0; L < p.L; ++L) {
-        const bool m = inr && (fabs(yj - L * p.lane_width) <= p.lane_width / 2 + 1.0);
-        const u64 b = __ballot(m);
-        if (lane_id == 0) sh.mask[L][wave] = b;
-      }
-    }
-    __syncthreads();
 
     // ---- D. Road.act: lane-change policy (behavior.py:219-263) ----------------------------------------
     const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
@@ -1136,7 +1140,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       const u64 below = ((u64)1 << lane_id_) - 1;
       const Body mine{me.x, me.y, me.v, me.ch, me.sh};
       int n_list = 0, k = 1;  // wave-uniform
-      bool go_a = active, go_b = active, walking = true;
+      bool go_a = active, go_b = active, walking = true, any_pass = false;
       for (;;) {
         while (walking && n_list < 64) {
           const int ra = rank - k, rb = rank + k;
@@ -1165,6 +1169,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
           }
         }
         if (__syncthreads_or(walking || n_list > 0) == 0) break;  // block-uniform
+        any_pass = true;
         const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
         const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
         const int c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
@@ -1189,7 +1194,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
         if (64 + lane_id_ < left) plist[64 + lane_id_] = (unsigned short)c1;
         n_list = left;
       }
-      __syncthreads();
+      if (any_pass) __syncthreads();  // (block-uniform; without a pass nobody wrote a verdict slot since its reset)
       if (active && sh.jmax[i] >= 0) {
         me.impx = sh.aux1[i];
         me.impy = sh.ipy[i];
