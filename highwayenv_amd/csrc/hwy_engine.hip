@@ -630,7 +630,15 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
     HWY_HIP(eng, hwy::launch_rollout(p, eng->cfg.num_envs, eng->stream, eng->rollout_waves_per_eu, eng->cfg.tune_extra_lds));
     return HWY_OK;
   }
-  // the workgroup kernel (N > 64) and the road-network kernels: k launches back to back on the engine's stream, block k of every plane
+  if (is_net(eng)) {  // the merge kernel has the multi-step form too
+    p.k_steps = k_steps;
+    p.num_envs = eng->cfg.num_envs;
+    hwy::NetParams np;
+    hwy::net_params_from_config(eng->cfg, p, np);
+    HWY_HIP(eng, hwy::launch_net_rollout(np, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
+    return HWY_OK;
+  }
+  // the workgroup kernel (N > 64) and the intersection kernel: k launches back to back on the engine's stream, block k of every plane
   for (int32_t k = 0; k < k_steps; ++k) {
     p.actions = d_actions + (size_t)k * n_act; p.obs = d_obs + (size_t)k * n_obs; p.reward = d_reward + (size_t)k * n_ea;
     p.terminated = d_terminated + (size_t)k * E; p.truncated = d_truncated + (size_t)k * E;

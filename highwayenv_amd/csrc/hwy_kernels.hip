@@ -110,6 +110,19 @@ int net_step_resident_blocks(int waves_per_eu) {
     default: return resident_blocks(hwy_net_step_kernel<4>, 64, 0);
   }
 }
+hipError_t launch_net_rollout(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) {
+    hipLaunchKernelGGL((hwy_net_rollout_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
+    return hipGetLastError();
+  }
+  switch (waves_per_eu) {
+    case 1: hipLaunchKernelGGL((hwy_net_rollout_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 2: hipLaunchKernelGGL((hwy_net_rollout_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 3: hipLaunchKernelGGL((hwy_net_rollout_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    default: hipLaunchKernelGGL((hwy_net_rollout_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
   if (np.s.obs_type != HWY_OBS_KINEMATICS) {  // the OccupancyGrid build (its own instantiation: hwy_net.h, net_observe<GRID>)
     hipLaunchKernelGGL((hwy_net_step_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);

@@ -19,6 +19,7 @@ hipError_t launch_math_probe(int op, const double *in, double *out, long long n,
 hipError_t launch_observe(const StepParams &p, int num_envs, hipStream_t stream);
 // road-network scenarios (hwy_net.h): one wavefront per environment
 hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu);
+hipError_t launch_net_rollout(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu);  // np.s.k_steps steps per launch
 hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream);
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream);
 // intersection scenario (hwy_ix.h): one wavefront per environment

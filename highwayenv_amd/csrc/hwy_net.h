@@ -337,13 +337,13 @@ __device__ inline void net_neighbours_scan(const NetShared &sh, u64 pm, int bits
 //      their features), but only Road.vehicles are rasterised (not the Obstacle of Road.objects, :366-368) and the on-road
 //      layer walks the waypoints of EVERY lane of the table -- lane.position(wp, 0) = (x0 + wp, y0 [+ amplitude * sin(
 //      pulsation * wp + phase)]), SineLane included (:454-484). ---------------------------------------------------------
-__device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh, int e, int a, const Veh &me, bool veh,
+__device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh, int e, int eo, int a, const Veh &me, bool veh,
                                         double ex, double ey, double ev, double ec, double es) {
   const StepParams &p = np.s;
   const int i = threadIdx.x, NT = 64;
   const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
   int32_t *own = p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
-  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)F * WH;  // eo: output row (hwy_wave.h: observe_wave)
   for (int t = i; t < WH; t += NT) {
     grid_ws_store(own + t, 0x7fffffff);
     grid_ws_store(road + t, 0);
@@ -412,7 +412,7 @@ __device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh
 //      observation -- a compile-time switch, so that the Kinematics kernels (the measured configs) carry none of the grid
 //      code in their register / scalar allocation. ---------------------------------------------------------------------
 template <bool GRID>
-__device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, const Veh &me, bool write_reward) {
+__device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, int eo, const Veh &me, bool write_reward) {
   const StepParams &p = np.s;
   const int i = threadIdx.x;
   const bool present = i < p.N && !(me.flags & HWY_F_ABSENT);
@@ -445,10 +445,10 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
     if constexpr (GRID) {
-      if (p.obs) net_observe_grid(np, sh, e, a, me, veh, ex, ey, ev, ec, es);
+      if (p.obs) net_observe_grid(np, sh, e, eo, a, me, veh, ex, ey, ev, ec, es);
     }
     if (!GRID && p.obs) {
-      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (present && row >= 0) {
         for (int f = 0; f < F; ++f) {
@@ -475,7 +475,7 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
     }
     if (write_reward && i == ia) {
       const bool crashed = (me.flags & HWY_F_CRASHED) != 0;
-      const int act = p.actions ? p.actions[(size_t)e * p.A + a] : HWY_IDLE;
+      const int act = p.actions ? p.actions[(size_t)eo * p.A + a] : HWY_IDLE;
       const double scaled_speed = lmap(me.v, p.rs0, p.rs1, 0.0, 1.0);
       double reward = 0.0;
       reward = reward + p.collision_reward * (crashed ? 1.0 : 0.0);
@@ -484,16 +484,16 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
       reward = reward + np.lane_change_reward * ((act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) ? 1.0 : 0.0);
       reward = reward + np.merging_speed_reward * merging;
       reward = lmap(reward, p.collision_reward + np.merging_speed_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
-      p.reward[(size_t)e * p.A + a] = reward;
-      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
-      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      p.reward[(size_t)eo * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)eo * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = crashed ? 1 : 0;
       if (a == 0) {
         const bool term = crashed || (me.x > np.merge_end_x);  // merge_env.py:77-79 / :365-369
         const double t = p.st.time[e] + p.policy_dt;
         const bool trunc = t >= p.duration;  // duration == +inf: MergeEnv never truncates (merge_env.py:81-82)
         p.st.time[e] = t;
-        p.terminated[e] = term ? 1 : 0;
-        p.truncated[e] = trunc ? 1 : 0;
+        p.terminated[eo] = term ? 1 : 0;
+        p.truncated[eo] = trunc ? 1 : 0;
         if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
       }
     }
@@ -617,32 +617,40 @@ __device__ inline void net_spawn_env(const NetParams &np, NetShared &sh, uint64_
 }
 
 // =============================================================================================================
-template <int WPE, bool GRID = false>
-__global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams np) {
+// A second view `q` of the by-value kernel argument `np` through a pointer the compiler cannot see through (hwy_wave.h:
+// HWY_RELOAD_PARAMS).  The kernel must have NetParams as its only argument.
+#ifndef HWY_RELOAD_NET_PARAMS
+#define HWY_RELOAD_NET_PARAMS(q, np)                              \
+  auto kernarg_ = __builtin_amdgcn_kernarg_segment_ptr();         \
+  asm volatile("" : "+s"(kernarg_));                              \
+  const NetParams &q = *(const NetParams *)kernarg_
+#endif
+
+// One policy step of environment e by its wavefront (the lane table is in LDS); eo = row of the action / output planes.
+template <bool GRID>
+__device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &sh, const int e, const int eo) {
   const StepParams &p = np.s;
-  __shared__ NetShared sh;
-  const int e = blockIdx.x, i = threadIdx.x;
+  const int i = threadIdx.x;
   const int N = p.N;
-  net_load_table(np, sh);
 
   // ---- auto-reset --------------------------------------------------------------------------------------------
   if (p.autoreset && p.st.done[e]) {
     Veh me;
     const uint32_t episode = p.st.episode[e] + 1u;
     net_spawn_env(np, sh, p.rp.base_seed + (uint64_t)e, episode, me);
-    net_observe<GRID>(np, sh, e, me, false);
+    net_observe<GRID>(np, sh, e, eo, me, false);
     store_vehicle<1>(p, e, me);
     if (i < p.A) {  // agent a == slot a
-      p.reward[(size_t)e * p.A + i] = 0.0;
-      if (p.info_speed) p.info_speed[(size_t)e * p.A + i] = me.v;
-      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + i] = 0;
+      p.reward[(size_t)eo * p.A + i] = 0.0;
+      if (p.info_speed) p.info_speed[(size_t)eo * p.A + i] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + i] = 0;
     }
     if (i == 0) {
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
       p.st.episode[e] = episode;
-      p.terminated[e] = 0;
-      p.truncated[e] = 0;
+      p.terminated[eo] = 0;
+      p.truncated[eo] = 0;
     }
     return;
   }
@@ -682,7 +690,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
     // ---- A. meta-actions of all agents (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315;
     //         ControlledVehicle.act starts with follow_road, :98) ---------------------------------------------
     if (fr == 0 && p.actions && controlled) {
-      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)e * p.A + agent]);
+      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)eo * p.A + agent]);
       me.tgt = net_follow_road(sh, me.tgt, me.x, me.y);
       if (act == HWY_FASTER || act == HWY_SLOWER) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
@@ -1003,11 +1011,33 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams n
   }  // frames
 
   // ---- G. observe / reward / done ------------------------------------------------------------------------------
-  if (p.full_step) net_observe<GRID>(np, sh, e, me, true);
+  if (p.full_step) net_observe<GRID>(np, sh, e, eo, me, true);
   {
     // rank hint for the next step is not used by this kernel; keep the slot index
     me.rank = i & 0xff;
     store_vehicle<1>(p, e, me, false);
+  }
+}
+
+template <int WPE, bool GRID = false>
+__global__ void __launch_bounds__(64, WPE) hwy_net_step_kernel(const NetParams np) {
+  __shared__ NetShared sh;
+  net_load_table(np, sh);
+  net_policy_step<GRID>(np, sh, blockIdx.x, blockIdx.x);
+}
+
+// hwy_rollout_device on the road-network kernel: np.s.k_steps policy steps per wavefront in one launch (hwy_wave.h:
+// hwy_rollout_wave_kernel has the argument); the lane table is loaded into LDS once.
+template <int WPE, bool GRID = false>
+__global__ void __launch_bounds__(64, WPE) hwy_net_rollout_kernel(const NetParams np) {
+  __shared__ NetShared sh;
+  net_load_table(np, sh);
+  const int e = blockIdx.x;
+  for (int k = 0; k < np.s.k_steps; ++k) {  // wave-uniform
+    HWY_RELOAD_NET_PARAMS(nk, np);  // a fresh, opaque view of the arguments per step: nothing stays live -- spilled -- across steps
+    net_policy_step<GRID>(nk, sh, e, k * nk.s.num_envs + e);
+    HWY_WAVE_LDS_FENCE();
+    __threadfence_block();
   }
 }
 
@@ -1022,7 +1052,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_reset_kernel(const NetParams 
   Veh me;
   const uint64_t seed = p.reset_seeds ? p.reset_seeds[e] : p.rp.base_seed + (uint64_t)e;
   net_spawn_env(np, sh, seed, 0u, me);
-  net_observe<GRID>(np, sh, e, me, false);
+  net_observe<GRID>(np, sh, e, e, me, false);
   store_vehicle<1>(p, e, me);
   if (i == 0) {
     p.st.time[e] = 0.0;
@@ -1038,7 +1068,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_net_observe_kernel(const NetParam
   net_load_table(np, sh);
   Veh me;
   load_vehicle<1>(np.s, blockIdx.x, me);
-  net_observe<GRID>(np, sh, blockIdx.x, me, false);
+  net_observe<GRID>(np, sh, blockIdx.x, blockIdx.x, me, false);
 }
 
 }  // namespace hwy

@@ -116,7 +116,13 @@ void dispatch(Which which, const StepParams &p, int E) {
     const bool grid = p.obs_type != HWY_OBS_KINEMATICS;
     switch (which) {
       // same dispatch rule as hwy_kernels.hip: the OccupancyGrid observation has its own instantiation
-      case STEP: if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1, true>(q); }, E, 64, np);
+      case STEP: if (g_k_steps > 0) {  // hwy_rollout_device: k steps in one launch
+                   np.s.k_steps = g_k_steps;
+                   np.s.num_envs = E;
+                   if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_rollout_kernel<1, true>(q); }, E, 64, np);
+                   else emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_rollout_kernel<1>(q); }, E, 64, np);
+                 }
+                 else if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1, true>(q); }, E, 64, np);
                  else emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_step_kernel<1>(q); }, E, 64, np);
                  break;
       case RESET: if (grid) emu::launch([](const hwy::NetParams &q) { hwy::hwy_net_reset_kernel<1, true>(q); }, E, 64, np);
@@ -163,6 +169,7 @@ size_t emu_config_size(void) { return sizeof(hwy_config); }
 // k > 0: emu_run(mode 1) on the one-wavefront kernel runs k policy steps in one launch; the action / output arrays hold k blocks
 void emu_set_rollout(int k) { g_k_steps = k; }
 int emu_has_rollout_kernel(const hwy_config *cfg) {
+  if (cfg->scenario == HWY_SCENARIO_MERGE || cfg->scenario == HWY_SCENARIO_MERGE_GENERIC) return 1;
   return cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !g_force_block && !cfg->tune_block_kernel;
 }
 
