@@ -147,6 +147,16 @@ struct StepParams {
   ResetParams rp;
 };
 
+// A second view `q` of the by-value kernel argument `p` through a pointer the compiler cannot see through: the fields are
+// loaded (scalar loads from the kernel-argument segment) where they are used instead of staying live -- as SGPRs spilled to
+// VGPR lanes -- across long code.  The kernel must have StepParams as its only argument (offset 0 of the segment).
+#ifndef HWY_RELOAD_STEP_PARAMS
+#define HWY_RELOAD_STEP_PARAMS(q, p)                                  \
+  auto kernarg_##q = __builtin_amdgcn_kernarg_segment_ptr();          \
+  asm volatile("" : "+s"(kernarg_##q));                             \
+  const StepParams &q = *(const StepParams *)kernarg_##q
+#endif
+
 // ---- utils.py ---------------------------------------------------------------------------
 // utils.py:50-56: x if |x| > eps else (eps if x >= 0 else -eps).  For every x but NaN that is max(|x|, eps) carrying the sign
 // of (x < 0) -- -0.0 counts as >= 0, like in the reference: a max, a compare and a sign flip instead of two compares and two
@@ -679,7 +689,8 @@ __device__ inline void observe_grid(const StepParams &p, int e, int a, const Veh
 //      Expects sh.x/y/v/c/s to hold the CURRENT state of all vehicles.  Block-uniform control flow.
 template <int NW>
 __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::Shared &sh, int e, const Veh &me,
-                                   bool write_reward) {
+                                   bool write_reward, int eo = -1) {
+  eo = eo < 0 ? e : eo;  // row of the output planes (== e except in a multi-step launch, hwy_rollout_device)
   const bool kin = p.obs_type == HWY_OBS_KINEMATICS;
   typedef EnvBlock<NW> B;
   const int i = threadIdx.x;
@@ -711,9 +722,9 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
         pos += (kk < key) || (kk == key && k < i);
       }
     }
-    if (p.obs && !kin) observe_grid<NW>(p, e, a, me, ex, ey, ev, ec, es);
+    if (p.obs && !kin) observe_grid<NW>(p, e, a, me, ex, ey, ev, ec, es, eo);
     if (p.obs && kin) {
-      float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+      float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)(V * F);
       const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
       if (active && row >= 0) {
         for (int f = 0; f < F; ++f) {
@@ -755,9 +766,9 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
       if (p.flags & HWY_C_NORMALIZE_REWARD)
         reward = lmap(reward, p.collision_reward, p.high_speed_reward + p.right_lane_reward, 0.0, 1.0);
       reward *= (on_road ? 1.0 : 0.0);
-      p.reward[(size_t)e * p.A + a] = reward;
-      if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
-      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = crashed ? 1 : 0;
+      p.reward[(size_t)eo * p.A + a] = reward;
+      if (p.info_speed) p.info_speed[(size_t)eo * p.A + a] = me.v;
+      if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = crashed ? 1 : 0;
       if (a == 0) {
         // _is_terminated looks at controlled_vehicles[0] (highway_env.py:141-147); time += 1/policy_frequency
         // (abstract.py:274); _is_truncated: time >= duration (highway_env.py:149-151)
@@ -765,8 +776,8 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
         const double t = p.st.time[e] + p.policy_dt;
         const bool trunc = t >= p.duration;
         p.st.time[e] = t;
-        p.terminated[e] = term ? 1 : 0;
-        p.truncated[e] = trunc ? 1 : 0;
+        p.terminated[eo] = term ? 1 : 0;
+        p.truncated[eo] = trunc ? 1 : 0;
         if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
       }
     }
@@ -859,11 +870,11 @@ __global__ void __launch_bounds__(NW * 64) hwy_observe_kernel(const StepParams p
 // =============================================================================================
 // The fused policy-step kernel.
 // WPE = minimum waves per SIMD the register allocator must leave room for (occupancy knob).
-template <int NW, int WPE>
-__global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams p) {
+// One policy step of environment e by its workgroup; eo = row of the action / output planes (hwy_wave.h: observe_wave).
+template <int NW>
+__device__ __forceinline__ void block_policy_step(const StepParams &p, typename EnvBlock<NW>::Shared &sh, const int e, const int eo) {
   typedef EnvBlock<NW> B;
-  __shared__ typename B::Shared sh;
-  const int e = blockIdx.x, i = threadIdx.x;
+  const int i = threadIdx.x;
   const int N = p.N;
   const bool active = i < N;
   const int lane_id = i & 63, wave = i >> 6;
@@ -875,22 +886,22 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     spawn_env<NW>(p, sh.aux0, sh.aux1, e, p.rp.base_seed + (uint64_t)e, episode, me);
     publish<NW>(sh, me, active);
     __syncthreads();
-    observe_env<NW>(p, sh, e, me, false);
+    observe_env<NW>(p, sh, e, me, false, eo);
     store_vehicle<NW>(p, e, me);
     if (active && (me.flags & HWY_F_CONTROLLED)) {
       for (int a = 0; a < p.A; ++a)
         if (p.agent_index[a] == i) {
-          p.reward[(size_t)e * p.A + a] = 0.0;
-          if (p.info_speed) p.info_speed[(size_t)e * p.A + a] = me.v;
-          if (p.info_crashed) p.info_crashed[(size_t)e * p.A + a] = 0;
+          p.reward[(size_t)eo * p.A + a] = 0.0;
+          if (p.info_speed) p.info_speed[(size_t)eo * p.A + a] = me.v;
+          if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = 0;
         }
     }
     if (i == 0) {
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
       p.st.episode[e] = episode;
-      p.terminated[e] = 0;
-      p.truncated[e] = 0;
+      p.terminated[eo] = 0;
+      p.truncated[eo] = 0;
     }
     return;
   }
@@ -920,7 +931,7 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
     // ---- A. action_type.act (abstract.py:294-304) -> MDPVehicle.act(label) (controller.py:295-315):
     //         target updates only; the controllers run below with Road.act (same state => same command)
     if (fr == 0 && p.actions && controlled) {
-      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)e * p.A + agent]);
+      const int act = HWY_ACTION_TO_ALL(p.action_set, p.actions[(size_t)eo * p.A + agent]);
       if (act == HWY_FASTER || act == HWY_SLOWER) {
         const double xs = (me.v - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
         int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
@@ -1265,10 +1276,29 @@ __global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams
       publish<NW>(sh, me, active);
       __syncthreads();
     }
-    observe_env<NW>(p, sh, e, me, true);
+    observe_env<NW>(p, sh, e, me, true, eo);
   }
   me.rank = rank;  // the hint the next step verifies
   store_vehicle<NW>(p, e, me, false);
+}
+
+template <int NW, int WPE>
+__global__ void __launch_bounds__(NW * 64, WPE) hwy_step_kernel(const StepParams p) {
+  __shared__ typename EnvBlock<NW>::Shared sh;
+  block_policy_step<NW>(p, sh, blockIdx.x, blockIdx.x);
+}
+
+// hwy_rollout_device on the workgroup kernel: p.k_steps policy steps per workgroup in one launch (hwy_wave.h:
+// hwy_rollout_wave_kernel has the argument).
+template <int NW, int WPE>
+__global__ void __launch_bounds__(NW * 64, WPE) hwy_rollout_kernel(const StepParams p) {
+  __shared__ typename EnvBlock<NW>::Shared sh;
+  const int e = blockIdx.x;
+  for (int k = 0; k < p.k_steps; ++k) {  // block-uniform
+    HWY_RELOAD_STEP_PARAMS(pk, p);  // a fresh, opaque view of the arguments per step: nothing stays live -- spilled -- across steps
+    block_policy_step<NW>(pk, sh, e, k * pk.num_envs + e);
+    __syncthreads();  // the next step's loads and LDS writes follow this step's stores and LDS reads
+  }
 }
 
 // ---- self-test kernel for hwy_math.h (hwy_debug_math) ------------------------------------------------

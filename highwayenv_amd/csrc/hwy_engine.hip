@@ -624,10 +624,11 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
   p.full_step = 1;
   p.actions = d_actions; p.obs = d_obs; p.reward = d_reward; p.terminated = d_terminated; p.truncated = d_truncated;
   p.info_speed = d_info_speed; p.info_crashed = d_info_crashed;
-  if (!is_ix(eng) && !is_net(eng) && hwy::has_rollout_kernel(p, eng->force_block_kernel)) {
+  if (!is_ix(eng) && !is_net(eng)) {  // straight road: K steps in ONE launch
     p.k_steps = k_steps;
     p.num_envs = eng->cfg.num_envs;
-    HWY_HIP(eng, hwy::launch_rollout(p, eng->cfg.num_envs, eng->stream, eng->rollout_waves_per_eu, eng->cfg.tune_extra_lds));
+    HWY_HIP(eng, hwy::launch_rollout(p, eng->cfg.num_envs, eng->stream, eng->rollout_waves_per_eu, eng->cfg.tune_extra_lds,
+                                     eng->force_block_kernel, eng->waves_per_eu));
     return HWY_OK;
   }
   if (is_net(eng)) {  // the merge kernel has the multi-step form too
@@ -638,7 +639,8 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
     HWY_HIP(eng, hwy::launch_net_rollout(np, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
     return HWY_OK;
   }
-  // the workgroup kernel (N > 64) and the intersection kernel: k launches back to back on the engine's stream, block k of every plane
+  // the intersection kernel (its next-episode pre-warming blocks are ordered by launches): k launches back to back on the
+  // engine's stream, block k of every plane
   for (int32_t k = 0; k < k_steps; ++k) {
     p.actions = d_actions + (size_t)k * n_act; p.obs = d_obs + (size_t)k * n_obs; p.reward = d_reward + (size_t)k * n_ea;
     p.terminated = d_terminated + (size_t)k * E; p.truncated = d_truncated + (size_t)k * E;

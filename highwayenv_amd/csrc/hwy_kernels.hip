@@ -36,6 +36,17 @@ static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t
   return hipGetLastError();
 }
 template <int WPE>
+static hipError_t launch_block_rollout_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
+  switch (waves_for(p.N)) {
+    case 1: hipLaunchKernelGGL((hwy_rollout_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL((hwy_rollout_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((hwy_rollout_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((hwy_rollout_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+template <int WPE>
 static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t stream, int lds) {
   // lds = hwy_config.tune_extra_lds: dynamic LDS reserved per workgroup, i.e. fewer resident wavefronts per SIMD, so that part
   // of the grid is dispatched as wavefronts retire (the hardware then balances unevenly loaded SIMDs)
@@ -53,10 +64,18 @@ static hipError_t launch_rollout_wpe(const StepParams &p, int num_envs, hipStrea
     hipLaunchKernelGGL((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
-// hwy_rollout_device on the one-wavefront kernel: p.k_steps policy steps in one launch.  False = this engine's step kernel has
-// no multi-step form (N > 64, road networks): the caller launches step by step.
-bool has_rollout_kernel(const StepParams &p, bool force_block_kernel) { return p.N <= 64 && !force_block_kernel; }
-hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds) {
+// hwy_rollout_device on the straight-road kernels: p.k_steps policy steps in one launch -- the one-wavefront kernel for N <= 64,
+// the workgroup kernel otherwise (or when forced).
+hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds,
+                          bool force_block_kernel, int block_waves_per_eu) {
+  if (p.N > 64 || force_block_kernel) {
+    switch (block_waves_per_eu) {
+      case 1: return launch_block_rollout_wpe<1>(p, num_envs, stream);
+      case 2: return launch_block_rollout_wpe<2>(p, num_envs, stream);
+      case 3: return launch_block_rollout_wpe<3>(p, num_envs, stream);
+      default: return launch_block_rollout_wpe<4>(p, num_envs, stream);
+    }
+  }
   switch (waves_per_eu) {
     case 1: return launch_rollout_wpe<1>(p, num_envs, stream, extra_lds);
     case 2: return launch_rollout_wpe<2>(p, num_envs, stream, extra_lds);

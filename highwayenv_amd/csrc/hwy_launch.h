@@ -9,8 +9,9 @@
 namespace hwy {
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds);
-bool has_rollout_kernel(const StepParams &p, bool force_block_kernel);
-hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds);
+// p.k_steps policy steps per launch (hwy_rollout_device): one-wavefront kernel (waves_per_eu, extra_lds) or workgroup kernel
+hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds,
+                          bool force_block_kernel, int block_waves_per_eu);
 // workgroups of the step kernel the device holds at once (0 = unknown / not applicable)
 int step_resident_blocks(const StepParams &p, int waves_per_eu, bool force_block_kernel, int extra_lds);
 int net_step_resident_blocks(int waves_per_eu);

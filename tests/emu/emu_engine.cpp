@@ -149,7 +149,9 @@ void dispatch(Which which, const StepParams &p, int E) {
   }
 #define RUN(NW)                                                                                         \
   switch (which) {                                                                                      \
-    case STEP: emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW, 1>(q); }, E, NW * 64, p); break;     \
+    case STEP: if (g_k_steps > 0) { StepParams pk = p; pk.k_steps = g_k_steps; pk.num_envs = E;                \
+                 emu::launch([](const StepParams &q) { hwy::hwy_rollout_kernel<NW, 1>(q); }, E, NW * 64, pk); } \
+               else emu::launch([](const StepParams &q) { hwy::hwy_step_kernel<NW, 1>(q); }, E, NW * 64, p); break;     \
     case RESET: emu::launch([](const StepParams &q) { hwy::hwy_reset_kernel<NW>(q); }, E, NW * 64, p); break;   \
     case OBSERVE: emu::launch([](const StepParams &q) { hwy::hwy_observe_kernel<NW>(q); }, E, NW * 64, p); break; \
   }
@@ -169,8 +171,7 @@ size_t emu_config_size(void) { return sizeof(hwy_config); }
 // k > 0: emu_run(mode 1) on the one-wavefront kernel runs k policy steps in one launch; the action / output arrays hold k blocks
 void emu_set_rollout(int k) { g_k_steps = k; }
 int emu_has_rollout_kernel(const hwy_config *cfg) {
-  if (cfg->scenario == HWY_SCENARIO_MERGE || cfg->scenario == HWY_SCENARIO_MERGE_GENERIC) return 1;
-  return cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !g_force_block && !cfg->tune_block_kernel;
+  return cfg->scenario != HWY_SCENARIO_INTERSECTION;
 }
 
 // mode: 0 = frames only (hwy_step_frames), 1 = full policy step (hwy_step), 2 = observe only

@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tools", "ablate", "_build", "asm_base")
+OUT = os.path.join("/tmp", "hwy_asm_base")  # (150 MB of compiler temporaries: kept out of the tree that gpurun ships)
 KERNEL = "_ZN3hwy20hwy_step_wave_kernelILi3ELb0EEEvNS_10StepParamsE"
 
 

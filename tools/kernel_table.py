@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "tools", "ablate", "_build", "asm_base")
+OUT = os.path.join("/tmp", "hwy_asm_base")  # (150 MB of compiler temporaries: kept out of the tree that gpurun ships)
 ASM = os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 if "--fresh" in sys.argv or not os.path.exists(ASM):
     os.makedirs(OUT, exist_ok=True)
