@@ -615,9 +615,6 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
   if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated)
     return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: actions/obs/reward/terminated/truncated must be non-NULL");
   HWY_HIP(eng, hipSetDevice(eng->device));
-  size_t n_act, n_obs, n_ea;
-  io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
-  const size_t E = eng->cfg.num_envs;
   StepParams p;
   fill_params(eng, p);
   p.n_frames = eng->cfg.frames_per_step;
@@ -639,15 +636,13 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
     HWY_HIP(eng, hwy::launch_net_rollout(np, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
     return HWY_OK;
   }
-  // the intersection kernel (its next-episode pre-warming blocks are ordered by launches): k launches back to back on the
-  // engine's stream, block k of every plane
-  for (int32_t k = 0; k < k_steps; ++k) {
-    p.actions = d_actions + (size_t)k * n_act; p.obs = d_obs + (size_t)k * n_obs; p.reward = d_reward + (size_t)k * n_ea;
-    p.terminated = d_terminated + (size_t)k * E; p.truncated = d_truncated + (size_t)k * E;
-    p.info_speed = d_info_speed ? d_info_speed + (size_t)k * n_ea : nullptr;
-    p.info_crashed = d_info_crashed ? d_info_crashed + (size_t)k * n_ea : nullptr;
-    HWY_HIP(eng, launch_step_any(eng, p));
-  }
+  // the intersection kernel: STEP blocks only (no shadow is advanced during the launch; an environment that ends in it warms its
+  // next episode up inline -- WHEN the warm-up frames are computed cannot change a result)
+  p.k_steps = k_steps;
+  p.num_envs = eng->cfg.num_envs;
+  hwy::IxParams ip;
+  fill_ix(eng, p, ip);
+  HWY_HIP(eng, hwy::launch_ix_rollout(ip, eng->cfg.num_envs, eng->stream, eng->waves_per_eu));
   return HWY_OK;
 }
 

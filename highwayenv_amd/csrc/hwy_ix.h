@@ -869,7 +869,7 @@ __device__ inline void ix_ws_store(int32_t *q, int32_t v, bool lds) { if (lds) *
 __device__ inline int32_t ix_ws_load(int32_t *q, bool lds) { return lds ? *q : grid_ws_load(q); }
 
 template <typename SH>
-__device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a, const IxVeh &me, bool present, int ia) {
+__device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a, const IxVeh &me, bool present, int ia, int eo) {
   const StepParams &p = ip.s;
   const int i = threadIdx.x, NT = (int)blockDim.x;
   const int W = p.gW, H = p.gH, WH = W * H, F = p.F;
@@ -886,7 +886,7 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
   int32_t *own = lds ? lds_ws : p.grid_ws + ((size_t)e * p.A + a) * 2 * (size_t)WH, *road = own + WH;
   int32_t *w_off = lds_ws + 2 * WH, *w_j0 = w_off + HWY_MAX_GLANES;
   unsigned char *w_lane = reinterpret_cast<unsigned char *>(w_j0 + HWY_MAX_GLANES);
-  float *out = p.obs + ((size_t)e * p.A + a) * (size_t)F * WH;
+  float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)F * WH;  // eo: output row (hwy_wave.h: observe_wave)
   __syncthreads();
   for (int t = i; t < WH; t += NT) {
     ix_ws_store(own + t, 0x7fffffff, lds);
@@ -996,7 +996,8 @@ __device__ inline void ix_observe_grid(const IxParams &ip, SH &sh, int e, int a,
 
 // ---- KinematicObservation (observation.py:234-276, road.py:421-450) + IntersectionEnv reward / termination -----------
 template <typename SH>
-__device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh &me, bool write_reward) {
+__device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh &me, bool write_reward, int eo = -1) {
+  eo = eo < 0 ? e : eo;  // row of the output planes (== e except in a multi-step launch, hwy_rollout_device)
   const StepParams &p = ip.s;
   const int i = threadIdx.x;
   const bool present = !(me.flags & HWY_F_ABSENT);
@@ -1038,7 +1039,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
   int a = 0;
   for (u64 am = egos; am && a < p.A; am &= am - 1, ++a) {
     const int ia = ctz64(am);
-    if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, a, me, present, ia);
+    if (p.obs && p.obs_type == HWY_OBS_OCCUPANCY_GRID) ix_observe_grid(ip, sh, e, a, me, present, ia, eo);
     if (!(p.obs && p.obs_type == HWY_OBS_KINEMATICS)) continue;
     const double ex = wave_bcast(me.x, ia), ey = wave_bcast(me.y, ia), ev = wave_bcast(me.v, ia);
     const double ech = wave_bcast(me.ch, ia), esh = wave_bcast(me.sh, ia);  // (cross-lane reads stay in uniform control flow)
@@ -1059,7 +1060,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
       const double kk = wave_bcast(key, k);
       pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
     }
-    float *out = p.obs + ((size_t)e * p.A + a) * (size_t)(V * F);
+    float *out = p.obs + ((size_t)eo * p.A + a) * (size_t)(V * F);
     const int row = (i == ia) ? 0 : (elig && pos < V - 1 ? pos + 1 : -1);
     if (present && row >= 0) {
       const double ch = me.ch, shh = me.sh;
@@ -1117,7 +1118,7 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
     reward = arrived ? ip.arrived_reward : reward;
     reward *= (on_road ? 1.0 : 0.0);
     if (p.flags & HWY_C_NORMALIZE_REWARD) reward = lmap(reward, p.collision_reward, ip.arrived_reward, 0.0, 1.0);
-    const size_t o = (size_t)e * p.A + agent;
+    const size_t o = (size_t)eo * p.A + agent;
     p.reward[o] = reward;
     if (p.info_speed) p.info_speed[o] = me.v;
     // bit 0: vehicle.crashed; bit 1: has_arrived(vehicle) -- agents_terminated is either (:119-121)
@@ -1127,8 +1128,8 @@ __device__ inline void ix_observe(const IxParams &ip, SH &sh, int e, const IxVeh
       const double t = p.st.time[e] + p.policy_dt;
       const bool trunc = t >= p.duration;
       p.st.time[e] = t;
-      p.terminated[e] = term ? 1 : 0;
-      p.truncated[e] = trunc ? 1 : 0;
+      p.terminated[eo] = term ? 1 : 0;
+      p.truncated[eo] = trunc ? 1 : 0;
       if (p.autoreset) p.st.done[e] = (term || trunc) ? 1 : 0;
     }
   }
@@ -1331,6 +1332,12 @@ __device__ inline void ix_spawn_finalise(const IxParams &ip, SH &sh, uint64_t se
     }
   }
 }
+#ifndef HWY_RELOAD_IX_PARAMS
+#define HWY_RELOAD_IX_PARAMS(q, ip)                              \
+  auto kernarg_ = __builtin_amdgcn_kernarg_segment_ptr();        \
+  asm volatile("" : "+s"(kernarg_));                           \
+  const IxParams &q = *(const IxParams *)kernarg_
+#endif
 template <typename SH>
 __device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t seed, uint32_t episode, IxVeh &me,
                                     int &road_steps) {
@@ -1349,13 +1356,16 @@ __device__ inline void ix_spawn_env(const IxParams &ip, SH &sh, int e, uint64_t 
 // Every role runs the SAME three stages -- set up the vehicle planes, run n frames, finish -- so that the frame loop, the
 // spawn rules and the observation are instantiated ONCE in the kernel: inlined per role they made 250 KB of code, four
 // times the instruction cache a pair of CUs shares.
-template <int WPE, int CAP, int NT = CAP>
-__global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip) {
+// One block's work of one launch step: block index `bx` < num_envs steps (or re-spawns) environment bx, bx >= num_envs advances
+// the shadow of environment bx - num_envs.  eo = row of the action / output planes (hwy_wave.h: observe_wave).
+template <int CAP, int NT>
+__device__ __forceinline__ void ix_policy_block(const IxParams &ip, IxSharedT<CAP, NT> &sh, const int bx, const int eo_step,
+                                                const bool load_table = true) {
   const StepParams &p = ip.s;
-  __shared__ IxSharedT<CAP, NT> sh;
   const int i = threadIdx.x;
-  const bool shadow_block = (int)blockIdx.x >= ip.num_envs;  // wave-uniform, like everything that selects a role below
-  const int e = shadow_block ? (int)blockIdx.x - ip.num_envs : (int)blockIdx.x;
+  const bool shadow_block = bx >= ip.num_envs;  // wave-uniform, like everything that selects a role below
+  const int e = shadow_block ? bx - ip.num_envs : bx;
+  const int eo = shadow_block ? e : eo_step;
   const int total = 3 * (int)rint(1 / p.dt);  // frames of the simulated seconds of _make_vehicles
   const bool resetting = p.autoreset && p.st.done[e];
   const int32_t *m = ip.shadow_meta ? ip.shadow_meta + 4 * e : nullptr;  // {episode, progress, RegulatedRoad.steps, -}
@@ -1367,7 +1377,7 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
     if (!p.autoreset || resetting) return;
     if (shadow_mine && m[1] > total) return;
   }
-  ix_load_table(ip, sh);
+  if (load_table) ix_load_table(ip, sh);  // (block-uniform; a multi-step launch loads it once)
   const uint64_t seed = p.rp.base_seed + (uint64_t)e;
 
   // ---- stage 1: whose planes, how many frames, what comes after them -------------------------------------------------
@@ -1379,7 +1389,7 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
   uint32_t step_no = 0;
   if (role == STEP) {
     n_run = p.n_frames;
-    actions = p.actions;
+    actions = p.actions ? p.actions + (size_t)(eo - e) * p.A : nullptr;  // (ix_frames indexes [e][agent])
     road_steps = ip.road_steps[e];
     step_no = (uint32_t)rint(p.st.time[e] / p.policy_dt);  // read before anybody advances the clock
   } else {
@@ -1417,26 +1427,48 @@ __global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip)
   }
   if (role == RESPAWN || p.full_step) {
     __syncthreads();
-    ix_observe(ip, sh, e, me, role == STEP);
+    ix_observe(ip, sh, e, me, role == STEP, eo);
   }
   if (role == STEP && p.full_step && !ip.host_spawn) ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);
   ix_store_vehicle(ip, e, me, false, role == RESPAWN);  // (a re-spawn moves the episode from the shadow planes to these)
   if (role == RESPAWN) {  // the step after terminated | truncated re-spawned the environment
     __threadfence();  // the shadow has been read before `done` is cleared (the pre-warming block starts over once it sees that)
     if (i < p.A) {
-      p.reward[(size_t)e * p.A + i] = 0.0;
-      if (p.info_speed) p.info_speed[(size_t)e * p.A + i] = sh.lim[ip.access_lane[i & 3]];
-      if (p.info_crashed) p.info_crashed[(size_t)e * p.A + i] = 0;
+      p.reward[(size_t)eo * p.A + i] = 0.0;
+      if (p.info_speed) p.info_speed[(size_t)eo * p.A + i] = sh.lim[ip.access_lane[i & 3]];
+      if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + i] = 0;
     }
     if (i == 0) {
       p.st.time[e] = 0.0;
       p.st.done[e] = 0;
       p.st.episode[e] = next_episode;
-      p.terminated[e] = 0;
-      p.truncated[e] = 0;
+      p.terminated[eo] = 0;
+      p.truncated[eo] = 0;
     }
   }
   if (i == 0) ip.road_steps[e] = road_steps;
+}
+
+template <int WPE, int CAP, int NT = CAP>
+__global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel(const IxParams ip) {
+  __shared__ IxSharedT<CAP, NT> sh;
+  ix_policy_block<CAP, NT>(ip, sh, (int)blockIdx.x, (int)blockIdx.x);
+}
+
+// hwy_rollout_device on the intersection kernel: ip.s.k_steps policy steps per wavefront in one launch (hwy_wave.h:
+// hwy_rollout_wave_kernel has the argument).  The grid holds the STEP blocks only: no block advances a shadow during the launch, so
+// an environment that ends in it warms its next episode up inline (what it does whenever it ends before its shadow is ready) --
+// WHEN the warm-up frames are computed cannot change a result (tests/test_ix_device_traffic.py).
+template <int WPE, int CAP, int NT = CAP>
+__global__ void __launch_bounds__(NT, WPE) hwy_ix_rollout_kernel(const IxParams ip) {
+  __shared__ IxSharedT<CAP, NT> sh;
+  const int e = blockIdx.x;
+  for (int k = 0; k < ip.s.k_steps; ++k) {  // block-uniform
+    HWY_RELOAD_IX_PARAMS(ik, ip);  // a fresh, opaque view of the arguments per step: nothing stays live -- spilled -- across steps
+    ix_policy_block<CAP, NT>(ik, sh, e, k * ik.num_envs + e, k == 0);
+    __syncthreads();
+    __threadfence_block();
+  }
 }
 
 // Reset kernel: AbstractEnv.reset for the masked environments + first observation.

@@ -173,6 +173,20 @@ static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t str
   else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
   else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(grid), dim3(64), 0, stream, ip);  // 24 KB of LDS: 2 waves/SIMD
 }
+template <int WPE>
+static void launch_ix_rollout_wpe(const IxParams &ip, int num_envs, hipStream_t stream) {
+  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_rollout_kernel<WPE, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_rollout_kernel<WPE, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else hipLaunchKernelGGL((hwy_ix_rollout_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+}
+// ip.s.k_steps policy steps per launch (hwy_rollout_device); STEP blocks only
+hipError_t launch_ix_rollout(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
+  switch (waves_per_eu) {
+    case 3: case 4: launch_ix_rollout_wpe<3>(ip, num_envs, stream); break;
+    default: launch_ix_rollout_wpe<2>(ip, num_envs, stream); break;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
   switch (waves_per_eu) {
     case 3: case 4: launch_ix_step_wpe<3>(ip, num_envs, stream); break;  // (158 VGPRs: 3 waves/SIMD is the most that fits)

@@ -25,6 +25,7 @@ hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t strea
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream);
 // intersection scenario (hwy_ix.h): one wavefront per environment
 hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu);
+hipError_t launch_ix_rollout(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu);  // ip.s.k_steps steps per launch
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream);
 hipError_t launch_ix_observe(const IxParams &ip, int num_envs, hipStream_t stream);
 }  // namespace hwy

@@ -363,10 +363,10 @@ int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward
  *   d_actions int32 [K][E][A], d_obs f32 [K][E][A][V][F], d_reward f64 [K][E][A], d_terminated / d_truncated u8 [K][E],
  *   d_info_speed f64 [K][E][A], d_info_crashed u8 [K][E][A] (the last two may be NULL).
  * Results are those of k_steps calls of hwy_step_device, bit for bit (auto-reset included: an environment that ends in step k
- * is re-spawned in step k + 1 when hwy_set_autoreset is on).  On the one-wavefront kernel (N <= 64 vehicles, straight road) the
- * k steps run in ONE launch -- the dispatch and, above all, the wait for the slowest SIMD at the end of every step are paid
- * once per call; the other kernels run k launches back to back.  Enqueues on the engine's stream, does not synchronise, does
- * not validate action ids (see hwy_step_device).
+ * is re-spawned in step k + 1 when hwy_set_autoreset is on).  The k steps run in ONE launch of the scenario's multi-step kernel:
+ * the dispatch and, above all, the wait for the slowest SIMD at the end of every step are paid once per call.  (Intersection: the
+ * launch holds no pre-warming blocks, an environment that ends in it prepares its next episode inline -- same results.)  Enqueues
+ * on the engine's stream, does not synchronise, does not validate action ids (see hwy_step_device).
  */
 int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_t *d_actions, float *d_obs, double *d_reward,
                        uint8_t *d_terminated, uint8_t *d_truncated, double *d_info_speed, uint8_t *d_info_crashed);

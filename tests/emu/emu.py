@@ -144,6 +144,7 @@ class EmuEngine:
         speed, crashed = np.zeros((K, E, A)), np.zeros((K, E, A), np.uint8)
         s = _abi.state_struct(self.st)
         ar = self.autoreset
+        self._bind_shadow()
         lib().emu_set_rollout(C.c_int(K))
         try:
             rc = lib().emu_run(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),

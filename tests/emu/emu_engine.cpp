@@ -89,6 +89,14 @@ void dispatch(Which which, const StepParams &p, int E) {
       ip.shadow_meta = g_shadow_meta;
       if (which == STEP && p.autoreset && p.full_step) grid = 2 * E;
     }
+    if (which == STEP && g_k_steps > 0) {  // hwy_rollout_device: k steps in one launch, STEP blocks only (same rule as hwy_kernels.hip)
+      ip.s.k_steps = g_k_steps;
+      ip.s.num_envs = E;
+      if (p.N <= 32 && ip.helpers) emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_rollout_kernel<1, 32, 64>(q); }, E, 64, ip);
+      else if (p.N <= 32) emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_rollout_kernel<1, 32>(q); }, E, 32, ip);
+      else emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_rollout_kernel<1, 64>(q); }, E, 64, ip);
+      return;
+    }
     if (p.N <= 32 && ip.helpers) {  // same dispatch rule as hwy_kernels.hip
       switch (which) {
         case STEP: emu::launch([](const hwy::IxParams &q) { hwy::hwy_ix_step_kernel<1, 32, 64>(q); }, grid, 64, ip); break;
@@ -171,7 +179,8 @@ size_t emu_config_size(void) { return sizeof(hwy_config); }
 // k > 0: emu_run(mode 1) on the one-wavefront kernel runs k policy steps in one launch; the action / output arrays hold k blocks
 void emu_set_rollout(int k) { g_k_steps = k; }
 int emu_has_rollout_kernel(const hwy_config *cfg) {
-  return cfg->scenario != HWY_SCENARIO_INTERSECTION;
+  (void)cfg;
+  return 1;  // every step kernel has a multi-step form
 }
 
 // mode: 0 = frames only (hwy_step_frames), 1 = full policy step (hwy_step), 2 = observe only

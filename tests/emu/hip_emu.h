@@ -25,6 +25,7 @@
 #define HWY_FMA_K(a, b, c) fma((a), (b), (c))
 #define HWY_RELOAD_PARAMS(q, p) const StepParams &q = p  // hwy_wave.h: re-read of the kernel-argument segment
 #define HWY_RELOAD_STEP_PARAMS(q, p) const StepParams &q = p  // hwy_device.h
+#define HWY_RELOAD_IX_PARAMS(q, ip) const IxParams &q = ip  // hwy_ix.h
 #define HWY_RELOAD_NET_PARAMS(q, np) const NetParams &q = np  // hwy_net.h: the same for the road-network kernels
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)

@@ -85,16 +85,20 @@ def test_k_steps_on_the_merge_kernel(backend):
     _compare(backend, cfg, st, K, 5, {})
 
 
-@pytest.mark.gpu
-def test_k_steps_on_the_intersection_kernel():
-    """Device traffic (clear / spawn / re-spawn on Philox inside the launches): K launches back to back."""
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("slots,grid", [(30, True), (40, False)])  # helper-lane build (N <= 32) and the 64-slot build
+def test_k_steps_on_the_intersection_kernel(backend, slots, grid):
+    """Device traffic (clear / spawn / re-spawn on Philox inside the launch).  The multi-step launch holds the STEP blocks only: an
+    environment that ends in it warms its next episode up inline, where one launch per step pre-warms it in shadow blocks -- WHEN the
+    warm-up frames are computed must not change a result."""
     from highwayenv_amd import intersection as hix
-    from highwayenv_amd.engine import Engine
     cfg_d = hix.intersection_default_config()
-    cfg_d.update({"max_vehicles": 30, "observation": {"type": "OccupancyGrid"}})
-    E, K = 64, 10
+    cfg_d.update({"max_vehicles": slots, "duration": 5})
+    if grid:
+        cfg_d["observation"] = {"type": "OccupancyGrid"}
+    E, K = (3, 7) if backend == "emu" else (64, 14)
     cfg = _abi.make_config(cfg_d, E, scenario="intersection")
-    a, b = Engine(cfg), Engine(cfg)
+    a, b = make_engine(backend, cfg), make_engine(backend, cfg)
     acts = np.random.default_rng(2).integers(0, 3, size=(K, E, 1)).astype(np.int32)
     for eng in (a, b):
         eng.reset(base_seed=21)
