@@ -32,8 +32,10 @@ def build(force: bool = False) -> str:
     stale = not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        tmp = f"{_LIB}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
         subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
-                        "-o", _LIB, srcs[0]], check=True, capture_output=True)
+                        "-o", tmp, srcs[0]], check=True, capture_output=True)
+        os.replace(tmp, _LIB)
     return _LIB
 
 

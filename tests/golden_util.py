@@ -98,11 +98,16 @@ def _assert_impacts(got, want, rows, atol, what, signed=None):
 def mask_knife_edge_flags(got: dict, want: dict, flag_margin) -> None:
     """A wreck pushed back by its impact rests EXACTLY touching what it hit; from then on `intersecting` (utils.py:222-224: the
     partner's crashed flag -- in practice the never-pushed Obstacle's) hinges on a distance of ~0 (oracle.impact_margins.flag_margin
-    < KNIFE).  On those slots the crashed / has-impact BITS of `got` are taken from `want`; positions, speeds and |impact| stay
-    compared (a flipped decision moves nothing by more than the ~0 distance it hinges on)."""
+    < KNIFE).  On those slots the crashed / has-impact BITS of `got` are taken from `want`, and so is the PENDING IMPACT: a pair
+    found touching overwrites the slot's impact with its own ~0 translation (the last colliding pair wins, objects.py:104-112), a
+    pair found apart leaves the impact of an earlier, real collision in place -- either is the reference's answer for one of the
+    two roundings.  Positions and speeds stay compared (a flipped decision moves nothing by more than the ~0 distance it hinges
+    on before the impact is applied; the callers re-synchronise wrecked environments)."""
     edge = np.asarray(flag_margin) < KNIFE
     bits = _abi.F_CRASHED | _abi.F_HAS_IMPACT
     got["flags"][edge] = (got["flags"][edge] & ~bits) | (want["flags"][edge] & bits)
+    for k in ["impact_x", "impact_y"]:
+        got[k][edge] = want[k][edge]
 
 
 def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
