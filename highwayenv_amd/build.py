@@ -19,7 +19,11 @@ import glob
 # plus the public ABI header -- globbed so that a new kernel header can never be forgotten by is_stale()
 HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"))) + [
     os.path.join("..", "..", "include", "hwy_engine.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# -disable-machine-licm: MachineLICM hoists the materialisation of every f64 literal (two v_mov_b32 each) and of most LDS
+# offsets out of the frame loop, where they sit in ~50 VGPRs for the whole loop (tools/vgpr_pressure.py).  Without it the
+# road-network kernel fits 128 VGPRs with NO spills (181 natural / 64 spilled before), the one-wavefront kernel 102 (118),
+# the intersection kernel 150 (203); every workload measured 0.3 .. 3 % faster (profiles/r03_history.md).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm"]
 
 
 def _hipcc() -> str:

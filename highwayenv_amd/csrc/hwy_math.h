@@ -172,12 +172,12 @@ __device__ inline double atan_fd(double x) {
   const double lo = r0 ? 0.0 : r1 ? 2.26987774529616870924e-17 : r2 ? 3.06161699786838301793e-17
                   : r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
   const double z = t * t, w = z * z;
-  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
-                                                 6.66107313738753120669e-02), 9.09088713343650656196e-02),
-                                  1.42857142725034663711e-01), 3.33333333333329318027e-01);
-  const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
-                                          -7.69187620504482999495e-02), -1.11111104054623557880e-01),
-                            -1.99999999998764832476e-01);
+  constexpr double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+               aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+               aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+               aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+  const double s1 = z * HWY_FMA_K(w, HWY_FMA_K(w, HWY_FMA_K(w, HWY_FMA_K(w, fma(w, HWY_KC(aT10), HWY_KC(aT8)), aT6), aT4), aT2), aT0);
+  const double s2 = w * HWY_FMA_K(w, HWY_FMA_K(w, HWY_FMA_K(w, fma(w, HWY_KC(aT9), HWY_KC(aT7)), aT5), aT3), aT1);
   const double r = r0 ? t - t * (s1 + s2) : hi - ((t * (s1 + s2) - lo) - t);
   return x < 0 ? -r : r;
 }

@@ -17,6 +17,9 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from highwayenv_amd.build import HIPCC_FLAGS  # noqa: E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "highwayenv_amd", "csrc")
@@ -264,6 +267,9 @@ FLAG_VARIANTS = {
     "f_o2": ["-O2"],
     "f_sgprfirst": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=true"],
     "f_licm": ["-mllvm", "-disable-licm-promotion"],
+    "f_mlicm": [],   # WITH MachineLICM (the build flags of highwayenv_amd/build.py minus -disable-machine-licm)
+    "f_sink": ["-mllvm", "-sink-insts-to-avoid-spills"],
+    "f_nopostlicm": ["-mllvm", "-disable-postra-machine-licm"],
 }
 
 
@@ -280,7 +286,7 @@ def build(name):
         open(os.path.join(d, f), "w").write(text.replace('#include "../../include/hwy_engine.h"',
                                                          f'#include "{ROOT}/include/hwy_engine.h"'))
     lib = os.path.join(OUT, f"libhwy_engine_{name}.so")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"] + FLAG_VARIANTS.get(name, [])
+    flags = (HIPCC_FLAGS[:-2] if name == "f_mlicm" else HIPCC_FLAGS) + FLAG_VARIANTS.get(name, [])
     r = subprocess.run(["hipcc", *flags, "-shared", "-o", lib, os.path.join(d, "hwy_kernels.hip"),
                         os.path.join(d, "hwy_engine.hip"), os.path.join(d, "hwy_comm.hip"), "-ldl"], capture_output=True, text=True)
     shutil.rmtree(d)

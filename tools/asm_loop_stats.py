@@ -13,6 +13,9 @@ import re
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from highwayenv_amd.build import HIPCC_FLAGS  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join("/tmp", "hwy_asm_base")  # (150 MB of compiler temporaries: kept out of the tree that gpurun ships)
 KERNEL = "_ZN3hwy20hwy_step_wave_kernelILi3ELb0EEEvNS_10StepParamsE"
@@ -20,7 +23,7 @@ KERNEL = "_ZN3hwy20hwy_step_wave_kernelILi3ELb0EEEvNS_10StepParamsE"
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+    subprocess.run(["hipcc", *HIPCC_FLAGS,
                     "-gline-tables-only", "-c", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip"),
                     "-o", os.path.join(OUT, "k.o"), "-save-temps=obj"], check=True, capture_output=True)
     s = open(os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()

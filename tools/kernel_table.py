@@ -6,14 +6,17 @@ import re
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from highwayenv_amd.build import HIPCC_FLAGS  # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join("/tmp", "hwy_asm_base")  # (150 MB of compiler temporaries: kept out of the tree that gpurun ships)
 ASM = os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 if "--fresh" in sys.argv or not os.path.exists(ASM):
     os.makedirs(OUT, exist_ok=True)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-gline-tables-only",
+    subprocess.run(["hipcc", *HIPCC_FLAGS, "-gline-tables-only",
                     "-c", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip"), "-o", os.path.join(OUT, "k.o"),
-                    "-save-temps=obj"], check=True, capture_output=True, cwd=OUT)
+                    "-save-temps=obj", *os.environ.get("HWY_EXTRA_FLAGS", "").split()], check=True, capture_output=True, cwd=OUT)
 s = open(ASM).read()
 meta = s[s.index("amdhsa.kernels:"):]
 print(f"{'kernel':58s} {'vgpr':>5s} {'spill':>5s} {'sgpr':>5s} {'s-spill':>7s} {'LDS B':>6s} {'priv B':>6s} {'scratch ops':>11s} {'waves/SIMD':>10s}")
