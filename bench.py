@@ -329,6 +329,11 @@ def main() -> None:
     ap.add_argument("--rollout-k", type=int, default=16,
                     help="also time hwy_rollout_device with this many policy steps per launch (reported as rollout_k<K> next to the "
                          "headline; 0 / 1 = skip)")
+    ap.add_argument("--split-batch", type=int, default=0,
+                    help="N=1 only: also time the batch as S independent sub-batches (one engine and one HIP stream each, stepped "
+                         "round-robin: the tail of one sub-batch's launch overlaps the body of the next one's), reported as "
+                         "`split_batch_sS` next to the headline.  Off by default: its launches carry the headline kernel's name, "
+                         "so they would mix into a rocprofv3 --stats average of the default command")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds, prio_shift, "
                          "ix_prewarm_frames: highwayenv_amd._abi.TUNING_KEYS); selects a kernel variant, never changes a result; repeatable")
@@ -530,6 +535,45 @@ def main() -> None:
                    "what": "hwy_rollout_device: K policy steps per launch with pre-staged actions, every step's outputs written; "
                            "bit-identical to K one-step launches (tests/test_rollout.py)"}
 
+    # The same batch as S independent sub-batches (S engines of E / S environments, one stream each, stepped round-robin with the
+    # same pre-staged device actions): what an actor that alternates between sub-batches sees.  Environments are independent,
+    # so sub-batch s of step k + 1 only waits for sub-batch s of step k -- the latency-bound tail of one launch (the slowest
+    # wavefronts of a launch run alone on their SIMDs) overlaps the next sub-batch.  Reported NEXT TO the headline.
+    split = None
+    S = args.split_batch
+    if world == 1 and S > 1 and E % S == 0:
+        Es = E // S
+        cfg_s = _abi.make_config(cfg_dict, Es, fast=fast, scenario=scenario, tuning=tuning)
+        sub_streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        subs = []
+        for k in range(S):
+            e_ = Engine(cfg_s, device=local_rank, stream=sub_streams[k].cuda_stream)
+            e_.reset(base_seed=1_000_003 * (k + 11), **spawn_kw)
+            e_.set_autoreset(True, base_seed=77_000_001 * (k + 11), **spawn_kw)
+            subs.append((e_, PackedStepOutputs(cfg_s, dev, 1, 0, force_collective=False, depth=1)))
+        n_s = min(args.steps, 400)
+
+        def sub_steps(t_lo, t_hi):
+            for t in range(t_lo, t_hi):
+                for k, (e_, o_) in enumerate(subs):
+                    e_.step_device(actions[t, k * Es:(k + 1) * Es].data_ptr(), *o_.pointers(0))
+        sub_steps(0, args.warmup)
+        torch.cuda.synchronize(dev)
+        reg = []
+        for r in range(R):
+            t0 = time.perf_counter()
+            sub_steps(args.warmup, args.warmup + n_s)
+            torch.cuda.synchronize(dev)
+            reg.append(time.perf_counter() - t0)
+        el = float(np.median(reg))
+        split = {"sub_batches": S, "envs_per_sub_batch": Es, "steps": n_s, "ms_per_step": el / n_s * 1e3, "value": n_s * E / el,
+                 "unit": "env-steps/s", "ms_per_step_repeats": [x / n_s * 1e3 for x in reg],
+                 "what": "S engines on S streams stepped round-robin (one launch per sub-batch and step, actions pre-staged on the "
+                         "device): every environment advances one policy step per step, sub-batches are not synchronised with "
+                         "each other"}
+        for e_, _ in subs:
+            e_.close()
+
     # PCIe-inclusive rate of the host-pointer entry point (hwy_step: H2D actions, kernel, D2H results, sync);
     # reported for DESIGN.md, never as `value`
     host_rate = None
@@ -594,6 +638,7 @@ def main() -> None:
                        "world_size_reported_by_the_process_group": dist.get_world_size() if use_dist else 1},
             "gather_every_1": per_step_gather,
             f"rollout_k{args.rollout_k}": rollout,
+            **({f"split_batch_s{args.split_batch}": split} if split else {}),
             "vehicle_steps_per_s": value * N,
             "vehicle_steps_per_s_excl_ego": value * (N - A),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
