@@ -23,7 +23,11 @@ HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"
 # offsets out of the frame loop, where they sit in ~50 VGPRs for the whole loop (tools/vgpr_pressure.py).  Without it the
 # road-network kernel fits 128 VGPRs with NO spills (181 natural / 64 spilled before), the one-wavefront kernel 102 (118),
 # the intersection kernel 150 (203); every workload measured 0.3 .. 3 % faster (profiles/r03_history.md).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm"]
+# -amdgpu-sched-strategy=iterative-ilp: with the registers the first flag frees, the ILP-first scheduler shortens the dependent
+# f64 chains the slowest wavefronts of a launch wait on (interleaved A/B on one box: headline 45.38 -> 44.90 us, merge config 5
+# 317.5 -> 313.5, highway-v0 135.9 -> 134.4; max-ilp / max-memory-clause / the occupancy bias: within +-0.5 %).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
+               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def _hipcc() -> str:

@@ -871,6 +871,55 @@ __global__ void __launch_bounds__(NW * 64) hwy_observe_kernel(const StepParams p
 // The fused policy-step kernel.
 // WPE = minimum waves per SIMD the register allocator must leave room for (occupancy knob).
 // One policy step of environment e by its workgroup; eo = row of the action / output planes (hwy_wave.h: observe_wave).
+// ---- taking turns at the SIMD's issue port ------------------------------------------------------------------------------
+// The hardware arbiter issues from the OLDEST ready wavefront first.  With exactly four environments per SIMD (4096 envs)
+// that lets the first wavefront run as if it were alone (latency-bound: ~30 % of the VALU issue slots), the next two fill
+// the gaps, the fourth gets the leftovers and then finishes ALONE at the same 30 %: measured end times of the four
+// wavefronts of a SIMD 24 / 31 / 37 / 43 us (tools/wave_timeline2.py).  Equal shares would end all four together, sooner.
+// So every wavefront sets its own priority (s_setprio, 0..3) to (hardware wave slot + clock >> shift) & 3: at any time the
+// four wavefronts of a SIMD hold four different priorities and the top one changes every 2^shift clock ticks.  The clock
+// is read with s_memtime one turn ahead (the value requested at the previous checkpoint is used), so no checkpoint waits
+// for it.  Scheduling only: no result depends on it.
+struct WaveTurn {
+  unsigned long long t;
+  int slot, shift;
+};
+__device__ inline void wave_turn_init(WaveTurn &w, int shift) {
+#ifdef HWY_HAVE_SETPRIO
+  w.shift = shift;
+  w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4 /* HW_REG_HW_ID, WAVE_ID bits 3:0 */) & 3) : 0;
+  w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+  (void)w; (void)shift;
+#endif
+}
+// Workgroup kernel (several wavefronts per environment, joined by barriers): all wavefronts of a workgroup must share one
+// priority, so the slot is the workgroup's slot on its CU (HW_ID.TG_ID) -- the wavefronts that meet on a SIMD belong to
+// different workgroups of the CU.
+__device__ inline void wave_turn_init_workgroup(WaveTurn &w, int shift) {
+#ifdef HWY_HAVE_SETPRIO
+  w.shift = shift;
+  w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4 /* HW_REG_HW_ID, TG_ID bits 19:16 */) & 3) : 0;
+  w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
+#else
+  (void)w; (void)shift;
+#endif
+}
+__device__ inline void wave_turn(WaveTurn &w) {
+#ifdef HWY_HAVE_SETPRIO
+  if (w.shift > 0) {  // wave-uniform (SGPR)
+    const int prio = (w.slot + (int)(w.t >> w.shift)) & 3;
+    w.t = __builtin_amdgcn_s_memtime();
+    if (prio == 0) __builtin_amdgcn_s_setprio(0);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  }
+#else
+  (void)w;
+#endif
+}
+
 template <int NW>
 __device__ __forceinline__ void block_policy_step(const StepParams &p, typename EnvBlock<NW>::Shared &sh, const int e, const int eo) {
   typedef EnvBlock<NW> B;
@@ -915,6 +964,9 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
     for (int a = 0; a < p.A; ++a)
       if (p.agent_index[a] == i) agent = a;
 
+  WaveTurn turn;
+  wave_turn_init_workgroup(turn, p.prio_shift);
+
   // static collision-check membership (index space)
   u64 chk[NW];
   int ph0 = 0, ph1 = 0, ph2 = 0;  // block_ballot phases of the three slot pairs
@@ -928,6 +980,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
   const bool all_check = n_chk == N;  // highway-v0: full pairwise; highway-fast-v0: ego only
 
   for (int fr = 0; fr < p.n_frames; ++fr) {
+    wave_turn(turn);
     // ---- A. action_type.act (abstract.py:294-304) -> MDPVehicle.act(label) (controller.py:295-315):
     //         target updates only; the controllers run below with Road.act (same state => same command)
     if (fr == 0 && p.actions && controlled) {
@@ -1001,6 +1054,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       __syncthreads();
     }
 
+    wave_turn(turn);
     // ---- D. Road.act: lane-change policy (behavior.py:219-263) ----------------------------------------
     const bool crashed0 = (me.flags & HWY_F_CRASHED) != 0;
     const bool drives = idm && !crashed0;  // IDMVehicle.act returns early when crashed (behavior.py:102-103)
@@ -1073,6 +1127,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       }
     }
 
+    wave_turn(turn);
     // ---- E. Road.act: low-level control (controller.py:89-133, behavior.py:104-137) ---------------------
     // tb = tan(beta) = 1/2 tan(steering) (see steer_tan_beta); acceleration command
     double tb = 0.0, accel = 0.0;
@@ -1124,6 +1179,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       sincos_bounded(me.h, &me.sh, &me.ch);
     }
 
+    wave_turn(turn);
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
     __syncthreads();  // all reads of the frame-start snapshot are done
     publish<NW>(sh, me, active);

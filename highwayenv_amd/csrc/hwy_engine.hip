@@ -30,7 +30,7 @@ struct hwy_engine {
   bool force_block_kernel = false;  // hwy_config.tune_block_kernel: use the generic workgroup kernel even for N <= 64
   int waves_per_eu = 3;  // register-allocation variant of the step kernel (hwy_config.tune_waves_per_eu)
   int rollout_waves_per_eu = 3;  // ... and of the multi-step kernel (hwy_rollout_device)
-  int prio_shift = 0;    // issue-priority turns of the one-wavefront kernels (hwy_config.tune_prio_shift; 0 = off)
+  int prio_shift = 0;    // issue-priority turns of the step kernels (hwy_config.tune_prio_shift; 0 = off)
   // device state
   double *d_f64 = nullptr;   // 9 fields x E x pitch
   int32_t *d_packed = nullptr;
@@ -273,32 +273,26 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
   eng->force_block_kernel = cfg->tune_block_kernel != 0;
-  // the road-network kernel gains more from a 4th resident wave per SIMD than it loses to the spills (measured)
-  // intersection kernel with helper lanes (N <= 32, hwy_ix.h): 208 VGPRs, 2 waves/SIMD is the faster build at every batch
-  // size measured (a 3rd wave costs 125 spilled registers).  Without them (N > 32, or tune_ix_no_helpers): 176 VGPRs fit 2
-  // waves/SIMD; a 3rd pays once the batch exceeds the 2048 wave slots of the 2-wave build (+8 % at 4096 environments)
+  // road-network kernel: 128 VGPRs, 4 waves/SIMD, no spills.
+  // intersection kernel with helper lanes (N <= 32, hwy_ix.h): 150 VGPRs, but 20.2 KB of LDS per one-wavefront workgroup keep it
+  // at 2 per SIMD.  Without them (N > 32, or tune_ix_no_helpers): 128 VGPRs / 16.7 KB (2048 x 30: 371.9 us against 285.1)
   if (cfg->scenario == HWY_SCENARIO_INTERSECTION) {
     const bool helpers = cfg->num_vehicles <= 32 && !cfg->tune_ix_no_helpers;
     eng->waves_per_eu = (cfg->num_envs > 2048 && !helpers) ? 3 : 2;
   }
   else if (cfg->scenario != HWY_SCENARIO_HIGHWAY) eng->waves_per_eu = 4;
-  else if (!(cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) && cfg->num_vehicles <= 64) {
-    // full-pairwise build of the one-wavefront kernel: 137 VGPRs (3 waves/SIMD, no spills) or 128 with 6 spilled (4 waves/
-    // SIMD).  A batch that fits 3 waves/SIMD runs the spill-free build; beyond that the 4th resident wave wins by far
-    // (highway-v0 x 4096 envs: 188 -> 154 us per step, with the priority turns the all-resident grid allows)
+  else {
+    // highway scenario.  One-wavefront kernels (N <= 64; 102 VGPRs ego-only, 128 full-pairwise: every allocation variant is the
+    // same code since the build stopped hoisting literals, build.py).  Workgroup kernel (N > 64, ceil(N / 64) wavefronts per
+    // environment): 146 .. 154 VGPRs at 3 waves/SIMD, 128 with 18 .. 30 spilled at 4 -- the 4-wave build pays as soon as the grid
+    // no longer fits 3 resident wavefronts per SIMD (1024 x 101: 159.2 / 164.4 us; 2048 x 101: 273.2 / 209.6 us)
     hipDeviceProp_t prop;
     const int simds = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * 4;
-    eng->waves_per_eu = cfg->num_envs > 3 * simds ? 4 : 3;
+    const long long waves = (long long)cfg->num_envs * ((cfg->num_vehicles + 63) / 64);
+    eng->waves_per_eu = waves > 3LL * simds ? 4 : 3;
   }
   if (cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4) eng->waves_per_eu = cfg->tune_waves_per_eu;
-  // the multi-step kernel keeps a few more registers across the steps (129 VGPRs against 118, ego-only build): beyond 3 resident
-  // wavefronts per SIMD the 4-wave allocation (2 spilled) is the one that holds the whole grid
   eng->rollout_waves_per_eu = eng->waves_per_eu;
-  if (cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !(cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4)) {
-    hipDeviceProp_t prop;
-    const int simds = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * 4;
-    if (cfg->num_envs > 3 * simds) eng->rollout_waves_per_eu = 4;
-  }
   auto bail = [&](hipError_t e, const char *what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
     hwy_destroy(eng);
@@ -389,7 +383,14 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     int resident = 0;
     if (cfg->scenario == HWY_SCENARIO_HIGHWAY) resident = hwy::step_resident_blocks(probe, eng->waves_per_eu, eng->force_block_kernel, cfg->tune_extra_lds);
     else if (cfg->scenario != HWY_SCENARIO_INTERSECTION) resident = hwy::net_step_resident_blocks(eng->waves_per_eu);
-    eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? HWY_DEFAULT_PRIO_SHIFT : 0;
+    // the turn that pays is about a sixth of a wavefront's lifetime, i.e. it grows with the frames of a policy step: 2^14 ticks
+    // for the 5 frames of highway-fast-v0 (13: 47.0 us, 14: 44.96, 15: 47.7), 2^16 for the 15 frames of highway-v0 (14: 134.3
+    // us, 15 / 16: 133.3) and of the merge scenarios (config 5: 14: 313.8, 16 / 17: 296.0, 18: 314.8; merge-v0: 14: 178.2,
+    // 15 / 16: 172.7, 17: 182.1) and of the workgroup kernel, whose wavefronts take turns by workgroup (config-3 shard 1024 x 101:
+    // off 161.1, 16: 159.4; 2048 x 101: 214.8 / 207.6) -- profiles/r03_history.md
+    int shift = HWY_DEFAULT_PRIO_SHIFT;
+    for (int f = 7; f <= cfg->frames_per_step && shift < 18; f *= 2) ++shift;  // +1 from 7 frames on, +2 from 14 on, ...
+    eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? shift : 0;
   }
   *out = eng;
   return HWY_OK;

@@ -111,8 +111,25 @@ static int resident_blocks(K kernel, int block, int dyn_lds) {
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
+template <int WPE>
+static int block_resident_wpe(int n) {
+  switch (waves_for(n)) {
+    case 1: return resident_blocks(hwy_step_kernel<1, WPE>, 64, 0);
+    case 2: return resident_blocks(hwy_step_kernel<2, WPE>, 128, 0);
+    case 3: return resident_blocks(hwy_step_kernel<3, WPE>, 192, 0);
+    case 4: return resident_blocks(hwy_step_kernel<4, WPE>, 256, 0);
+    default: return 0;
+  }
+}
 int step_resident_blocks(const StepParams &p, int waves_per_eu, bool force_block_kernel, int extra_lds) {
-  if (p.N > 64 || force_block_kernel) return 0;  // (the workgroup kernels keep the hardware order)
+  if (p.N > 64 || force_block_kernel) {  // workgroup kernel: turns by workgroup (hwy_device.h: wave_turn_init_workgroup)
+    switch (waves_per_eu) {
+      case 1: return block_resident_wpe<1>(p.N);
+      case 2: return block_resident_wpe<2>(p.N);
+      case 3: return block_resident_wpe<3>(p.N);
+      default: return block_resident_wpe<4>(p.N);
+    }
+  }
   const bool fast = (p.flags & HWY_C_EGO_ONLY_COLLISIONS) != 0;
   switch (waves_per_eu) {
     case 1: return fast ? resident_blocks(hwy_step_wave_kernel<1, false>, 64, extra_lds) : resident_blocks(hwy_step_wave_kernel<1, true>, 64, extra_lds);

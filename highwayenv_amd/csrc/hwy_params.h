@@ -7,7 +7,7 @@
 #include "hwy_device.h"
 
 #ifndef HWY_DEFAULT_PRIO_SHIFT
-#define HWY_DEFAULT_PRIO_SHIFT 14  // 16 k clock ticks (~7 us) per turn: measured best (profiles/r02_history.md); used only when the
+#define HWY_DEFAULT_PRIO_SHIFT 14  // 16 k clock ticks (~7 us) per turn at 5 frames per policy step (hwy_create scales it); used only when the
                                    // whole grid is resident at once -- otherwise the hardware's oldest-first order lets queued
                                    // workgroups start sooner (measured: highway-v0 at 3 waves/SIMD loses 10 % with turns)
 #endif

@@ -42,43 +42,6 @@ __device__ inline int wave_send_i(int v, int dst) { return __builtin_amdgcn_ds_p
   const StepParams &q = *(const StepParams *)kernarg_
 #endif
 
-// ---- taking turns at the SIMD's issue port ------------------------------------------------------------------------------
-// The hardware arbiter issues from the OLDEST ready wavefront first.  With exactly four environments per SIMD (4096 envs)
-// that lets the first wavefront run as if it were alone (latency-bound: ~30 % of the VALU issue slots), the next two fill
-// the gaps, the fourth gets the leftovers and then finishes ALONE at the same 30 %: measured end times of the four
-// wavefronts of a SIMD 24 / 31 / 37 / 43 us (tools/wave_timeline2.py).  Equal shares would end all four together, sooner.
-// So every wavefront sets its own priority (s_setprio, 0..3) to (hardware wave slot + clock >> shift) & 3: at any time the
-// four wavefronts of a SIMD hold four different priorities and the top one changes every 2^shift clock ticks.  The clock
-// is read with s_memtime one turn ahead (the value requested at the previous checkpoint is used), so no checkpoint waits
-// for it.  Scheduling only: no result depends on it.
-struct WaveTurn {
-  unsigned long long t;
-  int slot, shift;
-};
-__device__ inline void wave_turn_init(WaveTurn &w, int shift) {
-#ifdef HWY_HAVE_SETPRIO
-  w.shift = shift;
-  w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4 /* HW_REG_HW_ID, WAVE_ID bits 3:0 */) & 3) : 0;
-  w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
-#else
-  (void)w; (void)shift;
-#endif
-}
-__device__ inline void wave_turn(WaveTurn &w) {
-#ifdef HWY_HAVE_SETPRIO
-  if (w.shift > 0) {  // wave-uniform (SGPR)
-    const int prio = (w.slot + (int)(w.t >> w.shift)) & 3;
-    w.t = __builtin_amdgcn_s_memtime();
-    if (prio == 0) __builtin_amdgcn_s_setprio(0);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-  }
-#else
-  (void)w;
-#endif
-}
-
 // One wavefront == one workgroup: LDS instructions of a wavefront execute in order, so a ds_read issued after a ds_write
 // of the same wavefront sees it without any wait or s_barrier.  Only the COMPILER must keep the order (and the CPU
 // emulation of tests/emu, whose 64 threads are separate fibers, needs a real rendezvous).

@@ -269,6 +269,11 @@ FLAG_VARIANTS = {
     "f_licm": ["-mllvm", "-disable-licm-promotion"],
     "f_mlicm": [],   # WITH MachineLICM (the build flags of highwayenv_amd/build.py minus -disable-machine-licm)
     "f_sink": ["-mllvm", "-sink-insts-to-avoid-spills"],
+    "f_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "f_iterilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    "f_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "f_bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
+    "f_bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
     "f_nopostlicm": ["-mllvm", "-disable-postra-machine-licm"],
 }
 
@@ -286,7 +291,11 @@ def build(name):
         open(os.path.join(d, f), "w").write(text.replace('#include "../../include/hwy_engine.h"',
                                                          f'#include "{ROOT}/include/hwy_engine.h"'))
     lib = os.path.join(OUT, f"libhwy_engine_{name}.so")
-    flags = (HIPCC_FLAGS[:-2] if name == "f_mlicm" else HIPCC_FLAGS) + FLAG_VARIANTS.get(name, [])
+    flags = list(HIPCC_FLAGS)
+    if name == "f_mlicm":
+        k = flags.index("-disable-machine-licm")
+        del flags[k - 1:k + 1]  # ("-mllvm", "-disable-machine-licm")
+    flags = flags + FLAG_VARIANTS.get(name, [])  # (a later -amdgpu-sched-strategy= overrides the build's)
     r = subprocess.run(["hipcc", *flags, "-shared", "-o", lib, os.path.join(d, "hwy_kernels.hip"),
                         os.path.join(d, "hwy_engine.hip"), os.path.join(d, "hwy_comm.hip"), "-ldl"], capture_output=True, text=True)
     shutil.rmtree(d)
