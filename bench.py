@@ -553,10 +553,13 @@ def main() -> None:
             subs.append((e_, PackedStepOutputs(cfg_s, dev, 1, 0, force_collective=False, depth=1)))
         n_s = min(args.steps, 400)
 
+        a_base, a_step, a_sub = actions.data_ptr(), E * A * 4, Es * A * 4   # (raw pointers: the loop is launch-bound on the host)
+        sub_ptrs = [o_.pointers(0) for _, o_ in subs]
+
         def sub_steps(t_lo, t_hi):
             for t in range(t_lo, t_hi):
-                for k, (e_, o_) in enumerate(subs):
-                    e_.step_device(actions[t, k * Es:(k + 1) * Es].data_ptr(), *o_.pointers(0))
+                for k, (e_, _) in enumerate(subs):
+                    e_.step_device(a_base + t * a_step + k * a_sub, *sub_ptrs[k])
         sub_steps(0, args.warmup)
         torch.cuda.synchronize(dev)
         reg = []
