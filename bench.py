@@ -457,8 +457,8 @@ def main() -> None:
     for t in range(args.warmup):
         one_step(t)
     fence()
-    # HIP events on the launch stream around every 8th launch of the timed regions (an event pair costs ~8 us of
-    # stream time, 12 % of a launch: timing every launch would slow down the very loop being measured)
+    # HIP events on every 8th launch of the timed regions: the engine hands the pair to hipExtLaunchKernelGGL, which records the
+    # DISPATCH's own begin / end timestamps into them (the clock readings rocprofv3 --kernel-trace reports) on the launch stream
     eng.profile_enable(0 if os.environ.get("HWY_BENCH_NO_EVENTS") == "1" else EVENT_EVERY)
     region_s = []
     for r in range(R):
@@ -475,14 +475,6 @@ def main() -> None:
     elapsed = float(np.median(region_s))
     kernel_ms, launches = eng.profile_read()
     eng.profile_enable(0)
-    # what an event pair alone measures on this stream (no kernel in between): the sampled launches carry about this much
-    # on top of the kernel itself, which is why avg_kernel_us can exceed ms_per_step
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for a_, b_ in ev:
-        a_.record(stream)
-        b_.record(stream)
-    torch.cuda.synchronize(dev)
-    event_pair_us = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]) * 1e3)
     # N > 1: the same loop with ONE gather per step (what a policy that needs every step's outputs on rank 0 before it can
     # act would see), reported next to the batched number
     per_step_gather = None
@@ -596,11 +588,11 @@ def main() -> None:
         env_steps = args.steps * E * world
         value = env_steps / elapsed
         b_env = algorithmic_bytes_per_env_step(N, A, int(np.prod(_abi.obs_shape(cfg))))
-        # The dominant kernel's launch duration: HIP events on the launch stream around every 8th launch, MINUS what an empty
-        # event pair alone measures on that stream (~5 us), and never more than the wall-clock step that contains the launch
-        # (a kernel cannot take longer than its step).  Without events (HWY_BENCH_NO_EVENTS=1, a developer knob): the wall step.
+        # The dominant kernel's launch duration: the dispatch timestamps of every 8th launch (HIP events filled in by
+        # hipExtLaunchKernelGGL), never more than the wall-clock step that contains the launch (a kernel cannot take longer than its
+        # step).  Without events (HWY_BENCH_NO_EVENTS=1, a developer knob): the wall step.
         wall_step_s = elapsed / args.steps
-        event_kernel_s = (kernel_ms / 1e3 / launches - event_pair_us * 1e-6) if launches else None
+        event_kernel_s = (kernel_ms / 1e3 / launches) if launches else None
         avg_kernel_s = min(event_kernel_s, wall_step_s) if event_kernel_s and event_kernel_s > 0 else wall_step_s
         achieved = b_env * E / avg_kernel_s / 1e9
         line = {
@@ -650,11 +642,12 @@ def main() -> None:
                          "kernel_source_sha16": _kernel_build_id(),
                          "kernel": ("hwy_ix_step_kernel  (one 64-wide wavefront per env)" if scenario == "intersection" else
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
-                                    f"hwy_step_wave_kernel<3,{str(not fast).lower()}>  (one 64-wide wavefront per env)" if N <= 64 else
-                                    f"hwy_step_kernel<{(N + 63) // 64},3>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
-                         "avg_kernel_us_method": "min(HIP-event bracket - empty event pair, wall ms_per_step)",
-                         "event_bracket_us": (kernel_ms / launches * 1e3) if launches else None,
-                         "empty_event_pair_us": event_pair_us,
+                                    f"hwy_step_wave_kernel<WPE,{str(not fast).lower()}>  (one 64-wide wavefront per env; every WPE variant is the same "
+                                    "102 / 128-VGPR code)" if N <= 64 else
+                                    f"hwy_step_kernel<{(N + 63) // 64},WPE>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
+                         "avg_kernel_us_method": "min(mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's "
+                                                 "own timestamps, wall ms_per_step)",
+                         "event_kernel_us": (kernel_ms / launches * 1e3) if launches else None,
                          "algorithmic_bytes_per_launch": b_env * E,
                          "valu": valu_view(E, avg_kernel_s, args.workload)},
             "terminated_in_last_step": int(term),

@@ -556,9 +556,10 @@ static int timed_launch(hwy_engine *eng, const StepParams &p) {
     eng->events.emplace_back(a, b);
   }
   auto &pr = eng->events[eng->events_used++];
-  HWY_HIP(eng, hipEventRecord(pr.first, eng->stream));
-  HWY_HIP(eng, launch_step_any(eng, p));
-  HWY_HIP(eng, hipEventRecord(pr.second, eng->stream));
+  hwy::set_launch_events(pr.first, pr.second);  // the dispatch's own begin / end timestamps (hwy_kernels.hip)
+  const hipError_t err = launch_step_any(eng, p);
+  hwy::set_launch_events(nullptr, nullptr);
+  HWY_HIP(eng, err);
   return HWY_OK;
 }
 static int drain_events(hwy_engine *eng) {

@@ -2,6 +2,7 @@
 // observe kernels of hwy_device.h and exposes plain launch functions to the C-ABI host
 // (hwy_engine.hip).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #define HWY_HAVE_SETPRIO 1  // s_setprio / s_memtime / s_getreg exist on the device (not in the CPU emulation of tests/emu)
 #include "hwy_device.h"
@@ -12,14 +13,23 @@
 
 namespace hwy {
 
+// Kernel timing (hwy_profile_enable): every launch goes through hipExtLaunchKernelGGL, which records the DISPATCH's own begin and
+// end timestamps into the two events it is given -- the same clock readings rocprofv3 --kernel-trace reports, with no stream
+// overhead between them (events recorded around a launch with hipEventRecord also measure ~3 us of command processing).
+// Null events (the normal case): a plain launch.
+static thread_local hipEvent_t g_launch_start = nullptr, g_launch_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_launch_start = start; g_launch_stop = stop; }
+#define HWY_LAUNCH(KERNEL, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(KERNEL, grid, block, lds, stream, ::hwy::g_launch_start, ::hwy::g_launch_stop, 0, __VA_ARGS__)
+
 static inline int waves_for(int n_vehicles) { return (n_vehicles + 63) / 64; }
 
 #define HWY_DISPATCH(KERNEL)                                                                  \
   switch (waves_for(p.N)) {                                                                   \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(num_envs), dim3(64), 0, stream, p); break;     \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(num_envs), dim3(128), 0, stream, p); break;    \
-    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(num_envs), dim3(192), 0, stream, p); break;    \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(num_envs), dim3(256), 0, stream, p); break;    \
+    case 1: HWY_LAUNCH(KERNEL<1>, dim3(num_envs), dim3(64), 0, stream, p); break;     \
+    case 2: HWY_LAUNCH(KERNEL<2>, dim3(num_envs), dim3(128), 0, stream, p); break;    \
+    case 3: HWY_LAUNCH(KERNEL<3>, dim3(num_envs), dim3(192), 0, stream, p); break;    \
+    case 4: HWY_LAUNCH(KERNEL<4>, dim3(num_envs), dim3(256), 0, stream, p); break;    \
     default: return hipErrorInvalidValue;                                                     \
   }                                                                                           \
   return hipGetLastError();
@@ -27,10 +37,10 @@ static inline int waves_for(int n_vehicles) { return (n_vehicles + 63) / 64; }
 template <int WPE>
 static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
   switch (waves_for(p.N)) {
-    case 1: hipLaunchKernelGGL((hwy_step_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((hwy_step_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((hwy_step_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((hwy_step_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
+    case 1: HWY_LAUNCH((hwy_step_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 2: HWY_LAUNCH((hwy_step_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
+    case 3: HWY_LAUNCH((hwy_step_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
+    case 4: HWY_LAUNCH((hwy_step_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -38,10 +48,10 @@ static hipError_t launch_step_wpe(const StepParams &p, int num_envs, hipStream_t
 template <int WPE>
 static hipError_t launch_block_rollout_wpe(const StepParams &p, int num_envs, hipStream_t stream) {
   switch (waves_for(p.N)) {
-    case 1: hipLaunchKernelGGL((hwy_rollout_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((hwy_rollout_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((hwy_rollout_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((hwy_rollout_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
+    case 1: HWY_LAUNCH((hwy_rollout_kernel<1, WPE>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 2: HWY_LAUNCH((hwy_rollout_kernel<2, WPE>), dim3(num_envs), dim3(128), 0, stream, p); break;
+    case 3: HWY_LAUNCH((hwy_rollout_kernel<3, WPE>), dim3(num_envs), dim3(192), 0, stream, p); break;
+    case 4: HWY_LAUNCH((hwy_rollout_kernel<4, WPE>), dim3(num_envs), dim3(256), 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -51,17 +61,17 @@ static hipError_t launch_wave_wpe(const StepParams &p, int num_envs, hipStream_t
   // lds = hwy_config.tune_extra_lds: dynamic LDS reserved per workgroup, i.e. fewer resident wavefronts per SIMD, so that part
   // of the grid is dispatched as wavefronts retire (the hardware then balances unevenly loaded SIMDs)
   if (p.flags & HWY_C_EGO_ONLY_COLLISIONS)
-    hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
+    HWY_LAUNCH((hwy_step_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
   else
-    hipLaunchKernelGGL((hwy_step_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
+    HWY_LAUNCH((hwy_step_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
 template <int WPE>
 static hipError_t launch_rollout_wpe(const StepParams &p, int num_envs, hipStream_t stream, int lds) {
   if (p.flags & HWY_C_EGO_ONLY_COLLISIONS)
-    hipLaunchKernelGGL((hwy_rollout_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
+    HWY_LAUNCH((hwy_rollout_wave_kernel<WPE, false>), dim3(num_envs), dim3(64), lds, stream, p);
   else
-    hipLaunchKernelGGL((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
+    HWY_LAUNCH((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
 // hwy_rollout_device on the straight-road kernels: p.k_steps policy steps in one launch -- the one-wavefront kernel for N <= 64,
@@ -148,53 +158,53 @@ int net_step_resident_blocks(int waves_per_eu) {
 }
 hipError_t launch_net_rollout(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
   if (np.s.obs_type != HWY_OBS_KINEMATICS) {
-    hipLaunchKernelGGL((hwy_net_rollout_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
+    HWY_LAUNCH((hwy_net_rollout_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
     return hipGetLastError();
   }
   switch (waves_per_eu) {
-    case 1: hipLaunchKernelGGL((hwy_net_rollout_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    case 2: hipLaunchKernelGGL((hwy_net_rollout_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    case 3: hipLaunchKernelGGL((hwy_net_rollout_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    default: hipLaunchKernelGGL((hwy_net_rollout_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 1: HWY_LAUNCH((hwy_net_rollout_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 2: HWY_LAUNCH((hwy_net_rollout_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 3: HWY_LAUNCH((hwy_net_rollout_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    default: HWY_LAUNCH((hwy_net_rollout_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
   }
   return hipGetLastError();
 }
 hipError_t launch_net_step(const NetParams &np, int num_envs, hipStream_t stream, int waves_per_eu) {
   if (np.s.obs_type != HWY_OBS_KINEMATICS) {  // the OccupancyGrid build (its own instantiation: hwy_net.h, net_observe<GRID>)
-    hipLaunchKernelGGL((hwy_net_step_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
+    HWY_LAUNCH((hwy_net_step_kernel<3, true>), dim3(num_envs), dim3(64), 0, stream, np);
     return hipGetLastError();
   }
   switch (waves_per_eu) {
-    case 1: hipLaunchKernelGGL((hwy_net_step_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    case 2: hipLaunchKernelGGL((hwy_net_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    case 3: hipLaunchKernelGGL((hwy_net_step_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
-    default: hipLaunchKernelGGL((hwy_net_step_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 1: HWY_LAUNCH((hwy_net_step_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 2: HWY_LAUNCH((hwy_net_step_kernel<2>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    case 3: HWY_LAUNCH((hwy_net_step_kernel<3>), dim3(num_envs), dim3(64), 0, stream, np); break;
+    default: HWY_LAUNCH((hwy_net_step_kernel<4>), dim3(num_envs), dim3(64), 0, stream, np); break;
   }
   return hipGetLastError();
 }
 hipError_t launch_net_reset(const NetParams &np, int num_envs, hipStream_t stream) {
-  if (np.s.obs_type != HWY_OBS_KINEMATICS) hipLaunchKernelGGL((hwy_net_reset_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
-  else hipLaunchKernelGGL((hwy_net_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) HWY_LAUNCH((hwy_net_reset_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
+  else HWY_LAUNCH((hwy_net_reset_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
   return hipGetLastError();
 }
 hipError_t launch_net_observe(const NetParams &np, int num_envs, hipStream_t stream) {
-  if (np.s.obs_type != HWY_OBS_KINEMATICS) hipLaunchKernelGGL((hwy_net_observe_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
-  else hipLaunchKernelGGL((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
+  if (np.s.obs_type != HWY_OBS_KINEMATICS) HWY_LAUNCH((hwy_net_observe_kernel<1, true>), dim3(num_envs), dim3(64), 0, stream, np);
+  else HWY_LAUNCH((hwy_net_observe_kernel<1>), dim3(num_envs), dim3(64), 0, stream, np);
   return hipGetLastError();
 }
 template <int WPE>
 static void launch_ix_step_wpe(const IxParams &ip, int num_envs, hipStream_t stream) {
   // with next-episode pre-warming the grid holds a second block per environment (hwy_ix.h: ix_prewarm)
   const int grid = (ip.shadow_meta && ip.s.autoreset && ip.s.full_step) ? 2 * num_envs : num_envs;
-  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32, 64>), dim3(grid), dim3(64), 0, stream, ip);
-  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_step_kernel<2, 64>), dim3(grid), dim3(64), 0, stream, ip);  // 24 KB of LDS: 2 waves/SIMD
+  if (ip.s.N <= 32 && ip.helpers) HWY_LAUNCH((hwy_ix_step_kernel<WPE, 32, 64>), dim3(grid), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) HWY_LAUNCH((hwy_ix_step_kernel<WPE, 32>), dim3(grid), dim3(32), 0, stream, ip);
+  else HWY_LAUNCH((hwy_ix_step_kernel<2, 64>), dim3(grid), dim3(64), 0, stream, ip);  // 24 KB of LDS: 2 waves/SIMD
 }
 template <int WPE>
 static void launch_ix_rollout_wpe(const IxParams &ip, int num_envs, hipStream_t stream) {
-  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_rollout_kernel<WPE, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
-  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_rollout_kernel<WPE, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_rollout_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32 && ip.helpers) HWY_LAUNCH((hwy_ix_rollout_kernel<WPE, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) HWY_LAUNCH((hwy_ix_rollout_kernel<WPE, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else HWY_LAUNCH((hwy_ix_rollout_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
 }
 // ip.s.k_steps policy steps per launch (hwy_rollout_device); STEP blocks only
 hipError_t launch_ix_rollout(const IxParams &ip, int num_envs, hipStream_t stream, int waves_per_eu) {
@@ -212,14 +222,14 @@ hipError_t launch_ix_step(const IxParams &ip, int num_envs, hipStream_t stream, 
   return hipGetLastError();
 }
 hipError_t launch_ix_reset(const IxParams &ip, int num_envs, hipStream_t stream) {
-  if (ip.s.N <= 32 && ip.helpers) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
-  else if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_reset_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32 && ip.helpers) HWY_LAUNCH((hwy_ix_reset_kernel<2, 32, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  else if (ip.s.N <= 32) HWY_LAUNCH((hwy_ix_reset_kernel<2, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else HWY_LAUNCH((hwy_ix_reset_kernel<2, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 hipError_t launch_ix_observe(const IxParams &ip, int num_envs, hipStream_t stream) {
-  if (ip.s.N <= 32) hipLaunchKernelGGL((hwy_ix_observe_kernel<1, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
-  else hipLaunchKernelGGL((hwy_ix_observe_kernel<1, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
+  if (ip.s.N <= 32) HWY_LAUNCH((hwy_ix_observe_kernel<1, 32>), dim3(num_envs), dim3(32), 0, stream, ip);
+  else HWY_LAUNCH((hwy_ix_observe_kernel<1, 64>), dim3(num_envs), dim3(64), 0, stream, ip);
   return hipGetLastError();
 }
 __global__ void hwy_math_probe_kernel(int op, const double *in, double *out, long long n) {
@@ -227,7 +237,7 @@ __global__ void hwy_math_probe_kernel(int op, const double *in, double *out, lon
   if (k < n) out[k] = math_probe(op, in[k]);
 }
 hipError_t launch_math_probe(int op, const double *in, double *out, long long n, hipStream_t stream) {
-  hipLaunchKernelGGL(hwy_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, in, out, n);
+  HWY_LAUNCH(hwy_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, op, in, out, n);
   return hipGetLastError();
 }
 hipError_t launch_reset(const StepParams &p, int num_envs, hipStream_t stream) { HWY_DISPATCH(hwy_reset_kernel) }

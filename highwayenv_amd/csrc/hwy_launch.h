@@ -7,6 +7,8 @@
 #include "hwy_ix.h"
 
 namespace hwy {
+// the events the launches of THIS THREAD record their dispatch begin / end timestamps into (nullptr, nullptr = none)
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds);
 // p.k_steps policy steps per launch (hwy_rollout_device): one-wavefront kernel (waves_per_eu, extra_lds) or workgroup kernel

@@ -420,11 +420,12 @@ int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32_t reset);
 int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n);
 
 /*
- * Kernel timing with HIP events recorded on the engine's stream around the step kernel of
- * hwy_step / hwy_step_device / hwy_step_frames calls.  `enabled`: 0 = off, k > 0 = time every k-th
- * launch (an event pair costs ~8 us of stream time per launch on MI355X, so a sampled k keeps the
- * measurement from slowing down what it measures).  hwy_profile_read synchronises and returns the
- * accumulated kernel time and the number of TIMED launches since the last hwy_profile_enable(eng, k > 0).
+ * Kernel timing of the step kernel of hwy_step / hwy_step_device / hwy_step_frames calls with HIP events on the
+ * engine's stream: the launch (hipExtLaunchKernelGGL) records the DISPATCH's own begin and end timestamps into
+ * the pair, i.e. what rocprofv3 --kernel-trace reports for it (events recorded around the launch with
+ * hipEventRecord also measure ~3 us of command processing).  `enabled`: 0 = off, k > 0 = time every k-th
+ * launch.  hwy_profile_read synchronises and returns the accumulated kernel time and the number of TIMED
+ * launches since the last hwy_profile_enable(eng, k > 0).
  */
 int hwy_profile_enable(hwy_engine *eng, int32_t enabled);
 int hwy_profile_read(hwy_engine *eng, double *total_ms, int64_t *launches);

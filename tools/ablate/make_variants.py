@@ -141,19 +141,23 @@ def ix_ticks(text):
     t = sub("    // ---- F. collisions (road.py:477-481", "    IXTICK(5)\n    // ---- F. collisions (road.py:477-481")(t)
     t = sub("      if (present && crash) me.flags |= HWY_F_CRASHED;\n    }\n  }\n}",
             "      if (present && crash) me.flags |= HWY_F_CRASHED;\n    }\n  }\n  IXTICK(6)\n}")(t)
-    # the step kernel only (the first occurrence of each pattern after its head)
-    a = t.index("__global__ void __launch_bounds__(NT, WPE) hwy_ix_step_kernel")
+    # the shared step body (ix_policy_block): the first occurrence of each pattern after its head; every pattern must be found
+    a = t.index("__device__ __forceinline__ void ix_policy_block(")
     head, k = t[:a], t[a:]
-    k = sub("  ix_load_table(ip, sh);\n", "  ix_load_table(ip, sh);\n  if (i == 0) { for (int q = 0; q < 16; ++q) sh.tk[q] = 0; sh.tprev = clock64(); }\n")(k) if False else \
-        k.replace("  ix_load_table(ip, sh);\n", "  ix_load_table(ip, sh);\n  if (i == 0) { for (int q = 0; q < 16; ++q) sh.tk[q] = 0; sh.tprev = clock64(); }\n", 1)
-    k = k.replace("  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n",
-                  "  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n  IXTICK(9)\n", 1)
-    k = k.replace("    ix_observe(ip, sh, e, me, role == STEP);\n  }\n", "    ix_observe(ip, sh, e, me, role == STEP);\n  }\n  IXTICK(7)\n", 1)
-    k = k.replace("ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n", "ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n  IXTICK(8)\n", 1)
-    k = k.replace("  if (i == 0) ip.road_steps[e] = road_steps;\n}",
-                  "  if (i == 0) ip.road_steps[e] = road_steps;\n  IXTICK(10)\n"
-                  "  if (i == 0 && p.obs) { float *o = p.obs + (size_t)e * p.A * (p.obs_type == HWY_OBS_KINEMATICS ? p.V * p.F : p.F * p.gW * p.gH);\n"
-                  "    for (int q = 0; q < 14; ++q) o[q] = (float)sh.tk[q]; o[14] = (float)role; o[15] = (float)n_run; }\n}", 1)
+
+    def once(k, old, new):
+        if old not in k:
+            raise Stale(old)
+        return k.replace(old, new, 1)
+    k = once(k, "  if (load_table) ix_load_table(ip, sh);", "  if (load_table) ix_load_table(ip, sh);\n  if (i == 0) { for (int q = 0; q < 16; ++q) sh.tk[q] = 0; sh.tprev = clock64(); }\n  //")
+    k = once(k, "  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n",
+             "  if (finalise) ix_spawn_finalise(ip, sh, seed, next_episode, me);\n  IXTICK(9)\n")
+    k = once(k, "    ix_observe(ip, sh, e, me, role == STEP, eo);\n  }\n", "    ix_observe(ip, sh, e, me, role == STEP, eo);\n  }\n  IXTICK(7)\n")
+    k = once(k, "ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n", "ix_clear_spawn(ip, sh, me, seed, p.st.episode[e], step_no);\n  IXTICK(8)\n")
+    k = once(k, "  if (i == 0) ip.road_steps[e] = road_steps;\n}",
+             "  if (i == 0) ip.road_steps[e] = road_steps;\n  IXTICK(10)\n"
+             "  if (i == 0 && p.obs) { float *o = p.obs + (size_t)eo * p.A * (p.obs_type == HWY_OBS_KINEMATICS ? p.V * p.F : p.F * p.gW * p.gH);\n"
+             "    for (int q = 0; q < 14; ++q) o[q] = (float)sh.tk[q]; o[14] = (float)role; o[15] = (float)n_run; }\n}")
     return head + k
 
 

@@ -30,7 +30,7 @@ KERNEL_OF = {"fast": "hwy_step_wave_kernel", "merge_ma4": "hwy_net_step_kernel",
 out_notes = {}
 # bench lines
 for name in ("fast", "merge_ma4", "intersection", "v0", "cfg3", "intersection_kin", "merge", "fast_1024", "fast_2048", "fast_8192",
-             "fast_16384", "fast_forcedist"):
+             "fast_16384", "fast_forcedist", "fast_split2", "intersection_split2", "cfg3_2048"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         d = jl(p)
@@ -88,9 +88,10 @@ for name, wl in (("fast", "fast"), ("merge_ma4", "merge_ma4"), ("intersection", 
         sq_all[wl] = d
 if sq_all:  # one file, keyed by bench.py's --workload (bench.py: valu_view)
     json.dump(sq_all, open(os.path.join(DST, "r03_pmc_sq.json"), "w"), indent=1)
-sec = os.path.join(SRC, "sections_fast.txt")
-if os.path.exists(sec):
-    shutil.copy(sec, os.path.join(DST, "r03_section_clocks.txt"))
+for src_name, dst_name in (("sections_fast.txt", "r03_section_clocks.txt"), ("sections_merge_ma4.txt", "r03_section_clocks_merge_ma4.txt")):
+    sec = os.path.join(SRC, src_name)
+    if os.path.exists(sec):
+        open(os.path.join(DST, dst_name), "w").writelines(line for line in open(sec) if "amdgpu.ids" not in line)
 for t in ("timeline_default", "timeline_noturns"):
     p = os.path.join(SRC, t + ".txt")
     if os.path.exists(p):
