@@ -88,7 +88,8 @@ for name, wl in (("fast", "fast"), ("merge_ma4", "merge_ma4"), ("intersection", 
         sq_all[wl] = d
 if sq_all:  # one file, keyed by bench.py's --workload (bench.py: valu_view)
     json.dump(sq_all, open(os.path.join(DST, "r03_pmc_sq.json"), "w"), indent=1)
-for src_name, dst_name in (("sections_fast.txt", "r03_section_clocks.txt"), ("sections_merge_ma4.txt", "r03_section_clocks_merge_ma4.txt")):
+for src_name, dst_name in (("sections_fast.txt", "r03_section_clocks.txt"), ("sections_merge_ma4.txt", "r03_section_clocks_merge_ma4.txt"),
+                           ("sections_intersection.txt", "r03_section_clocks_intersection.txt")):
     sec = os.path.join(SRC, src_name)
     if os.path.exists(sec):
         open(os.path.join(DST, dst_name), "w").writelines(line for line in open(sec) if "amdgpu.ids" not in line)

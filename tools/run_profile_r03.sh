@@ -2,7 +2,7 @@
 # GPU box: everything behind profiles/r03_* in ONE call (tests, bench lines, rocprofv3 kernel stats, PMC traffic and SQ
 # counters, wave timeline, secondary workloads).  Raw output under gpurun_out/r03prof/; tools/collect_profile_r03.py
 # (build container) turns it into the committed summaries.  Build the instrumented variants first:
-#   python tools/ablate/make_variants.py wtimeline wticks nticks
+#   python tools/ablate/make_variants.py wtimeline wticks nticks ixticks
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/run_profile_r03.sh'
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r03prof; mkdir -p $O
 cd $R
@@ -53,6 +53,7 @@ timeout 200 python bench.py --no-cpu-baseline --repeats 3 --split-batch 2 > $O/b
 timeout 200 python bench.py --workload intersection --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 --split-batch 2 > $O/bench_intersection_split2.json 2>> $O/bench_misc.err
 timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_cfg3_2048.json 2>> $O/bench_misc.err
 HWY_ENGINE_LIB=tools/ablate/_build/libhwy_engine_nticks.so timeout 200 python tools/net_section_cycles.py merge_ma4 > $O/sections_merge_ma4.txt 2>&1
+HWY_ENGINE_LIB=tools/ablate/_build/libhwy_engine_ixticks.so timeout 200 python tools/ix_section_dist.py > $O/sections_intersection.txt 2>&1
 # keep the merged output small: only the stats / counter CSVs
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
