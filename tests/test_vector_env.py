@@ -47,6 +47,11 @@ def test_interface_and_next_step_autoreset_on_the_emulator():
         vector.HighwayVectorEnv(EmuBatchedFast, num_envs=2).step_wait()
 
 
+def test_stream_argument_needs_the_torch_front_end():
+    with pytest.raises(ValueError):
+        vector.HighwayVectorEnv("highway-fast-v0", num_envs=2, stream=object())
+
+
 def test_ids_resolve_to_the_batched_classes():
     assert envs.batched_class("highway-fast-v0") is envs.BatchedHighwayEnvFast
     assert envs.batched_class("highwayenv_amd/merge-v0") is envs.BatchedMergeEnv
@@ -125,6 +130,23 @@ def test_torch_outputs_alias_the_device_buffers_and_match_numpy():
         np.testing.assert_array_equal(tt.cpu().numpy(), tn)
         np.testing.assert_array_equal(trt.cpu().numpy(), trn)
         np.testing.assert_array_equal(inf_t["speed"].cpu().numpy(), inf_n["speed"])
+    # an environment ON a caller's stream (stream=): no cross-stream ordering while that stream is current -- same results
+    lane = torch.cuda.Stream()
+    n2 = vector.HighwayVectorEnv("highway-fast-v0", num_envs=16, config=cfg)
+    t2 = vector.HighwayVectorEnv("highway-fast-v0", num_envs=16, config=cfg, output="torch", stream=lane)
+    assert t2.stream is lane
+    n2.reset(seed=9)
+    t2.reset(seed=9)
+    with torch.cuda.stream(lane):
+        for k in range(4):
+            acts = rng.integers(0, 5, size=16)
+            on, rn, tn, _, _ = n2.step(acts)
+            ot, rt, tt, _, _ = t2.step(torch.as_tensor(acts, device="cuda", dtype=torch.int32))
+            np.testing.assert_array_equal(ot.cpu().numpy(), on)
+            np.testing.assert_array_equal(rt.cpu().numpy(), rn)
+            np.testing.assert_array_equal(tt.cpu().numpy(), tn)
+    n2.close()
+    t2.close()
     # K steps in one launch from the torch front end == K steps
     acts = rng.integers(0, 5, size=(5, 16))
     outs = [n.step(acts[k]) for k in range(5)]
