@@ -106,7 +106,7 @@ def test_packed_gather_world2_gloo(kind):
     procs = [ctx.Process(target=_worker, args=(r, world, port, E, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=600) for _ in range(world))  # (a cold `import torch` in a fresh container can take minutes)
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]

@@ -357,7 +357,7 @@ print("REGISTERED", len(reg.registry))
 '''
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "REGISTERED 22" in r.stdout
 
