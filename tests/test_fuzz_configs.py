@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 # HWY_FUZZ_BACKEND=emu replays a chunk on the CPU emulator of the kernel source (tests/emu): `pytest -m gpu` with that variable set
 # needs no GPU -- how a failing chunk of a large GPU run (HWY_FUZZ_CHUNKS) is taken apart
 BACKEND = os.environ.get("HWY_FUZZ_BACKEND", "hip")
+# HWY_FUZZ_CHUNKS chunks starting at HWY_FUZZ_FIRST (a chunk's seed is its number: large runs continue where the last one ended)
+CHUNKS = range(int(os.environ.get("HWY_FUZZ_FIRST", "0")), int(os.environ.get("HWY_FUZZ_FIRST", "0")) + int(os.environ.get("HWY_FUZZ_CHUNKS", "4")))
 
 # whole-step coverage of the intersection fuzz (printed per chunk): the rest are env-steps in which some car is below 1 m/s.
 # A per-chunk statistic over 6 random configurations: of 150 chunks on the GPU one fell to 38.8 %, the others stay above 40 %.
@@ -57,7 +59,7 @@ def random_config(rng):
     return cfg, fast
 
 
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))  # 10 configurations each
+@pytest.mark.parametrize("chunk", CHUNKS)  # 10 configurations each
 def test_random_configurations_vs_oracle(chunk):
     rng = np.random.default_rng(9000 + chunk)
     for k in range(10):
@@ -92,7 +94,7 @@ def random_merge_config(rng):
     return cfg
 
 
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))
+@pytest.mark.parametrize("chunk", CHUNKS)
 def test_random_merge_configurations_vs_oracle(chunk):
     from tests.test_net_parity import _rollout_vs_oracle
     rng = np.random.default_rng(7000 + chunk)
@@ -149,7 +151,7 @@ def _unmatched_rows(h, o, tol=1e-6, rows=False):
     return (h[miss], o[free]) if rows else len(miss)
 
 
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("HWY_FUZZ_CHUNKS", "4"))))
+@pytest.mark.parametrize("chunk", CHUNKS)
 def test_random_intersection_configurations_vs_oracle(chunk):
     """Device-traffic engine drives the episodes (reset, clear, spawn, auto-reset on Philox); every step is replayed from its
     own state on a host-traffic engine and on the oracle.  Two comparisons, and the fraction each covers is PRINTED and asserted:
