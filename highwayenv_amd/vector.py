@@ -85,7 +85,10 @@ class HighwayVectorEnv(_Base):
             # "create one"); every call orders it after the caller's current stream and the caller's stream after it.
             # ``stream=`` (a torch.cuda.Stream, not the default one): the engine runs ON that stream, and a step() issued while
             # it is the current stream needs no cross-stream ordering at all (two event record / wait pairs less per step).
-            self._stream = stream if stream is not None else torch.cuda.Stream(device=device)
+            if stream is None:  # built under `with torch.cuda.stream(s)`: that stream; under the default stream: a new one
+                cur = torch.cuda.current_stream(device)
+                stream = cur if cur.cuda_stream else torch.cuda.Stream(device=device)
+            self._stream = stream
             stream = self._stream.cuda_stream
             if not stream:
                 raise ValueError("stream= must be a real torch.cuda.Stream (the default stream's handle is NULL)")
