@@ -28,7 +28,9 @@ def rollout(backend, cfg_d, fast, E, steps, seed, mutate=None, actions=None, com
         wreck = ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0).any(1)
         # the step of an env's first collision is compared like any other (terminal observation, reward, positions) unless a
         # push direction sits on the knife edge (|d.normal| < 1e-9, utils.py:232-236); assert_state_close compares |impact|
-        ok = live & (~wreck | compare_wrecks | (m.margin.min(1) >= 1e-9))
+        # (free-running: the engine's state may differ from the oracle's by the 1e-7 the previous steps are held to, so a push
+        #  direction decided by |d.normal| below 1e-6 can flip -- two cars tracking one lane centre are that close laterally)
+        ok = live & (~wreck | compare_wrecks | (m.margin.min(1) >= 1e-6))
         what = f"step {t}"
         np.testing.assert_array_equal(term[live], te2[live], err_msg=what)
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)

@@ -164,7 +164,10 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
         what = f"step {t}"
         pres = (ref["flags"] & _abi.F_ABSENT) == 0
         wreck = (pres & ((ref["flags"] & (_abi.F_CRASHED | _abi.F_HAS_IMPACT)) != 0)).any(1)
-        well = m.margin.min(1) >= KNIFE
+        # (an environment that has run on its own state since the last re-synchronisation may differ from the oracle's by the
+        #  1e-7 its steps are held to: a push direction decided by |d.normal| below 1e-6 can flip there)
+        knife = np.where(drift > 0, 1e-6, KNIFE)
+        well = m.margin.min(1) >= knife
         n_col += int(wreck.sum())           # wrecked envs are re-spawned below: every wreck is a FIRST collision
         n_full += int((wreck & well).sum())
         np.testing.assert_array_equal(term, te2, err_msg=what)
@@ -185,7 +188,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
                 try:
                     assert_obs_close(obs[sel], o2[sel], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
                     np.testing.assert_allclose(reward[sel], r2[sel], rtol=0, atol=1e-9, err_msg=what)
-                    assert_net_state_close(_sub(got, sel), _sub(ref, sel), atol=atol, what=what, signed=(m.margin >= KNIFE)[sel])
+                    assert_net_state_close(_sub(got, sel), _sub(ref, sel), atol=atol, what=what, signed=(m.margin >= knife[:, None])[sel])
                 except AssertionError:
                     if strict:
                         raise
