@@ -77,5 +77,52 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def kernel_resources(lib_path: str = LIB_PATH) -> dict:
+    """What the compiler allocated to every kernel of the gfx950 code object inside the built library, read from the code
+    object's own metadata (NT_AMDGPU_METADATA note: the numbers the hardware dispatcher uses), keyed by demangled kernel name
+    without the argument list: ``{"hwy::hwy_step_wave_kernel<3, false>": {"vgpr": 102, "vgpr_spill": 0, "sgpr": 106,
+    "sgpr_spill": 76, "lds": 8080, "scratch": 36, "workgroup": 64}, ...}``.  Needs no GPU.  Used by tests/test_kernel_resources.py
+    (the occupancy DESIGN.md quotes for each step kernel is a property of the build, checked where the build is checked) and
+    tools/kernel_table.py --so."""
+    import re
+    import struct
+    import msgpack  # (build / test time only)
+    blob = open(lib_path, "rb").read()
+    o = blob.index(b"__CLANG_OFFLOAD_BUNDLE__")  # hipcc's fat binary: magic[24], u64 n, n x (u64 offset, u64 size, u64 len, triple)
+    n, q, co = struct.unpack_from("<Q", blob, o + 24)[0], o + 32, None
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", blob, q)
+        if b"gfx950" in blob[q + 24:q + 24 + tl]:
+            co = blob[o + off:o + off + size]
+        q += 24 + tl
+    if co is None or co[:4] != b"\x7fELF":
+        raise RuntimeError(f"{lib_path}: no gfx950 code object in the offload bundle")
+    shoff = struct.unpack_from("<Q", co, 0x28)[0]
+    shentsize, shnum = struct.unpack_from("<HH", co, 0x3A)
+    meta = None
+    for i in range(shnum):
+        sh = struct.unpack_from("<IIQQQQIIQQ", co, shoff + i * shentsize)
+        if sh[1] != 7:  # SHT_NOTE
+            continue
+        d, k = co[sh[4]:sh[4] + sh[5]], 0
+        while k < len(d):
+            nsz, dsz, ty = struct.unpack_from("<III", d, k)
+            k += 12 + ((nsz + 3) & ~3)
+            if ty == 32:  # NT_AMDGPU_METADATA (msgpack)
+                meta = msgpack.unpackb(d[k:k + dsz], raw=False)
+            k += (dsz + 3) & ~3
+    if meta is None:
+        raise RuntimeError(f"{lib_path}: the gfx950 code object carries no AMDGPU metadata note")
+    kernels = meta["amdhsa.kernels"]
+    names = subprocess.run(["c++filt"] + [k[".name"] for k in kernels], capture_output=True, text=True, check=True).stdout.split("\n")
+    out = {}
+    for k, name in zip(kernels, names):
+        out[re.sub(r"\(.*\)$", "", name).replace("void ", "")] = {
+            "vgpr": k[".vgpr_count"], "vgpr_spill": k[".vgpr_spill_count"], "sgpr": k[".sgpr_count"],
+            "sgpr_spill": k[".sgpr_spill_count"], "lds": k[".group_segment_fixed_size"],
+            "scratch": k[".private_segment_fixed_size"], "workgroup": k[".max_flat_workgroup_size"]}
+    return out
+
+
 if __name__ == "__main__":
     print(build_engine(force=True, verbose=True))

@@ -1,0 +1,78 @@
+"""The register / LDS allocation of the step kernels is a property of the BUILD: DESIGN.md section 3 quotes an occupancy for each
+of them (waves per SIMD by registers, workgroups per CU by LDS), and a compiler or source change that silently costs a resident
+wavefront or brings spills back would only show up as a slower bench line a round later.  Checked here from the code object's own
+metadata (highwayenv_amd.build.kernel_resources: no GPU needed), with bounds, not exact counts.
+
+gfx950: 512 VGPRs per SIMD lane (allocation granule 8), 160 KB of LDS per CU, 4 SIMDs per CU."""
+import pytest
+
+from highwayenv_amd import build
+
+LDS_PER_CU = 160 * 1024
+
+
+@pytest.fixture(scope="module")
+def res():
+    if build.is_stale():
+        build.build_engine()
+    return build.kernel_resources()
+
+
+def waves_per_simd(vgpr: int) -> int:
+    return min(8, 512 // (((vgpr + 7) // 8) * 8))
+
+
+def test_every_step_family_is_in_the_code_object(res):
+    names = " ".join(res)
+    for fam in ("hwy_step_wave_kernel", "hwy_rollout_wave_kernel", "hwy_step_kernel", "hwy_rollout_kernel", "hwy_reset_kernel",
+                "hwy_observe_kernel", "hwy_net_step_kernel", "hwy_net_rollout_kernel", "hwy_net_reset_kernel",
+                "hwy_net_observe_kernel", "hwy_ix_step_kernel", "hwy_ix_rollout_kernel", "hwy_ix_reset_kernel",
+                "hwy_ix_observe_kernel"):
+        assert f"hwy::{fam}<" in names, fam
+    for k, r in res.items():
+        assert r["sgpr"] <= 106, (k, r)  # (102 + VCC / flat scratch: nothing asks for more than the hardware has)
+
+
+@pytest.mark.parametrize("full_scan", ["false", "true"])
+def test_one_wavefront_kernel_four_waves_per_simd_no_vgpr_spills(res, full_scan):
+    """hwy_step_wave_kernel<WPE, FULL_SCAN>: the headline launch (4096 envs = 4 wavefronts on each of the 1024 SIMDs) needs 4 resident
+    wavefronts per SIMD by registers and 16 one-wavefront workgroups per CU by LDS; no VGPR is spilled."""
+    for wpe in (1, 2, 3, 4):
+        for fam in ("hwy_step_wave_kernel", "hwy_rollout_wave_kernel"):
+            r = res[f"hwy::{fam}<{wpe}, {full_scan}>"]
+            assert r["vgpr_spill"] == 0, r
+            assert waves_per_simd(r["vgpr"]) >= 4, r
+            assert 16 * r["lds"] <= LDS_PER_CU, r
+            assert r["workgroup"] == 64
+
+
+def test_merge_kernel_four_waves_per_simd(res):
+    """hwy_net_step_kernel<4, false> (BASELINE config 5): 128 VGPRs at 4 waves/SIMD -- the round-2 build spilled 54 there."""
+    r = res["hwy::hwy_net_step_kernel<4, false>"]
+    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] <= 4, r
+    assert 16 * r["lds"] <= LDS_PER_CU, r
+    r = res["hwy::hwy_net_rollout_kernel<4, false>"]
+    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] <= 12, r
+
+
+def test_intersection_kernel_allocation(res):
+    """hwy_ix_step_kernel<2, 32, 64> (BASELINE config 4: 32 slots + 32 helper lanes): no spills, registers for three wavefronts
+    per SIMD, LDS for eight workgroups per CU (the two per SIMD the launch is tuned for, profiles/r03_history.md)."""
+    r = res["hwy::hwy_ix_step_kernel<2, 32, 64>"]
+    assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
+    assert waves_per_simd(r["vgpr"]) >= 3, r
+    assert 8 * r["lds"] <= LDS_PER_CU, r
+    r = res["hwy::hwy_ix_rollout_kernel<2, 32, 64>"]
+    assert r["vgpr_spill"] == 0 and waves_per_simd(r["vgpr"]) >= 2 and 8 * r["lds"] <= LDS_PER_CU, r
+
+
+def test_workgroup_kernel_allocation(res):
+    """hwy_step_kernel<W, WPE> (N > 64: W wavefronts per environment).  The 3-wave builds hold no spills; the 4-wave builds
+    (batches beyond 3 resident wavefronts per SIMD) trade a few spilled VGPRs for the fourth wavefront."""
+    for w in (1, 2, 3, 4):
+        r3, r4 = res[f"hwy::hwy_step_kernel<{w}, 3>"], res[f"hwy::hwy_step_kernel<{w}, 4>"]
+        assert r3["vgpr_spill"] == 0 and waves_per_simd(r3["vgpr"]) >= 3, r3
+        assert waves_per_simd(r4["vgpr"]) >= 4 and r4["vgpr_spill"] <= 48, r4
+        assert r3["workgroup"] == 64 * w and r3["lds"] == r4["lds"]
+        # LDS never limits below what the registers allow: (waves/SIMD x 4 SIMDs) / W workgroups per CU
+        assert (12 // w) * r3["lds"] <= LDS_PER_CU and (16 // w) * r4["lds"] <= LDS_PER_CU, (r3, r4)
