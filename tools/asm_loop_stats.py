@@ -17,15 +17,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from highwayenv_amd.build import HIPCC_FLAGS  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join("/tmp", "hwy_asm_base")  # (150 MB of compiler temporaries: kept out of the tree that gpurun ships)
+# (150 MB of compiler temporaries: kept out of the tree that gpurun ships).  HWY_ASM_OUT / HWY_EXTRA_FLAGS: another directory
+# and extra hipcc flags (appended, so they override build.HIPCC_FLAGS) -- how a flag experiment is counted before it is timed:
+#   HWY_ASM_OUT=/tmp/hwy_asm_fma HWY_EXTRA_FLAGS=-ffp-contract=fast python tools/asm_loop_stats.py
+OUT = os.environ.get("HWY_ASM_OUT", os.path.join("/tmp", "hwy_asm_base"))
 KERNEL = "_ZN3hwy20hwy_step_wave_kernelILi3ELb0EEEvNS_10StepParamsE"
+if "--kernel" in sys.argv:
+    KERNEL = sys.argv.pop(sys.argv.index("--kernel") + 1)
+    sys.argv.remove("--kernel")
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     subprocess.run(["hipcc", *HIPCC_FLAGS,
                     "-gline-tables-only", "-c", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip"),
-                    "-o", os.path.join(OUT, "k.o"), "-save-temps=obj"], check=True, capture_output=True)
+                    "-o", os.path.join(OUT, "k.o"), "-save-temps=obj", *os.environ.get("HWY_EXTRA_FLAGS", "").split()],
+                   check=True, capture_output=True, cwd=OUT)
     s = open(os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     files = {}
     for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]+)"(?:\s+"([^"]+)")?', s):
