@@ -16,7 +16,12 @@ from highwayenv_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
-_LIB = os.path.join(_HERE, "_build", "libhwy_emu.so")
+# HWY_EMU_FLAGS: extra g++ flags for the emulator build (its own library file), e.g. "-ffp-contract=fast -mfma" -- how the test
+# suite's tolerances were tried against fused multiply-adds before the kernel build's -ffp-contract=off was put up for an A/B
+# (profiles/r03_history.md).  The default build rounds every a*b+c twice, like the kernel build and like numpy.
+_EXTRA = os.environ.get("HWY_EMU_FLAGS", "").split()
+_LIB = os.path.join(_HERE, "_build", "libhwy_emu.so" if not _EXTRA else
+                    "libhwy_emu_%08x.so" % (__import__("zlib").crc32(" ".join(_EXTRA).encode()) & 0xffffffff))
 _lib = None
 
 
@@ -33,7 +38,7 @@ def build(force: bool = False) -> str:
     if force or stale:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = f"{_LIB}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
-        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
+        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", *_EXTRA,
                         "-o", tmp, srcs[0]], check=True, capture_output=True)
         os.replace(tmp, _LIB)
     return _LIB

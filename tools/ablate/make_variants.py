@@ -279,6 +279,7 @@ FLAG_VARIANTS = {
     "f_bias0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"],
     "f_bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
     "f_nopostlicm": ["-mllvm", "-disable-postra-machine-licm"],
+    "f_fma": ["-ffp-contract=fast"],  # a*b+c fused where the compiler sees it (the build double-rounds like numpy: -ffp-contract=off)
 }
 
 
