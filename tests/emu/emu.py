@@ -12,7 +12,7 @@ import subprocess
 
 import numpy as np
 
-from highwayenv_amd import _abi
+from highwayenv_amd import _abi, build as build_flags
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
@@ -38,7 +38,8 @@ def build(force: bool = False) -> str:
     if force or stale:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = f"{_LIB}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
-        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", *_EXTRA,
+        contract = ["-ffp-contract=off"] if build_flags.FP_CONTRACT == "off" else ["-ffp-contract=fast", "-mfma"]  # like the kernel build
+        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", *contract, *_EXTRA,
                         "-o", tmp, srcs[0]], check=True, capture_output=True)
         os.replace(tmp, _LIB)
     return _LIB
