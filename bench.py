@@ -101,6 +101,26 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
             "source": d["_file"] + " (SQ counters of this kernel build and config)"}
 
 
+def kernel_resources_view(scenario: str, fast: bool, n_vehicles: int):
+    """Registers / spills / LDS the compiler allocated to the step-kernel family this workload launches, read from the code object
+    inside the library being timed (highwayenv_amd.build.kernel_resources; the WPE variants of a family that allocate the same are
+    listed once).  None if the metadata cannot be read (it is a report, never a reason to fail the bench)."""
+    try:
+        from highwayenv_amd import build
+        fam = ("hwy::hwy_ix_step_kernel<" if scenario == "intersection" else "hwy::hwy_net_step_kernel<" if scenario != "highway" else
+               "hwy::hwy_step_wave_kernel<" if n_vehicles <= 64 else f"hwy::hwy_step_kernel<{(n_vehicles + 63) // 64}, ")
+        tail = (", false>" if fast else ", true>") if fam.startswith("hwy::hwy_step_wave") else ""
+        lib = os.environ.get("HWY_ENGINE_LIB") or build.LIB_PATH
+        out, seen = {}, set()
+        for name, r in build.kernel_resources(lib).items():
+            if name.startswith(fam) and name.endswith(tail) and tuple(r.values()) not in seen:
+                seen.add(tuple(r.values()))
+                out[name.replace("hwy::", "")] = dict(r, waves_per_simd_by_vgprs=min(8, 512 // (((r["vgpr"] + 7) // 8) * 8)))
+        return out or None
+    except Exception:
+        return None
+
+
 def measured_traffic(workload: str, envs_per_gpu: int):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
     passes, calibrated on a known byte count in this kernel's access pattern: tools/traffic_probe.py,
@@ -649,7 +669,8 @@ def main() -> None:
                                                  "own timestamps, wall ms_per_step)",
                          "event_kernel_us": (kernel_ms / launches * 1e3) if launches else None,
                          "algorithmic_bytes_per_launch": b_env * E,
-                         "valu": valu_view(E, avg_kernel_s, args.workload)},
+                         "valu": valu_view(E, avg_kernel_s, args.workload),
+                         "kernel_resources": kernel_resources_view(scenario, fast, N)},
             "terminated_in_last_step": int(term),
             "ix_spawn_counters": (lambda c: dict(c, drop_rate=c["ix_spawns_dropped"] / max(1, c["ix_spawns"] + c["ix_spawns_dropped"])))(eng.counters()) if scenario == "intersection" else None,
             "host_path_env_steps_per_s": host_rate,
