@@ -13,6 +13,7 @@ LDS_PER_CU = 160 * 1024
 
 @pytest.fixture(scope="module")
 def res():
+    pytest.importorskip("msgpack")  # (the metadata note is msgpack; present in the build image and on the GPU box)
     if build.is_stale():
         build.build_engine()
     return build.kernel_resources()
