@@ -167,7 +167,7 @@ def test_random_intersection_configurations_vs_oracle(chunk):
     from tests.backends import make_engine
     from tests.golden_util import KNIFE, assert_obs_close, ix_oracle_config, ix_oracle_state
     rng = np.random.default_rng(5000 + chunk)
-    tot_steps = tot_checked = tot_frames = tot_col = tot_col_full = tot_img_cells = tot_edge = 0
+    tot_steps = tot_checked = tot_frames = tot_col = tot_col_full = tot_img_cells = tot_edge = tot_touch = 0
     for k in range(4):
         cfg = random_intersection_config(rng)
         E = 12
@@ -197,7 +197,13 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                     np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
                 for f in ("impact_x", "impact_y"):  # signed
                     np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
-                np.testing.assert_array_equal(((g1["flags"] & _abi.F_HAS_IMPACT) != 0)[fine], (ost1["has_impact"] != 0)[fine])
+                # two wrecks resting EXACTLY touching (flag_margin < KNIFE: the `will_intersect` of that pair hinges on a distance of
+                # ~1e-16, emulator fuzz chunk 30103): whether the pair gets its ~0 translation as a pending impact is decided by the
+                # last bit -- the bit is compared on every other slot, such slots are counted (the translations above agree: both ~0)
+                touching = np.asarray(m1.flag_margin) < KNIFE
+                hi_g, hi_o = (g1["flags"] & _abi.F_HAS_IMPACT) != 0, ost1["has_impact"] != 0
+                np.testing.assert_array_equal((hi_g | touching)[fine], (hi_o | touching)[fine])
+                tot_touch += int((touching & (hi_g != hi_o))[fine].sum())
                 np.testing.assert_array_equal(((g1["flags"] & _abi.F_YIELDING) != 0)[fine], (ost1["is_yielding"] != 0)[fine])
                 tot_frames += int(fine.sum())
                 # -- the whole policy step -----------------------------------------------------------------------------
@@ -298,7 +304,9 @@ def test_random_intersection_configurations_vs_oracle(chunk):
     print(f"\nintersection fuzz chunk {chunk}: {tot_steps} live env-steps; first frame compared at 1e-9 on {tot_frames} "
           f"({100.0 * tot_frames / max(tot_steps, 1):.1f} %), whole step on {tot_checked} ({100.0 * frac:.1f} %); "
           f"{tot_col} fast-enough steps with a wreck, {tot_col_full} of them in full; as_image cells off by one: {tot_img_cells}"
-          + (f"; {tot_edge} env-steps diverged on a touching pair's knife edge (tolerated)" if tot_edge else ""))
+          + (f"; {tot_edge} env-steps diverged on a touching pair's knife edge (tolerated)" if tot_edge else "")
+          + (f"; {tot_touch} first-frame pending-impact bits of exactly touching wrecks differed (tolerated)" if tot_touch else ""))
+    assert tot_touch <= 0.02 * tot_frames + 2
     assert tot_frames >= 0.97 * tot_steps, "the first-frame comparison must cover (nearly) every live env-step"
     assert frac >= INTERSECTION_WHOLE_STEP_FLOOR, f"only {100 * frac:.1f} % of the env-steps were compared as whole steps"
     assert tot_col_full >= 0.9 * tot_col - 1
