@@ -49,6 +49,7 @@ VEHICLES_COUNT = 50
 LANES = 4
 EVENT_EVERY = 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_env_step(n_vehicles: int, agents: int, obs_floats: int = 25) -> int:
@@ -68,7 +69,7 @@ def _load_counters(name: str, workload: str):
     """A committed rocprofv3 PMC summary (profiles/<name>) -- returned ONLY if it was recorded for the kernel build
     being timed (its `kernel_source_sha16` equals this build's) and for this workload: counters of another build
     say nothing about this one, and PMC counters cannot be read from inside this process."""
-    for rnd in ("r03", "r02"):  # the newest round's file first
+    for rnd in ("r04", "r03", "r02"):  # the newest round's file first
         path = os.path.join(ROOT, "profiles", name.replace("RND", rnd))
         try:
             d = json.load(open(path))
@@ -92,7 +93,14 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     c = d["per_wave_per_step"]
     flop = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"]) * 64 * envs_per_gpu
     achieved = flop / avg_kernel_s / 1e12
+    # the ceiling that binds this kernel: every VALU instruction of a 64-wide wavefront holds its SIMD's issue port for 4 cycles
+    # (16 lanes per cycle, f64 and 32-bit alike), so a launch cannot end before (VALU instructions of all its wavefronts) x 4
+    # cycles / (1024 SIMDs x 2.4 GHz).  valu_issue = that floor / the measured launch duration.
+    # (the committed counters are sums over a launch / environments: per env-step, whatever the wavefronts per environment)
+    issue_floor_s = c["SQ_INSTS_VALU"] * 4.0 * envs_per_gpu / (SIMDS * CLOCK_HZ)
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
+            "valu_issue": issue_floor_s / avg_kernel_s, "valu_issue_floor_us": issue_floor_s * 1e6,
+            "valu_issue_method": f"SQ_INSTS_VALU per env-step x 4 cycles x {envs_per_gpu} envs / ({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz) / avg_kernel_us",
             "valu_instructions_per_env_step": c["SQ_INSTS_VALU"], "salu_instructions_per_env_step": c["SQ_INSTS_SALU"],
             # (one wavefront per environment and the whole grid resident: the headline workload only)
             "valu_issue_utilisation_while_resident": (c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"]
@@ -142,7 +150,7 @@ def cpu_baseline(workload: str, cfg_dict, fast: bool, scenario: str, have_gpu: b
     if have_gpu or scenario != "intersection":  # (the intersection port takes its start states from the engine)
         port = cpu_baseline_port(cfg_dict, fast, scenario=scenario)
     if ref_bench.available():
-        out = ref_bench.measure(workload, budget_s=20.0, all_cores_budget_s=10.0)
+        out = ref_bench.measure(workload, budget_s=30.0, all_cores_budget_s=30.0)
         out["reference"] = dict({k: v for k, v in out.items() if k != "all_cores"}, same_box=True, all_cores=out.get("all_cores"))
         if port is not None:
             out["port"] = port
@@ -161,7 +169,7 @@ def cpu_baseline(workload: str, cfg_dict, fast: bool, scenario: str, have_gpu: b
     return out
 
 
-def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 20.0, scenario: str = "highway"):
+def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 30.0, scenario: str = "highway"):
     """The CPU oracle (C port of the reference hot path, 1 thread) on a bounded sample of the
     same workload: same config, same spawn rule, random actions."""
     from highwayenv_amd import _abi, merge, spawn
@@ -198,7 +206,7 @@ def cpu_baseline_port(cfg_dict, fast: bool = True, budget_s: float = 20.0, scena
     n_thr = min(64, os.cpu_count() or 1)
     if n_thr > 1:
         counts = [0] * n_thr
-        stop_at = time.perf_counter() + 10.0
+        stop_at = time.perf_counter() + 30.0
 
         def worker(k):
             st_k = _abi.copy_state(st0)
@@ -480,14 +488,20 @@ def main() -> None:
     # HIP events on every 8th launch of the timed regions: the engine hands the pair to hipExtLaunchKernelGGL, which records the
     # DISPATCH's own begin / end timestamps into them (the clock readings rocprofv3 --kernel-trace reports) on the launch stream
     eng.profile_enable(0 if os.environ.get("HWY_BENCH_NO_EVENTS") == "1" else EVENT_EVERY)
-    region_s = []
+    region_s, region_dev_ms = [], []
     for r in range(R):
         t_first = args.warmup + r * args.steps
+        # the same region on the DEVICE timeline too: an event pair on the stream the engine launches on, around the K launches
+        # (host wall = this + the latency of fence()'s drain / barrier / synchronize, which a short region does not amortise)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record(stream)
         for t in range(t_first, t_first + args.steps):
             one_step(t)
+        ev1.record(stream)
         fence()
         dt_r = time.perf_counter() - t0
+        region_dev_ms.append(ev0.elapsed_time(ev1))
         el = torch.tensor([dt_r], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -516,7 +530,7 @@ def main() -> None:
     # K policy steps per launch with pre-staged actions (hwy_rollout_device: open-loop rollouts / action repeat): reported NEXT TO
     # the headline, never instead of it -- `value` stays one launch per step
     rollout = None
-    if world == 1 and args.rollout_k > 1:
+    if world == 1 and args.rollout_k > 1 and R * args.steps > args.rollout_k:  # (needs more staged action blocks than one call reads)
         Kr = args.rollout_k
         n_calls = max(1, args.steps // Kr)
         r_obs = torch.empty((Kr, E, A, *_abi.obs_shape(cfg)), dtype=torch.float32, device=dev)
@@ -528,6 +542,7 @@ def main() -> None:
 
         def roll(c):
             t0_ = args.warmup + (c * Kr) % (R * args.steps - Kr)
+            assert 0 <= t0_ and t0_ + Kr <= actions.shape[0]
             eng.rollout_device(Kr, actions[t0_].data_ptr(), r_obs.data_ptr(), r_rew.data_ptr(), r_term.data_ptr(),
                                r_trunc.data_ptr(), r_speed.data_ptr(), r_crashed.data_ptr())
         for c in range(2):
@@ -609,11 +624,12 @@ def main() -> None:
         value = env_steps / elapsed
         b_env = algorithmic_bytes_per_env_step(N, A, int(np.prod(_abi.obs_shape(cfg))))
         # The dominant kernel's launch duration: the dispatch timestamps of every 8th launch (HIP events filled in by
-        # hipExtLaunchKernelGGL), never more than the wall-clock step that contains the launch (a kernel cannot take longer than its
-        # step).  Without events (HWY_BENCH_NO_EVENTS=1, a developer knob): the wall step.
+        # hipExtLaunchKernelGGL), reported AS MEASURED.  A kernel cannot take longer than the step that contains it: if the
+        # events say so anyway the run is flagged (`event_exceeds_wall_step`) instead of clamped.  Without events
+        # (HWY_BENCH_NO_EVENTS=1, a developer knob): the wall step.
         wall_step_s = elapsed / args.steps
         event_kernel_s = (kernel_ms / 1e3 / launches) if launches else None
-        avg_kernel_s = min(event_kernel_s, wall_step_s) if event_kernel_s and event_kernel_s > 0 else wall_step_s
+        avg_kernel_s = event_kernel_s if event_kernel_s and event_kernel_s > 0 else wall_step_s
         achieved = b_env * E / avg_kernel_s / 1e9
         line = {
             "metric": "env-steps/s",
@@ -625,7 +641,11 @@ def main() -> None:
             "repeats": R,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_repeats": [x / args.steps * 1e3 for x in region_s],
-            "timing": f"median of {R} regions of {args.steps} steps (barrier + synchronize on both sides, max over ranks)",
+            "ms_per_step_device": float(np.median(region_dev_ms)) / args.steps,
+            "ms_per_step_device_repeats": [x / args.steps for x in region_dev_ms],
+            "timing": (f"median of {R} regions of {args.steps} steps (barrier + synchronize on both sides, max over ranks); "
+                       "ms_per_step / value = host wall clock around each region incl. the closing fence; ms_per_step_device = the "
+                       "same regions between two events on the engine's stream (rank 0)"),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -665,9 +685,10 @@ def main() -> None:
                                     f"hwy_step_wave_kernel<WPE,{str(not fast).lower()}>  (one 64-wide wavefront per env; every WPE variant is the same "
                                     "102 / 128-VGPR code)" if N <= 64 else
                                     f"hwy_step_kernel<{(N + 63) // 64},WPE>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
-                         "avg_kernel_us_method": "min(mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's "
-                                                 "own timestamps, wall ms_per_step)",
+                         "avg_kernel_us_method": ("mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's own "
+                                                  "timestamps (unclamped)" if event_kernel_s else "wall ms_per_step (no events)"),
                          "event_kernel_us": (kernel_ms / launches * 1e3) if launches else None,
+                         "event_exceeds_wall_step": bool(event_kernel_s and event_kernel_s > wall_step_s * 1.02),
                          "algorithmic_bytes_per_launch": b_env * E,
                          "valu": valu_view(E, avg_kernel_s, args.workload),
                          "kernel_resources": kernel_resources_view(scenario, fast, N)},

@@ -421,6 +421,14 @@ struct EnvBlock {
     const double r = fmax(v, 0.0) * fast_rcp(abs_not_zero(v0));
     return r > 0.0 ? log_pos(r) : -__builtin_inf();  // r == 0 -> exp(-inf) = 0 == pow(0, delta)
   }
+  // the same with 1 / |nz(v0)| handed in (v0 = the clipped target speed changes only with the meta-action of frame 0)
+  __device__ static inline double idm_inv_v0(const StepParams &p, double ts) {
+    return fast_rcp(abs_not_zero(clipd(ts, 0.0, p.speed_limit)));
+  }
+  __device__ static inline double idm_log_ratio_inv(double v, double inv_v0) {
+    const double r = fmax(v, 0.0) * inv_v0;
+    return r > 0.0 ? log_pos(r) : -__builtin_inf();
+  }
   __device__ static inline double idm_free_from_log(double log_ratio, double delta) {
     return HWY_COMFORT_ACC_MAX * (1 - exp_bounded(delta * log_ratio));
   }

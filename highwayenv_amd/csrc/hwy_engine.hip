@@ -616,6 +616,9 @@ extern "C" int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_
   if (k_steps < 1) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: k_steps must be >= 1");
   if (!d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated)
     return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: actions/obs/reward/terminated/truncated must be non-NULL");
+  if (k_steps > 1 && is_ix(eng) && (eng->cfg.flags & HWY_C_HOST_TRAFFIC))  // the host clears / spawns BETWEEN policy steps
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout_device: k_steps > 1 needs device traffic (HWY_C_HOST_TRAFFIC is set: "
+                                          "_clear_vehicles / _spawn_vehicle run on the host between steps)");
   HWY_HIP(eng, hipSetDevice(eng->device));
   StepParams p;
   fill_params(eng, p);
@@ -654,6 +657,8 @@ extern "C" int hwy_rollout(hwy_engine *eng, int32_t k_steps, const int32_t *acti
   if (k_steps < 1) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout: k_steps must be >= 1");
   if (!actions || !obs || !reward || !terminated || !truncated)
     return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout: actions/obs/reward/terminated/truncated must be non-NULL");
+  if (k_steps > 1 && is_ix(eng) && (eng->cfg.flags & HWY_C_HOST_TRAFFIC))
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_rollout: k_steps > 1 needs device traffic (HWY_C_HOST_TRAFFIC is set)");
   size_t n_act, n_obs, n_ea;
   io_counts(eng->cfg, &n_act, &n_obs, &n_ea);
   const size_t E = eng->cfg.num_envs, K = (size_t)k_steps;

@@ -16,26 +16,22 @@
 
 namespace hwy {
 
-// A loop-invariant f64 constant that must NOT be hoisted out of the frame loop: neither into a VGPR pair
-// (LICM did that with ~27 polynomial coefficients: +54 VGPRs) nor into an SGPR pair that then gets spilled to
-// VGPR lanes and re-read with v_readlane.  The constant is OR-ed (two s_or_b32 with literal operands) onto a
-// zero that a volatile asm produces in place, so there is no loop-invariant value left to hoist or spill, and
-// the result is an aligned SGPR pair (usable directly as the one constant-bus operand of an f64 VALU op).
+// A polynomial coefficient is the constant-bus operand of its VALU instruction: an aligned SGPR pair that the COMPILER
+// materialises where it is used (two s_mov_b32 with literal operands; it knows their hazards).  The build runs without
+// MachineLICM (build.py: -disable-machine-licm), so nothing hoists these materialisations out of the frame loop into VGPR
+// pairs (that cost +54 VGPRs) or into SGPR pairs that get spilled to VGPR lanes.  (Rounds 1-3 forced the same with a volatile
+// `s_mov_b64 0` + two s_or_b32 per constant; handing the plain value to the asm below saves one SALU instruction per
+// constant: frame loop of the headline kernel 952 -> 881 SALU, measured -2.4 % on the headline launch, -1.5 .. -4.5 % on the
+// other four workloads, profiles/r04_history.md.)
 #ifndef HWY_KC
-template <unsigned long long BITS>
-__device__ __forceinline__ double sgpr_const() {
-  unsigned long long z;
-  asm volatile("s_mov_b64 %0, 0" : "=s"(z));
-  return __longlong_as_double((long long)(BITS | z));
-}
-#define HWY_KC(c) ::hwy::sgpr_const<__builtin_bit_cast(unsigned long long, (double)(c))>()
+#define HWY_KC(c) (c)
 // a*b + K (fused) with the constant K as the constant-bus operand of a VOP3 v_fma_f64.  Written as asm because
 // the compiler selects the two-address v_fmac form for a Horner step, whose addend must live in a VGPR pair:
 // it would copy K there first (two more VALU ops per coefficient).
 template <unsigned long long BITS>
 __device__ __forceinline__ double fma_k(double a, double b) {
   double r;
-  const double k = sgpr_const<BITS>();
+  const double k = __longlong_as_double((long long)BITS);
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
   return r;
 }
@@ -43,7 +39,11 @@ __device__ __forceinline__ double fma_k(double a, double b) {
 #endif
 // Horner: poly(t; K_n ... K_0) with the two leading coefficients combined as t*K_n + K_(n-1) (two constants
 // cannot share one VALU instruction: one constant-bus read per instruction on gfx9)
-#define HWY_LEAD(t, kn, kn1) ((t) * HWY_KC(kn) + HWY_KC(kn1))
+__device__ __forceinline__ double lead_unfused(double t, double kn, double kn1) {
+#pragma clang fp contract(off)
+  return t * kn + kn1;
+}
+#define HWY_LEAD(t, kn, kn1) ::hwy::lead_unfused(t, HWY_KC(kn), HWY_KC(kn1))
 
 // ---- reciprocal / reciprocal square root: hardware seed (~2^-26) + two Newton steps ----------------
 __device__ inline double fast_rcp(double x) {

@@ -334,6 +334,7 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
   // idle lanes keep their own slot so that the permutation stays a bijection)
   int rank = active ? me.rank : i;
   bool has_tie = false;  // two vehicles share the same x (=> literal neighbour scans)
+  double inv_v0 = 0.0;   // 1 / |nz(clip(target speed))|: a per-STEP invariant of IDM's (v / v0)^delta
   for (int fr = 0; fr < p.n_frames; ++fr) {
     wave_turn(turn);
     // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315) ------------------------------
@@ -369,7 +370,8 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       m_pub = (i == L + 1) ? b : m_pub;
     }
     // frame-start snapshot, stored in rank order (with each vehicle's IDM log speed ratio)
-    const double log_ratio = active ? B::idm_log_ratio(p, me.v, sh.ts[i]) : 0.0;  // egos and wrecks can be followers too
+    if (fr == 0) inv_v0 = B::idm_inv_v0(p, sh.ts[i]);  // (after the meta-action of frame 0: the target speed is fixed for the step)
+    const double log_ratio = active ? B::idm_log_ratio_inv(me.v, inv_v0) : 0.0;  // egos and wrecks can be followers too
     HWY_WAVE_LDS_FENCE();  // previous frame's gathers are complete
     if (active) {
       sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;

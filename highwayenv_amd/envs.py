@@ -200,6 +200,10 @@ class BatchedHighwayEnv:
         else:
             base_seed = int(seeds[0]) + 0x9E3779B9
         eng.set_autoreset(self.autoreset, base_seed=base_seed, **self._device_spawn_args())
+        # SameStep re-spawns (reset_done): their own stream, keyed by the user's seed (reproducible; fresh entropy for seed=None)
+        # and restarted by every reset() -- a SeedSequence child, so that no (seed, env, episode) meets a first-episode seed s + e
+        self._same_step_entropy = int(base_seed)
+        self._episodes = np.zeros(E, np.uint64)
         self.time[:] = 0
         self.steps = 0
         st = eng.get_state()
@@ -211,15 +215,20 @@ class BatchedHighwayEnv:
     def reset_done(self, mask) -> np.ndarray:
         """Re-spawn the environments of ``mask`` [E] on the device NOW (the "SameStep" autoreset of a vector env: the step that
         ended an episode also returns the next episode's first observation) and return their observations [k, ...].  Seeds:
-        a counter-based sequence per environment, disjoint from the first episodes' (``spawn_mode="device"`` only)."""
+        hashed from (the seed given to reset(), env, episode number) -- reproducible per user seed, different between user
+        seeds, restarted by reset() (``spawn_mode="device"`` only)."""
         if self.spawn_mode != "device":
             raise NotImplementedError("reset_done (SameStep autoreset) needs spawn_mode='device'")
         mask = np.asarray(mask, bool)
-        if not hasattr(self, "_episodes") or len(self._episodes) != self.num_envs:
-            self._episodes = np.zeros(self.num_envs, np.uint64)
+        if self._engine is None or getattr(self, "_episodes", None) is None or len(self._episodes) != self.num_envs:
+            raise RuntimeError("reset_done before reset()")
         self._episodes[mask] += np.uint64(1)
-        base = np.uint64(getattr(self, "_same_step_base", 0x5EED5EED))
-        seeds = base + np.arange(self.num_envs, dtype=np.uint64) + np.uint64(self.num_envs) * self._episodes
+        # seed of (env e, episode k) = SeedSequence(entropy of this reset(), spawn_key=(0x5A3E, e, k)): hashed, so two user seeds
+        # never replay each other's later episodes and no later episode repeats a first one (seed + e)
+        seeds = np.zeros(self.num_envs, np.uint64)
+        for e in np.flatnonzero(mask):
+            seeds[e] = np.random.SeedSequence(self._same_step_entropy, spawn_key=(0x5A3E, int(e), int(self._episodes[e]))
+                                              ).generate_state(1, np.uint64)[0]
         obs = self._engine.reset(seeds=seeds, mask=mask.astype(np.uint8), **self._device_spawn_args())
         self.time[mask] = 0
         return self._shape_obs(obs)[mask]

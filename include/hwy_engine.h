@@ -367,6 +367,8 @@ int hwy_step(hwy_engine *eng, const int32_t *actions, float *obs, double *reward
  * the dispatch and, above all, the wait for the slowest SIMD at the end of every step are paid once per call.  (Intersection: the
  * launch holds no pre-warming blocks, an environment that ends in it prepares its next episode inline -- same results.)  Enqueues
  * on the engine's stream, does not synchronise, does not validate action ids (see hwy_step_device).
+ * HWY_ERR_INVALID_ARG for k_steps > 1 on an intersection engine configured with HWY_C_HOST_TRAFFIC: there the host runs
+ * _clear_vehicles / _spawn_vehicle between policy steps (intersection_env.py:199-203), which a K-step launch would skip.
  */
 int hwy_rollout_device(hwy_engine *eng, int32_t k_steps, const int32_t *d_actions, float *d_obs, double *d_reward,
                        uint8_t *d_terminated, uint8_t *d_truncated, double *d_info_speed, uint8_t *d_info_crashed);

@@ -38,8 +38,18 @@ def build(force: bool = False) -> str:
     if force or stale:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         tmp = f"{_LIB}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
-        contract = ["-ffp-contract=off"] if build_flags.FP_CONTRACT == "off" else ["-ffp-contract=fast", "-mfma"]  # like the kernel build
-        subprocess.run(["g++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", *contract, *_EXTRA,
+        # like the kernel build (build.FP_CONTRACT).  "on" = contraction by source expression is a FRONT-END rule: the emulator
+        # is compiled by the clang the kernels are compiled by (ROCm's), so the same a*b+c fuse here and on the GPU; g++ 11
+        # treats -ffp-contract=on as off and is only the fallback (then: fuse where it likes, same tolerances).
+        clang = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+        cxx = "g++"
+        if build_flags.FP_CONTRACT == "off":
+            contract = ["-ffp-contract=off"]
+        elif build_flags.FP_CONTRACT == "on" and os.path.exists(clang):
+            cxx, contract = clang, ["-ffp-contract=on", "-mfma"]
+        else:
+            contract = ["-ffp-contract=fast", "-mfma"]
+        subprocess.run([cxx, "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", *contract, *_EXTRA,
                         "-o", tmp, srcs[0]], check=True, capture_output=True)
         os.replace(tmp, _LIB)
     return _LIB

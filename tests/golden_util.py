@@ -305,16 +305,27 @@ def ix_engine_state(g: "GoldenIntersection", gst: dict, cfg) -> dict:
     return st
 
 
-def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what="", signed=None):
-    """Two hwy_state dicts of the intersection scenario (absent slots ignored)."""
+def assert_ix_engine_state_close(got: dict, want: dict, atol=1e-9, what="", signed=None, slow_atol=None, slow_below=2.0,
+                                 slow_start=None):
+    """Two hwy_state dicts of the intersection scenario (absent slots ignored).  `slow_atol`: the tolerance for vehicles
+    below `slow_below` m/s at either end of the compared interval (`slow_start` = their speeds at its start): steering_control
+    divides by not_zero(speed) twice, so a last-bit difference of two arithmetics (libm, fused multiply-add or not) grows
+    1e2 x faster per frame on a car that yields or queues than on one that drives."""
     pres = (want["flags"] & _abi.F_ABSENT) == 0
     np.testing.assert_array_equal((got["flags"] & _abi.F_ABSENT) == 0, pres, err_msg=f"{what}: present")
     for k in ["lane", "target_lane", "flags", "route"]:
         np.testing.assert_array_equal(got[k][pres], want[k][pres], err_msg=f"{what}: {k}")
     ctrl = pres & ((want["flags"] & _abi.F_CONTROLLED) != 0)
     np.testing.assert_array_equal(got["speed_index"][ctrl], want["speed_index"][ctrl], err_msg=f"{what}: speed_index")
+    slow = np.zeros_like(pres)
+    if slow_atol is not None:
+        slow = pres & ((want["speed"] < slow_below) | (got["speed"] < slow_below))
+        if slow_start is not None:
+            slow |= pres & (slow_start < slow_below)
     for k in ["x", "y", "heading", "speed", "target_speed"]:
-        np.testing.assert_allclose(got[k][pres], want[k][pres], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+        np.testing.assert_allclose(got[k][pres & ~slow], want[k][pres & ~slow], rtol=0, atol=atol, err_msg=f"{what}: {k}")
+        if slow.any():
+            np.testing.assert_allclose(got[k][slow], want[k][slow], rtol=0, atol=slow_atol, err_msg=f"{what}: {k} (below {slow_below} m/s)")
     _assert_impacts(got, want, pres, atol, what, signed)
     idm = pres & ~ctrl
     np.testing.assert_allclose(got["timer"][idm], want["timer"][idm], rtol=0, atol=atol, err_msg=f"{what}: timer")

@@ -129,8 +129,12 @@ def test_policy_steps_vs_reference(backend, name):
             sub_cfg = _hwy_config(g, int(sel.sum()))
             signed = np.zeros((int(sel.sum()), sub_cfg.num_vehicles), bool)
             signed[:, :g.N] = well[sel]
+            start = ix_engine_state(g, _sub(_sub(cat(starts), rows), sel), sub_cfg)["speed"]
+            # (1e-8 after 15 free-running frames for cars that drive; 1e-6 for a car below 2 m/s at either end of the step -- the
+            #  rule of tests/test_fuzz_configs.py: on the GPU's fused multiply-adds one yielding car of intersection_multi_agent3
+            #  ends step 7 4.8e-8 from the reference's numpy double-rounded trace, 1e-9 per frame from the same state)
             assert_ix_engine_state_close(_sub(_sub(got, rows), sel), ix_engine_state(g, _sub(want, sel), sub_cfg), atol=atol,
-                                         what=what, signed=signed)
+                                         what=what, signed=signed, slow_atol=1e-6, slow_start=start)
         np.testing.assert_array_equal(term[rows][live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[rows][live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(info["crashed"][rows][live, 0], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)

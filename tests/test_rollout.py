@@ -114,3 +114,27 @@ def test_k_steps_on_the_intersection_kernel(backend, slots, grid):
         np.testing.assert_array_equal(sa[f], sb[f], err_msg=f)
     for eng in (a, b):
         eng.close()
+
+
+@pytest.mark.gpu
+def test_k_steps_refused_with_host_side_traffic():
+    """An intersection engine with HWY_C_HOST_TRAFFIC (spawn_mode="reference") has its vehicles cleared / spawned by the host
+    between policy steps: a K-step launch would skip K - 1 of those passes, so hwy_rollout* refuse k_steps > 1 there
+    (include/hwy_engine.h) instead of returning something that is not "K calls of hwy_step"."""
+    from highwayenv_amd import intersection as hix
+    from highwayenv_amd.engine import Engine, EngineError
+    cfg_d = hix.intersection_default_config()
+    cfg_d.update({"max_vehicles": 30, "host_traffic": True})
+    cfg = _abi.make_config(cfg_d, 4, scenario="intersection")
+    dev = Engine(_abi.make_config(dict(cfg_d, host_traffic=False), 4, scenario="intersection"))
+    dev.reset(base_seed=3)
+    st = dev.get_state()
+    dev.close()
+    eng = Engine(cfg)
+    eng.set_state(st)
+    acts = np.ones((2, 4, 1), np.int32)
+    with pytest.raises(EngineError, match="device traffic"):
+        eng.rollout(acts)
+    obs, *_ = eng.rollout(acts[:1])   # one step is a step
+    assert obs.shape[0] == 1
+    eng.close()

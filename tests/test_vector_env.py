@@ -47,6 +47,37 @@ def test_interface_and_next_step_autoreset_on_the_emulator():
         vector.HighwayVectorEnv(EmuBatchedFast, num_envs=2).step_wait()
 
 
+def _same_step_second_episodes(seed, steps=3):
+    cfg = {"vehicles_count": 8, "lanes_count": 2, "duration": 2}
+    venv = vector.HighwayVectorEnv(EmuBatchedFast, num_envs=3, config=cfg, autoreset_mode="SameStep", spawn_mode="device")
+    out = []
+    for _rep in range(2):   # reset(seed) twice in one process: the same continuation both times
+        venv.reset(seed=seed)
+        seen = []
+        for _t in range(steps):
+            obs, _r, term, trunc, _i = venv.step(np.ones(3, np.int64))
+            if (term | trunc).any():
+                seen.append(obs[term | trunc].copy())
+        out.append(np.concatenate(seen))
+    venv.close()
+    np.testing.assert_array_equal(out[0], out[1])
+    return out[0]
+
+
+def test_same_step_respawn_seeds_follow_the_user_seed():
+    """reset_done (SameStep): later episodes are a function of the seed given to reset() -- reproducible for one seed (also
+    across two reset() calls of one process), different for two seeds, and not a copy of a first episode (round-3 advisor)."""
+    a, b = _same_step_second_episodes(11), _same_step_second_episodes(12)
+    assert a.shape == b.shape and len(a) >= 3
+    assert not np.array_equal(a, b)
+    np.testing.assert_array_equal(a, _same_step_second_episodes(11))
+    first = vector.HighwayVectorEnv(EmuBatchedFast, num_envs=3, config={"vehicles_count": 8, "lanes_count": 2, "duration": 2},
+                                    autoreset_mode="SameStep", spawn_mode="device")
+    o11, _ = first.reset(seed=11)
+    first.close()
+    assert not any(np.array_equal(r, o) for r in a for o in o11)
+
+
 def test_stream_argument_needs_the_torch_front_end():
     with pytest.raises(ValueError):
         vector.HighwayVectorEnv("highway-fast-v0", num_envs=2, stream=object())
