@@ -18,7 +18,7 @@ EXPORTS = [
     "hwy_abi_version", "hwy_config_size", "hwy_device_count", "hwy_status_string", "hwy_create",
     "hwy_destroy", "hwy_last_error", "hwy_set_state", "hwy_get_state", "hwy_reset", "hwy_step",
     "hwy_step_device", "hwy_rollout_device", "hwy_rollout", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
-    "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math", "hwy_get_counters",
+    "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math", "hwy_get_counters", "hwy_set_block_order",
     "hwy_comm_unique_id", "hwy_comm_init", "hwy_gather", "hwy_comm_destroy",
 ]
 
@@ -79,6 +79,8 @@ def load() -> C.CDLL:
     lib.hwy_debug_math.argtypes = [vp, i32, vp, vp, C.c_int64]
     lib.hwy_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), i32, i32]
     lib.hwy_get_counters.restype = C.c_int
+    lib.hwy_set_block_order.argtypes = [vp, vp]
+    lib.hwy_set_block_order.restype = C.c_int
     lib.hwy_comm_unique_id.argtypes = [vp]
     lib.hwy_comm_init.argtypes = [vp, vp, i32, i32]
     lib.hwy_gather.argtypes = [vp, vp, vp, C.c_size_t, i32]

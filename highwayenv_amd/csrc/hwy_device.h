@@ -144,6 +144,7 @@ struct StepParams {
   uint8_t *info_crashed;   // [E][A] or nullptr
   const uint8_t *reset_mask;  // reset kernel only: [E] or nullptr (= all)
   const uint64_t *reset_seeds;  // reset kernel only: [E] or nullptr (= base_seed + e)
+  const uint16_t *block_env;    // one-wavefront step kernel: environment of workgroup b (hwy_set_block_order), or nullptr (= b)
   ResetParams rp;
 };
 

@@ -41,6 +41,7 @@ struct hwy_engine {
   int32_t *d_shadow_packed = nullptr, *d_shadow_meta = nullptr;
   long long *d_shadow_route = nullptr;
   unsigned long long *d_counters = nullptr;  // [HWY_CTR_COUNT] (hwy_get_counters)
+  uint16_t *d_block_env = nullptr;           // [E] hwy_set_block_order (nullptr: workgroup b steps environment b)
   double *d_time = nullptr;
   uint8_t *d_done = nullptr;
   uint32_t *d_episode = nullptr;
@@ -188,6 +189,7 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.rp = eng->rp;
   p.grid_ws = eng->d_grid_ws;
   p.prio_shift = eng->prio_shift;
+  p.block_env = eng->d_block_env;
 }
 
 static bool is_ix(const hwy_engine *eng) { return eng->cfg.scenario == HWY_SCENARIO_INTERSECTION; }
@@ -404,7 +406,7 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out, eng->d_roll,
                   eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet,
-                  eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta, eng->d_counters};
+                  eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta, eng->d_counters, eng->d_block_env};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   if (eng->h_pinned) (void)hipHostFree(eng->h_pinned);
   if (eng->own_stream && eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -849,6 +851,32 @@ extern "C" int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32
   if (reset) HWY_HIP(eng, hipMemsetAsync(eng->d_counters, 0, sizeof host, eng->stream));
   HWY_HIP(eng, hipStreamSynchronize(eng->stream));
   for (int k = 0; k < n && k < HWY_CTR_COUNT; ++k) out[k] = host[k];
+  return HWY_OK;
+}
+
+extern "C" int hwy_set_block_order(hwy_engine *eng, const int32_t *env_of_block) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  HWY_HIP(eng, hipSetDevice(eng->device));
+  const int E = eng->cfg.num_envs;
+  if (!env_of_block) {  // back to the identity
+    HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+    if (eng->d_block_env) { HWY_HIP(eng, hipFree(eng->d_block_env)); eng->d_block_env = nullptr; }
+    return HWY_OK;
+  }
+  if (eng->cfg.scenario != HWY_SCENARIO_HIGHWAY || eng->cfg.num_vehicles > 64 || eng->force_block_kernel || E > 65535)
+    return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_block_order: only the one-wavefront step kernel (highway scenario, N <= 64, "
+                                          "at most 65535 environments) takes a workgroup order");
+  std::vector<uint8_t> seen((size_t)E, 0);
+  std::vector<uint16_t> tab((size_t)E);
+  for (int b = 0; b < E; ++b) {
+    const int32_t e = env_of_block[b];
+    if (e < 0 || e >= E || seen[(size_t)e]) return fail(eng, HWY_ERR_INVALID_ARG, "hwy_set_block_order: not a permutation of 0 .. num_envs - 1");
+    seen[(size_t)e] = 1;
+    tab[(size_t)b] = (uint16_t)e;
+  }
+  if (!eng->d_block_env) HWY_HIP(eng, hipMalloc((void **)&eng->d_block_env, (size_t)E * sizeof(uint16_t)));
+  HWY_HIP(eng, hipMemcpyAsync(eng->d_block_env, tab.data(), (size_t)E * sizeof(uint16_t), hipMemcpyHostToDevice, eng->stream));
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));  // (tab is a local)
   return HWY_OK;
 }
 

@@ -689,7 +689,10 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
 template <int WPE, bool FULL_SCAN>
 __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams p) {
   __shared__ WaveShared sh;
-  wave_policy_step<FULL_SCAN>(p, sh, blockIdx.x, blockIdx.x);
+  // which environment a workgroup steps is free (environments are independent): the dispatcher places workgroup b on the same
+  // SIMD launch after launch, so a table b -> environment is a PLACEMENT of the environments on the SIMDs (hwy_set_block_order)
+  const int e = p.block_env ? (int)p.block_env[blockIdx.x] : (int)blockIdx.x;
+  wave_policy_step<FULL_SCAN>(p, sh, e, e);
 }
 
 // hwy_rollout_device: p.k_steps consecutive policy steps of every environment in ONE launch (actions of step k in row

@@ -174,6 +174,17 @@ class Engine:
         self._check(self._lib.hwy_get_counters(self._h, out, 8, int(bool(reset))))
         return {k: int(out[i]) for i, k in enumerate(self.COUNTERS)}
 
+    def set_block_order(self, env_of_block=None):
+        """hwy_set_block_order: workgroup b of the following step launches steps environment ``env_of_block[b]`` (a permutation;
+        None = identity).  A placement of the environments on the SIMDs -- never changes a result."""
+        if env_of_block is None:
+            self._check(self._lib.hwy_set_block_order(self._h, None))
+            return
+        a = np.ascontiguousarray(env_of_block, np.int32)
+        if a.shape != (self.E,):
+            raise ValueError(f"env_of_block must have shape ({self.E},)")
+        self._check(self._lib.hwy_set_block_order(self._h, _ptr(a)))
+
     # -- multi-GPU: RCCL gather behind the ABI (one process per GPU) -----------------------------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -413,6 +413,15 @@ enum { HWY_CTR_IX_SPAWNS = 0, HWY_CTR_IX_SPAWNS_DROPPED = 1, HWY_CTR_COUNT = 8 }
 int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32_t reset);
 
 /*
+ * Placement of the environments on the GPU's SIMDs (tuning; never changes a result).  Environments are independent
+ * (the reference steps them in separate processes: scripts/sb3_highway_ppo.py:16-18), so WHICH workgroup of a launch steps
+ * environment e is free: with env_of_block[b] = e (host pointer, a permutation of 0 .. num_envs - 1) workgroup b of every
+ * following hwy_step* / hwy_step_device launch steps environment e; all inputs and outputs stay indexed by environment.
+ * NULL restores the identity.  One-wavefront step kernel only (HWY_SCENARIO_HIGHWAY, num_vehicles <= 64); synchronises.
+ */
+int hwy_set_block_order(hwy_engine *eng, const int32_t *env_of_block);
+
+/*
  * Self-test hook: evaluate one of the step kernel's own math routines (csrc/hwy_math.h -- bounded-domain
  * log / exp / sincos / asin, Newton-refined v_rcp_f64 / v_rsq_f64, floor-mod angle wrap) on n doubles on
  * the device.  Host pointers.  op: 0 log_pos, 1 exp_bounded, 2 sin, 3 cos, 4 asin_bounded, 5 fast_rcp, 8 atan_fd,

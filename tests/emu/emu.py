@@ -25,7 +25,28 @@ _LIB = os.path.join(_HERE, "_build", "libhwy_emu.so" if not _EXTRA else
 _lib = None
 
 
+def compile_emulator(src_cpp: str, out_lib: str, extra=()) -> None:
+    """One emulator library from `src_cpp` (emu_engine.cpp of this tree, or of a mutated copy: tests/test_mutations.py)."""
+    # like the kernel build (build.FP_CONTRACT).  "on" = contraction by source expression is a FRONT-END rule: the emulator
+    # is compiled by the clang the kernels are compiled by (ROCm's), so the same a*b+c fuse here and on the GPU; g++ 11
+    # treats -ffp-contract=on as off and is only the fallback (then: fuse where it likes, same tolerances).
+    clang = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
+    cxx = "g++"
+    if build_flags.FP_CONTRACT == "off":
+        contract = ["-ffp-contract=off"]
+    elif build_flags.FP_CONTRACT == "on" and os.path.exists(clang):
+        cxx, contract = clang, ["-ffp-contract=on", "-mfma"]
+    else:
+        contract = ["-ffp-contract=fast", "-mfma"]
+    tmp = f"{out_lib}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
+    subprocess.run([cxx, "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", *contract, *extra, "-o", tmp, src_cpp],
+                   check=True, capture_output=True)
+    os.replace(tmp, out_lib)
+
+
 def build(force: bool = False) -> str:
+    if os.environ.get("HWY_EMU_LIB"):  # a prebuilt (mutated) emulator: tests/test_mutations.py
+        return os.environ["HWY_EMU_LIB"]
     srcs = [os.path.join(_HERE, "emu_engine.cpp"), os.path.join(_HERE, "hip_emu.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave.h"),
@@ -37,29 +58,14 @@ def build(force: bool = False) -> str:
     stale = not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs)
     if force or stale:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-        tmp = f"{_LIB}.{os.getpid()}.tmp"   # pytest-xdist workers may build at once: never expose a half-written library
-        # like the kernel build (build.FP_CONTRACT).  "on" = contraction by source expression is a FRONT-END rule: the emulator
-        # is compiled by the clang the kernels are compiled by (ROCm's), so the same a*b+c fuse here and on the GPU; g++ 11
-        # treats -ffp-contract=on as off and is only the fallback (then: fuse where it likes, same tolerances).
-        clang = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang++")
-        cxx = "g++"
-        if build_flags.FP_CONTRACT == "off":
-            contract = ["-ffp-contract=off"]
-        elif build_flags.FP_CONTRACT == "on" and os.path.exists(clang):
-            cxx, contract = clang, ["-ffp-contract=on", "-mfma"]
-        else:
-            contract = ["-ffp-contract=fast", "-mfma"]
-        subprocess.run([cxx, "-std=c++20", "-O1", "-pthread", "-fPIC", "-shared", *contract, *_EXTRA,
-                        "-o", tmp, srcs[0]], check=True, capture_output=True)
-        os.replace(tmp, _LIB)
+        compile_emulator(srcs[0], _LIB, _EXTRA)
     return _LIB
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB)
+        _lib = C.CDLL(build())
         _lib.emu_config_size.restype = C.c_size_t
         assert _lib.emu_config_size() == C.sizeof(_abi.HwyConfig)
     return _lib
@@ -113,6 +119,9 @@ class EmuEngine:
             self.shadow[3][...] = -1
         self.autoreset = (int(enabled), int(base_seed), float(ego_spacing), float(vehicles_density), int(initial_lane_id))
 
+    def set_block_order(self, env_of_block=None):
+        self._block_env = None if env_of_block is None else np.ascontiguousarray(env_of_block, np.uint16)
+
     def _run(self, mode, n_frames, actions):
         E, A = self.E, self.A
         acts = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.int32).reshape(E, A))
@@ -125,6 +134,8 @@ class EmuEngine:
         s = _abi.state_struct(self.st)
         ar = self.autoreset
         self._bind_shadow()
+        be = getattr(self, "_block_env", None)
+        lib().emu_set_block_order(None if be is None else be.ctypes.data_as(C.c_void_p))
         rc = lib().emu_run(C.byref(self.cfg), C.byref(s), _p(self.done, C.c_uint8), _p(self.episode, C.c_uint32),
                            C.c_int(mode), C.c_int(n_frames), _p(acts, C.c_int32), _p(obs, C.c_float),
                            _p(reward, C.c_double), _p(term, C.c_uint8), _p(trunc, C.c_uint8), _p(speed, C.c_double),

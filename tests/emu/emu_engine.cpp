@@ -69,6 +69,8 @@ bool g_force_block = false;
 int g_k_steps = 0;  // > 0: the next STEP dispatch of the one-wavefront kernel is a multi-step launch (hwy_rollout_device)
 const hwy_config *g_cfg = nullptr;  // config of the call being dispatched (road-network scenarios need the lane table)
 hwy_state *g_st = nullptr;          // host state of the call (intersection scenario: route / road_steps planes)
+// hwy_set_block_order: environment of workgroup b in the one-wavefront step kernel (nullptr: b)
+static const uint16_t *g_block_env = nullptr;
 // intersection scenario, next-episode pre-warming: shadow planes owned by the Python side (emu_set_shadow)
 double *g_shadow_f64 = nullptr;
 int32_t *g_shadow_packed = nullptr, *g_shadow_meta = nullptr;
@@ -213,6 +215,7 @@ int emu_run(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *episo
   p.rp.fast = (cfg->flags & HWY_C_EGO_ONLY_COLLISIONS) ? 1 : 0;
   p.rp.base_seed = base_seed;
   p.grid_ws = grid_ws_for(cfg);
+  p.block_env = g_block_env;
   p.actions = actions; p.obs = obs; p.reward = reward; p.terminated = term; p.truncated = trunc;
   p.info_speed = speed; p.info_crashed = crashed;
   if (mode == 2) {
@@ -256,6 +259,8 @@ int emu_reset(const hwy_config *cfg, hwy_state *st, uint8_t *done, uint32_t *epi
 }
 
 void emu_force_block_kernel(int on) { g_force_block = on != 0; }
+
+void emu_set_block_order(const uint16_t *env_of_block) { g_block_env = env_of_block; }
 
 void emu_set_shadow(double *f64, int32_t *packed, long long *route, int32_t *meta) {
   g_shadow_f64 = f64; g_shadow_packed = packed; g_shadow_route = route; g_shadow_meta = meta;

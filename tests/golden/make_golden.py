@@ -149,7 +149,9 @@ SCENARIOS = [
 ]
 
 
-def run_scenario(sc: dict) -> dict:
+def run_scenario(sc: dict, only_envs=None) -> dict:
+    """`only_envs`: simulate only these env indices (tests/test_fixture_freshness.py regenerates env 0 of every fixture); the action
+    table is drawn for all of them either way, so an env's trajectory does not depend on which others are simulated."""
     seeds, steps = sc["seeds"], sc["steps"]
     E = len(seeds)
     if sc["action_seed"] is None:
@@ -164,6 +166,8 @@ def run_scenario(sc: dict) -> dict:
     per_env = []
     frames_for = sc["frames_for"]
     for e, seed in enumerate(seeds):
+        if only_envs is not None and e not in only_envs:
+            continue
         env = sc["cls"](dict(sc["config"]))
         obs0, _ = env.reset(seed=int(seed))
         T = int(env.config["simulation_frequency"] // env.config["policy_frequency"])
@@ -191,6 +195,7 @@ def run_scenario(sc: dict) -> dict:
         rec["T"] = T
         rec["cfg"] = dict(env.config)
         per_env.append(rec)
+    E = len(per_env)
     cfg = per_env[0]["cfg"]
     N = len(per_env[0]["init"]["x"])
     out["meta"] = np.asarray([E, N, per_env[0]["T"], steps, frames_for], np.int64)

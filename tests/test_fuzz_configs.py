@@ -20,6 +20,9 @@ CHUNKS = range(int(os.environ.get("HWY_FUZZ_FIRST", "0")), int(os.environ.get("H
 # whole-step coverage of the intersection fuzz (printed per chunk): the rest are env-steps in which some car is below 1 m/s.
 # A per-chunk statistic over 6 random configurations: of 150 chunks on the GPU one fell to 38.8 %, the others stay above 40 %.
 INTERSECTION_WHOLE_STEP_FLOOR = 0.33
+# per-chunk ceilings of the counted knife-edge cases of the intersection fuzz (4 configurations x 12 envs x 10 steps x 15 frames):
+# measured maxima + a small margin, see the assertion at the end of the test
+EDGE_MAX, TOUCH_MAX, LANE_FRAMES_MAX, FLIP_MAX, CUT_MAX = 4, 6, 12, 8, 12
 
 
 def random_config(rng):
@@ -156,18 +159,20 @@ def test_random_intersection_configurations_vs_oracle(chunk):
     """Device-traffic engine drives the episodes (reset, clear, spawn, auto-reset on Philox); every step is replayed from its
     own state on a host-traffic engine and on the oracle.  Two comparisons, and the fraction each covers is PRINTED and asserted:
 
-    * the FIRST FRAME of every env-step (meta-action, Road.act, Road.step incl. collisions) at 1e-9 -- every environment,
-      whatever its speeds and wrecks;
-    * the WHOLE policy step (15 frames + observation + reward + termination) wherever 15 frames of one trajectory are
-      comparable between two libms: no vehicle below 1 m/s (steering_control divides by not_zero(speed) twice, so last-bit
-      differences grow 1e2..1e4 x per frame there -- at an intersection cars yield and queue, so this is the bulk of the
-      exclusions), no lane-index knife edge, and -- steps WITH a collision are compared like any other -- no push on the
-      knife edge (|d.normal| < 1e-9)."""
+    * EVERY FRAME of every live env-step, teacher-forced (meta-action on the first, Road.act, RegulatedRoad.step incl. collisions):
+      frame k of engine and oracle both start from the engine's state after frame k - 1, compared at 1e-9 -- every environment,
+      whatever its speeds and wrecks; only a collision push on the knife edge (|d.normal| < 1e-9) takes an environment's frame out;
+    * the WHOLE policy step free-running (15 frames + observation + reward + termination) wherever 15 frames of one trajectory
+      are comparable between two arithmetics: no vehicle below 1 m/s (steering_control divides by not_zero(speed) twice, so
+      last-bit differences grow 1e2..1e4 x per frame there -- at an intersection cars yield and queue, so this is the bulk of
+      the exclusions), no lane-index knife edge, and -- steps WITH a collision are compared like any other -- no push on the
+      knife edge.  What this leaves out is covered by the first comparison, frame by frame."""
     from oracle import oracle, oracle_ix
     from tests.backends import make_engine
     from tests.golden_util import KNIFE, assert_obs_close, ix_oracle_config, ix_oracle_state
     rng = np.random.default_rng(5000 + chunk)
     tot_steps = tot_checked = tot_frames = tot_col = tot_col_full = tot_img_cells = tot_edge = tot_touch = 0
+    tot_all_frames = tot_live_frames = tot_lane_frames = tot_flip = tot_cut = 0
     for k in range(4):
         cfg = random_intersection_config(rng)
         E = 12
@@ -176,6 +181,7 @@ def test_random_intersection_configurations_vs_oracle(chunk):
             ch = _abi.make_config(dict(cfg, host_traffic=True), E, scenario="intersection")
             dev, host = make_engine(BACKEND, c), make_engine(BACKEND, ch)
             oc = ix_oracle_config(dict(cfg, host_traffic=True), ch, E)
+            T_frames = int(c.frames_per_step)
             dev.reset(base_seed=chunk * 1000 + k)
             dev.set_autoreset(True, base_seed=chunk * 1000 + k)
             checked = n_flip = n_cut = n_live = n_edge = 0
@@ -185,27 +191,49 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                 st = dev.get_state()
                 acts = rng.integers(0, 3, size=(E, c.num_agents)).astype(np.int32)
                 pres = (st["flags"] & _abi.F_ABSENT) == 0
-                # -- first frame, every environment ------------------------------------------------------------------
-                ost1 = ix_oracle_state(st, ch)
+                # -- every frame of the step, every live environment, teacher-forced ------------------------------------
+                # frame k starts from the ENGINE's state after frame k - 1 (read back through hwy_get_state), handed to the oracle in
+                # its own layout: both advance ONE frame from identical inputs, so no difference is carried from frame to frame and
+                # the slow, queueing, knife-edge env-steps that the whole-step comparison below has to leave out are compared too,
+                # frame by frame, at 1e-9 (positions, headings, speeds, signed impacts; pending-impact and yielding bits exact)
                 host.set_state(st)
-                host.step_frames(acts, 1)
-                with oracle.impact_margins(oc) as m1:
-                    oracle_ix.frames(oc, ost1, acts, 1)
-                g1 = host.get_state()
-                fine = ~done_prev & (m1.margin.min(1) >= 1e-9)
-                for f in ("x", "y", "heading", "speed"):
-                    np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
-                for f in ("impact_x", "impact_y"):  # signed
-                    np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame 0: {f}")
-                # two wrecks resting EXACTLY touching (flag_margin < KNIFE: the `will_intersect` of that pair hinges on a distance of
-                # ~1e-16, emulator fuzz chunk 30103): whether the pair gets its ~0 translation as a pending impact is decided by the
-                # last bit -- the bit is compared on every other slot, such slots are counted (the translations above agree: both ~0)
-                touching = np.asarray(m1.flag_margin) < KNIFE
-                hi_g, hi_o = (g1["flags"] & _abi.F_HAS_IMPACT) != 0, ost1["has_impact"] != 0
-                np.testing.assert_array_equal((hi_g | touching)[fine], (hi_o | touching)[fine])
-                tot_touch += int((touching & (hi_g != hi_o))[fine].sum())
-                np.testing.assert_array_equal(((g1["flags"] & _abi.F_YIELDING) != 0)[fine], (ost1["is_yielding"] != 0)[fine])
-                tot_frames += int(fine.sum())
+                st_k = st
+                for fr in range(T_frames):
+                    ost1 = ix_oracle_state(st_k, ch)
+                    host.step_frames(acts if fr == 0 else None, 1)
+                    with oracle.impact_margins(oc) as m1:
+                        oracle_ix.frames(oc, ost1, acts if fr == 0 else None, 1)
+                    g1 = host.get_state()
+                    fine = ~done_prev & (m1.margin.min(1) >= 1e-9)
+                    for f in ("x", "y", "heading", "speed"):
+                        np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame {fr}: {f}")
+                    # two wrecks resting EXACTLY touching (flag_margin < KNIFE: the `will_intersect` of that pair hinges on a distance
+                    # of ~1e-16, emulator fuzz chunk 30103): whether the pair gets its ~0 translation as a pending impact -- in place of
+                    # the translation another pair gave that slot earlier in the loop, "last pair wins" -- is decided by the last bit
+                    # (fuzz chunks 1, 11, 23 from frame 1 on: resting pile-ups).  Bit and translation are compared on every other slot,
+                    # such slots are counted
+                    touching = np.asarray(m1.flag_margin) < KNIFE
+                    sure = fine[:, None] & ~touching
+                    for f in ("impact_x", "impact_y"):  # signed
+                        np.testing.assert_allclose(g1[f][sure], ost1[f][sure], rtol=0, atol=1e-9, err_msg=f"step {t} frame {fr}: {f}")
+                    hi_g, hi_o = (g1["flags"] & _abi.F_HAS_IMPACT) != 0, ost1["has_impact"] != 0
+                    np.testing.assert_array_equal((hi_g | touching)[fine], (hi_o | touching)[fine], err_msg=f"step {t} frame {fr}: pending impacts")
+                    tot_touch += int((touching & ((hi_g != hi_o) | (np.abs(g1["impact_x"] - ost1["impact_x"]) > 1e-9)
+                                                  | (np.abs(g1["impact_y"] - ost1["impact_y"]) > 1e-9)))[fine].sum())
+                    np.testing.assert_array_equal(((g1["flags"] & _abi.F_YIELDING) != 0)[fine], (ost1["is_yielding"] != 0)[fine],
+                                                  err_msg=f"step {t} frame {fr}: is_yielding")
+                    np.testing.assert_array_equal(((g1["flags"] & _abi.F_CRASHED) != 0)[fine], (ost1["crashed"] != 0)[fine],
+                                                  err_msg=f"step {t} frame {fr}: crashed")
+                    # lane indices: exact wherever the oracle's own closest-lane decision is not a tie of the last bit (three lanes
+                    # leave an "ir" node together: see `flip` below) -- counted, the next frame starts from the engine's index
+                    pres_k = (g1["flags"] & _abi.F_ABSENT) == 0
+                    lane_diff = (pres_k & (g1["lane"] != ost1["lane"]))[fine]
+                    tot_lane_frames += int(lane_diff.any(1).sum())
+                    if fr == 0:
+                        tot_frames += int(fine.sum())
+                    tot_all_frames += int(fine.sum())
+                    tot_live_frames += int((~done_prev).sum())
+                    st_k = g1
                 # -- the whole policy step -----------------------------------------------------------------------------
                 ost = ix_oracle_state(st, ch)
                 host.set_state(st)
@@ -295,8 +323,9 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                 d_obs, d_rew, d_term, d_trunc, _ = dev.step(acts)
                 np.testing.assert_array_equal(d_term[ok], h_term[ok])  # same dynamics with device traffic switched on
                 done_prev = d_term | d_trunc
-            assert n_flip <= 0.05 * checked + 2 and n_cut <= 0.05 * checked * c.num_agents + 2 and n_edge <= 0.05 * checked + 2
             tot_edge += n_edge
+            tot_flip += n_flip
+            tot_cut += n_cut
             tot_col_full -= n_edge
             tot_steps += n_live
             tot_checked += checked
@@ -305,12 +334,17 @@ def test_random_intersection_configurations_vs_oracle(chunk):
         except AssertionError as ex:
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
     frac = tot_checked / max(tot_steps, 1)
-    print(f"\nintersection fuzz chunk {chunk}: {tot_steps} live env-steps; first frame compared at 1e-9 on {tot_frames} "
-          f"({100.0 * tot_frames / max(tot_steps, 1):.1f} %), whole step on {tot_checked} ({100.0 * frac:.1f} %); "
-          f"{tot_col} fast-enough steps with a wreck, {tot_col_full} of them in full; as_image cells off by one: {tot_img_cells}"
-          + (f"; {tot_edge} env-steps diverged on a touching pair's knife edge (tolerated)" if tot_edge else "")
-          + (f"; {tot_touch} first-frame pending-impact bits of exactly touching wrecks differed (tolerated)" if tot_touch else ""))
-    assert tot_touch <= 0.02 * tot_frames + 2
-    assert tot_frames >= 0.97 * tot_steps, "the first-frame comparison must cover (nearly) every live env-step"
+    print(f"\nintersection fuzz chunk {chunk}: {tot_steps} live env-steps = {tot_live_frames} frames; teacher-forced frames compared at "
+          f"1e-9: {tot_all_frames} ({100.0 * tot_all_frames / max(tot_live_frames, 1):.2f} %; first frames {tot_frames}); whole step on "
+          f"{tot_checked} ({100.0 * frac:.1f} %); {tot_col} fast-enough steps with a wreck, {tot_col_full} of them in full; "
+          f"as_image cells off by one: {tot_img_cells}; tolerated and counted: {tot_edge} env-steps diverged on a touching pair's knife "
+          f"edge, {tot_touch} pending-impact bits of exactly touching wrecks, {tot_lane_frames} frames with a last-bit lane index, "
+          f"{tot_flip} lane-index flips and {tot_cut} queue-order cuts in whole steps")
+    # the tolerated knife-edge cases, bounded by what 600 chunks measured on the GPU and the emulator (the worst chunk had 3 / 2 / 4 /
+    # 6 / 9: profiles/r04_history.md) -- a defect in the pile-up or ordering paths shows up as tens per chunk (tests/test_mutations.py)
+    if os.environ.get("HWY_FUZZ_CALIBRATE") != "1":  # (calibration runs only print the counts: tools/gpu_fuzz.sh)
+        assert tot_edge <= EDGE_MAX and tot_touch <= TOUCH_MAX and tot_lane_frames <= LANE_FRAMES_MAX, (tot_edge, tot_touch, tot_lane_frames)
+        assert tot_flip <= FLIP_MAX and tot_cut <= CUT_MAX, (tot_flip, tot_cut)
+    assert tot_all_frames >= 0.985 * tot_live_frames, "the teacher-forced comparison must cover (nearly) every live frame"
     assert frac >= INTERSECTION_WHOLE_STEP_FLOOR, f"only {100 * frac:.1f} % of the env-steps were compared as whole steps"
     assert tot_col_full >= 0.9 * tot_col - 1

@@ -154,6 +154,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
     eng.set_state(st)
     rng = np.random.default_rng(seed)
     n_term = n_crash = n_col = n_full = n_edge = 0
+    edge_log = []
     next_seed = 10_000_000 * seed
     drift = np.zeros(E, np.int64)   # steps since the env was last synchronised
     for t in range(steps):
@@ -189,10 +190,11 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
                     assert_obs_close(obs[sel], o2[sel], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
                     np.testing.assert_allclose(reward[sel], r2[sel], rtol=0, atol=1e-9, err_msg=what)
                     assert_net_state_close(_sub(got, sel), _sub(ref, sel), atol=atol, what=what, signed=(m.margin >= knife[:, None])[sel])
-                except AssertionError:
+                except AssertionError as ex:
                     if strict:
                         raise
                     n_edge += 1
+                    edge_log.append(f"step {t} env {e}: {str(ex).strip().splitlines()[0:3]}")
         n_term += int(term.sum())
         n_crash += int(i2["crashed"].any(1).sum())
         redo = term | trunc | wreck
@@ -215,7 +217,9 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
     eng.close()
     print(f"\n{scenario} [{backend}]: {n_col} first-collision env-steps, {n_full - n_edge} compared in full"
           + (f"; {n_edge} more diverged on a touching pair's knife edge (tolerated)" if n_edge else ""))
-    assert n_edge <= 2 + n_full // 10, "knife-edge divergences must stay rare"
+    # the budget is the measured rate, not a percentage: 9 such env-steps in 40 000 fuzz configurations, i.e.
+    # none or one per call -- a regression in the collision path shows up as several (tests/test_mutations.py)
+    assert n_edge <= 1, "knife-edge divergences must stay rare:\n" + "\n".join(edge_log)
     return n_term, n_crash
 
 
