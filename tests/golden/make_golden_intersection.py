@@ -222,7 +222,7 @@ def run_scenario(sc: dict, only_envs=None) -> dict:
         sc.get("cls"), IntersectionEnv)
     multi = cls is MultiAgentIntersectionEnv
     A = int(dict(cls.default_config(), **sc["config"])["controlled_vehicles"])
-    r_max = R_MAX_MA if multi else R_MAX
+    r_max = int(sc.get("r_max", R_MAX_MA if multi else R_MAX))   # (route slots recorded per vehicle)
     rng = np.random.default_rng(sc["action_seed"])
     p = sc.get("action_p")
     actions = (rng.choice(3, size=(steps, E, A), p=p) if p is not None

@@ -13,10 +13,9 @@ from oracle import oracle
 from tests.golden_util import ALL, WITH_FRAMES, Golden, assert_state_close
 
 
-@pytest.mark.parametrize("name", WITH_FRAMES)
-def test_oracle_teacher_forced_frames(name):
+def check_teacher_forced_frames(g):
     """Every single frame, started from the reference's own state: Road.act + Road.step."""
-    g = Golden(name)
+    name = g.name
     Ef = g.frames_for
     cfg = g.hwy_config(Ef)
     envs = slice(0, Ef)
@@ -32,10 +31,14 @@ def test_oracle_teacher_forced_frames(name):
             assert_state_close(st, g.state("frame", k), atol=1e-10, what=f"{name} step {step} frame {fr}")
 
 
-@pytest.mark.parametrize("name", ALL)
-def test_oracle_free_running_steps(name):
+@pytest.mark.parametrize("name", WITH_FRAMES)
+def test_oracle_teacher_forced_frames(name):
+    check_teacher_forced_frames(Golden(name))
+
+
+def check_free_running_steps(g):
     """Whole episodes from reset state: obs / reward / terminated / truncated / info / state per step."""
-    g = Golden(name)
+    name = g.name
     cfg = g.hwy_config()
     st = g.state("init")
     np.testing.assert_allclose(oracle.observe(cfg, st)[:, 0], g.z["obs0"], rtol=0, atol=1e-6)
@@ -49,6 +52,11 @@ def test_oracle_free_running_steps(name):
         np.testing.assert_allclose(info["speed"][:, 0], g.z["info_speed"][t], rtol=0, atol=1e-9, err_msg=what)
         np.testing.assert_array_equal(info["crashed"][:, 0], g.z["info_crashed"][t].astype(bool), err_msg=what)
         assert_state_close(st, g.state("step", t), atol=1e-8, what=what)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_oracle_free_running_steps(name):
+    check_free_running_steps(Golden(name))
 
 
 def test_oracle_known_answer_vector():

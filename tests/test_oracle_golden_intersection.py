@@ -18,12 +18,11 @@ def _sub(st, sel):
     return {k: np.ascontiguousarray(v[sel]) for k, v in st.items()}
 
 
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES + INTERSECTION_CRASH)
-def test_oracle_teacher_forced_frames(name):
+def check_teacher_forced_frames(g, coverage=True):
     """Every single frame (meta-action on the first one, Road.act, RegulatedRoad.step incl. the regulation every
     7th frame), started from the reference's own state.  Impacts are compared SIGNED wherever the collision is well
     conditioned (oracle.impact_margins >= KNIFE)."""
-    g = GoldenIntersection(name)
+    name = g.name
     ix = g.ix
     Ef = g.frames_for
     cfg = g.ix_config(Ef)
@@ -44,16 +43,20 @@ def test_oracle_teacher_forced_frames(name):
             want = g.state("frame", k)
             assert_ix_state_close(st, want, atol=1e-10, what=f"{name} step {step} frame {fr}", signed=m.margin >= KNIFE)
             n_yield += int(want["is_yielding"].sum())
-    assert n_yield > 0  # the fixtures do exercise the regulation
+    assert n_yield > 0 or not coverage  # the fixtures do exercise the regulation
 
 
-@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS + INTERSECTION_CRASH)
-def test_oracle_steps_observation_reward_and_clear_spawn(name):
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA_FRAMES + INTERSECTION_CRASH)
+def test_oracle_teacher_forced_frames(name):
+    check_teacher_forced_frames(GoldenIntersection(name))
+
+
+def check_steps_observation_reward_and_clear_spawn(g, coverage=True):
     """Whole policy steps from the reference's state at the start of each step: state before clear/spawn, obs, reward,
     terminated / truncated, info; then _clear_vehicles + _spawn_vehicle replayed on the recorded draws.  Steps WITH a
     collision are compared like any other (terminal observation and reward included, impacts signed) unless one of the
     collisions is on the knife edge (oracle.impact_margins < KNIFE)."""
-    g = GoldenIntersection(name)
+    name = g.name
     ix = g.ix
     cfg = g.ix_config()
     steps0 = g.z["road_steps0"]
@@ -64,6 +67,7 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
         st = g.state("init") if t == 0 else g.state("next", t - 1)
         st["road_steps"][...] = steps0 + t * g.T
         st["time"][...] = float(t)
+        v0 = st["speed"].copy()
         with oracle.impact_margins(cfg) as m:
             obs, reward, term, trunc, info = ix.step(cfg, st, g.actions[t])
         want = g.state("step", t)
@@ -72,7 +76,10 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
         clean = live & (m.margin.min(1) >= KNIFE)
         n_wreck += int((live & wreck).sum())
         n_wreck_full += int((clean & wreck).sum())
-        assert_ix_state_close(_sub(st, clean), _sub(want, clean), atol=1e-8, what=what, signed=(m.margin >= KNIFE)[clean])
+        # (1e-8 after 15 free-running frames; 1e-6 for a car below 2 m/s at either end of the step: steering_control divides by
+        #  not_zero(speed) twice -- live-reference case 229: 2e-8 on a car pulling away at 1 m/s)
+        assert_ix_state_close(_sub(st, clean), _sub(want, clean), atol=1e-8, what=what, signed=(m.margin >= KNIFE)[clean],
+                              slow_atol=1e-6, slow_start=v0[clean])
         np.testing.assert_array_equal(term[live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(info["crashed"][live], g.z["info_crashed"][t].astype(bool)[live], err_msg=what)
@@ -95,10 +102,15 @@ def test_oracle_steps_observation_reward_and_clear_spawn(name):
             after = set(nxt["vid"][e][nxt["present"][e] != 0].tolist())
             n_cleared += len(before - after)
         live &= ~g.z["terminated"][t].astype(bool)
-    assert n_spawned > 0 and (n_cleared > 0 or name != "intersection_dense")
+    assert not coverage or (n_spawned > 0 and (n_cleared > 0 or name != "intersection_dense"))
     print(f"\n{name}: {n_wreck} env-steps with a wreck on the road, {n_wreck_full} compared in full")
     if name in INTERSECTION_CRASH:
         assert n_wreck_full >= 0.9 * n_wreck > 0
+
+
+@pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_GRID + INTERSECTION_MA + INTERSECTION_INTENTIONS + INTERSECTION_CRASH)
+def test_oracle_steps_observation_reward_and_clear_spawn(name):
+    check_steps_observation_reward_and_clear_spawn(GoldenIntersection(name))
 
 
 @pytest.mark.parametrize("name", INTERSECTION + INTERSECTION_MA)

@@ -42,11 +42,10 @@ def test_reset_replays_the_reference_stream(name):
             np.testing.assert_array_equal(st[k][e][a], want[k][e][b], err_msg=f"{name} env {e}: {k}")
 
 
-@pytest.mark.parametrize("name", MERGE + MERGE_CRASH)
-def test_oracle_teacher_forced_frames(name):
+def check_teacher_forced_frames(g):
     """Every single frame, started from the reference's own state: Road.act + Road.step.  Impacts are compared SIGNED wherever
     the collision is well conditioned (oracle.impact_margins >= KNIFE), incl. the vehicle-vs-Obstacle branch."""
-    g = GoldenMerge(name)
+    name = g.name
     Ef = g.frames_for
     cfg = g.hwy_config(Ef)
     envs = slice(0, Ef)
@@ -61,11 +60,15 @@ def test_oracle_teacher_forced_frames(name):
                                    signed=m.margin >= KNIFE)
 
 
-@pytest.mark.parametrize("name", MERGE + MERGE_GRID + MERGE_CRASH)
-def test_oracle_free_running_steps(name):
+@pytest.mark.parametrize("name", MERGE + MERGE_CRASH)
+def test_oracle_teacher_forced_frames(name):
+    check_teacher_forced_frames(GoldenMerge(name))
+
+
+def check_free_running_steps(g):
     """Whole episodes from the reset state, compared while the episode is live (up to and including the
     terminal step; see DESIGN.md section 4 on post-termination wrecks)."""
-    g = GoldenMerge(name)
+    name = g.name
     cfg = g.hwy_config()
     st = g.state("init")
     np.testing.assert_allclose(oracle.observe(cfg, st), g.z["obs0"], rtol=0, atol=1e-6)
@@ -76,6 +79,10 @@ def test_oracle_free_running_steps(name):
         what = f"{name} step {t}"
         np.testing.assert_array_equal(term[live], g.z["terminated"][t].astype(bool)[live], err_msg=what)
         np.testing.assert_array_equal(trunc[live], g.z["truncated"][t].astype(bool)[live], err_msg=what)
+        # a wreck resting EXACTLY touching a third body (flag_margin < KNIFE: whether that pair "will intersect", and with its ~0
+        # translation replaces a real pending impact, hinges on the last bit -- tests/test_net_parity.py): a free-running episode
+        # leaves the comparison there (live-reference case 23; every frame of it is still pinned teacher-forced at 1e-10)
+        live = live & ~(np.asarray(m.flag_margin) < KNIFE).any(1)
         np.testing.assert_allclose(obs[live], g.z["obs"][t][live], rtol=0, atol=1e-6, err_msg=what)
         # the reference evaluates `action in [0, 2]` on the joint action tuple (never true) when A > 1
         ok = live & ((g.A == 1) | ~np.isin(g.actions[t, :, 0], [0, 2]))
@@ -87,6 +94,12 @@ def test_oracle_free_running_steps(name):
         assert_net_state_close(sub(st), sub(want), atol=1e-8, what=what, signed=(m.margin >= KNIFE)[live])
         live &= ~g.z["terminated"][t].astype(bool)
     assert not live.all() or g.steps < 12  # the fixtures do reach termination
+    return int(live.sum())
+
+
+@pytest.mark.parametrize("name", MERGE + MERGE_GRID + MERGE_CRASH)
+def test_oracle_free_running_steps(name):
+    check_free_running_steps(GoldenMerge(name))
 
 
 @pytest.mark.parametrize("name", ["merge_v1", "merge_generic_v1"])
