@@ -327,12 +327,54 @@ def self_launch(argv, n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def main() -> None:
+class GpuPlatform:
+    """What the rank body needs from the machine: a device, a stream with an engine on it, events, the process-group backend.
+    tests/test_bench_dryrun.py swaps in a CPU stand-in (gloo, a fake engine) to run the WHOLE control flow of an N-rank bench --
+    shard, two alternating output buffers, --gather-every, the per-step-gather leg, the one JSON line -- without a GPU."""
+    backend = "nccl"
+
+    def check(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+
+    def device(self, local_rank):
+        import torch
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+
+    def init_process_group(self, dist, rank, world, dev):
+        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=dev)
+
+    def make_engine(self, cfg, local_rank, dev):
+        # ONE stream for everything: the engine's launches, torch's tensor ops and the event torch.distributed records before it
+        # hands a buffer to RCCL.  It must be a real stream object: the handle of torch's default stream is NULL, which hwy_create
+        # reads as "create your own" -- and an engine-owned stream is not ordered with torch's.
+        import torch
+        from highwayenv_amd.engine import Engine
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        return Engine(cfg, device=local_rank, stream=stream.cuda_stream), stream
+
+    def synchronize(self, dev):
+        import torch
+        torch.cuda.synchronize(dev)
+
+    def event(self):
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+
+def main(argv=None, platform=None, emit=None):
+    platform = platform or GpuPlatform()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed steps PER REGION (SURVEY 8d: >= 1000)")
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--settle-ms", type=float, default=200.0,
+                    help="untimed: after the --warmup steps keep stepping until the GPU has been busy this long (engine clock ramp-up "
+                         "after idle); 0 = off.  Reported as `settle_steps`")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU,
                     help="environments per GPU (weak scaling, the default); with --scaling strong: the TOTAL over all GPUs")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -365,21 +407,22 @@ def main() -> None:
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds, prio_shift, "
                          "ix_prewarm_frames: highwayenv_amd._abi.TUNING_KEYS); selects a kernel variant, never changes a result; repeatable")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
-        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+        raise SystemExit(self_launch(sys.argv[1:] if argv is None else list(argv), args.gpus))
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
     cfg_dict, fast, scenario = workload_config(args.workload)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner through C
     # stdio when a communicator is created), so everything else is sent to stderr: fd 1 is pointed at fd 2 for the whole
     # run and the JSON line goes to the saved descriptor at the end.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-
-    def emit(obj) -> None:
+    if emit is None:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+
+        def emit(obj) -> None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     if args.cpu_baseline_only:
         out = cpu_baseline(args.workload, cfg_dict, fast, scenario, have_gpu=False)
@@ -401,19 +444,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the torch.distributed environment has WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    platform.check()
+    dev = platform.device(local_rank)
     # HWY_BENCH_FORCE_DIST=1 (developer knob): run the RCCL gather path even with a single rank
     use_dist = world > 1 or os.environ.get("HWY_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        platform.init_process_group(dist, rank, world, dev)
 
     from highwayenv_amd import _abi
-    from highwayenv_amd.engine import Engine
     from highwayenv_amd.dist import PackedStepOutputs
 
     E = args.envs_per_gpu
@@ -428,12 +468,7 @@ def main() -> None:
     spawn_kw = ({"ego_spacing": cfg_dict["ego_spacing"], "vehicles_density": cfg_dict["vehicles_density"]}
                 if scenario == "highway" else {})
 
-    # ONE stream for everything: the engine's launches, torch's tensor ops and the event torch.distributed records before it
-    # hands a buffer to RCCL.  It must be a real stream object: the handle of torch's default stream is NULL, which hwy_create
-    # reads as "create your own" -- and an engine-owned stream is not ordered with torch's.
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    eng = Engine(cfg, device=local_rank, stream=stream.cuda_stream)
+    eng, stream = platform.make_engine(cfg, local_rank, dev)
     eng.reset(base_seed=1_000_003 * (rank + 1), **spawn_kw)
     eng.set_autoreset(True, base_seed=77_000_001 * (rank + 1), **spawn_kw)
 
@@ -476,14 +511,25 @@ def main() -> None:
             drain()
             if use_dist:
                 dist.barrier()
-            torch.cuda.synchronize(dev)
+            platform.synchronize(dev)
 
         return one_step, fence, outs
 
     one_step, fence, outs = make_stepper(K)
 
+    t_first_launch = time.perf_counter()
     for t in range(args.warmup):
         one_step(t)
+    # Clock settling (untimed, like the warm-up; --settle-ms 0 switches it off): a short command line (the driver's --warmup 5
+    # --steps 20 is 5 ms of GPU work in all) would otherwise time the first milliseconds after an idle period, while the engine
+    # clock is still ramping up -- measured 44.4 us per step there against 41.7 us in steady state on the same box
+    # (profiles/r04_history.md).  More of the same untimed warm-up steps until the GPU has been busy for --settle-ms.
+    settle_steps = 0
+    while args.settle_ms > 0 and (time.perf_counter() - t_first_launch) * 1e3 < args.settle_ms:
+        for t in range(max(args.warmup, 1)):
+            one_step(t)
+        settle_steps += max(args.warmup, 1)
+        platform.synchronize(dev)
     fence()
     # HIP events on every 8th launch of the timed regions: the engine hands the pair to hipExtLaunchKernelGGL, which records the
     # DISPATCH's own begin / end timestamps into them (the clock readings rocprofv3 --kernel-trace reports) on the launch stream
@@ -493,7 +539,7 @@ def main() -> None:
         t_first = args.warmup + r * args.steps
         # the same region on the DEVICE timeline too: an event pair on the stream the engine launches on, around the K launches
         # (host wall = this + the latency of fence()'s drain / barrier / synchronize, which a short region does not amortise)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = platform.event(), platform.event()
         t0 = time.perf_counter()
         ev0.record(stream)
         for t in range(t_first, t_first + args.steps):
@@ -515,8 +561,8 @@ def main() -> None:
     if use_dist and K != 1:
         one_step1, fence1, _ = make_stepper(1)
         n1 = min(args.steps, 300)
-        for t in range(args.warmup, args.warmup + 20):
-            one_step1(t)
+        for j in range(20):   # (action rows of the timed regions, re-used: a short smoke run stages fewer than 20 of them)
+            one_step1(args.warmup + j % (R * args.steps))
         fence1()
         t0 = time.perf_counter()
         for t in range(args.warmup, args.warmup + n1):
@@ -571,6 +617,7 @@ def main() -> None:
     if world == 1 and S > 1 and E % S == 0:
         Es = E // S
         cfg_s = _abi.make_config(cfg_dict, Es, fast=fast, scenario=scenario, tuning=tuning)
+        from highwayenv_amd.engine import Engine
         sub_streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         subs = []
         for k in range(S):
@@ -638,6 +685,8 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
+            "settle_ms": args.settle_ms,
             "repeats": R,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_repeats": [x / args.steps * 1e3 for x in region_s],
@@ -702,6 +751,7 @@ def main() -> None:
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+    return outs
 
 
 if __name__ == "__main__":

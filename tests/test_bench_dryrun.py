@@ -1,0 +1,137 @@
+"""The whole control flow of an N-rank `bench.py` run on the CPU: two ranks on gloo, a stand-in engine that stamps (rank, step)
+into the output planes it is handed.  What an 8-GPU node would otherwise be the first to execute -- the shard sizes, the two
+alternating output buffers, `--gather-every` with a partly filled last buffer, the one-gather-per-step leg, `--scaling strong`,
+the ONE JSON line with the process group's world size -- runs here (round-3 verdict item 8)."""
+import ctypes as C
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeEngine:
+    """Engine.step_device's contract on host memory: fills the six output planes behind the raw pointers."""
+
+    def __init__(self, cfg, rank):
+        from highwayenv_amd import _abi
+        self.E, self.A, self.rank = cfg.num_envs, cfg.num_agents, rank
+        self.obs_len = int(np.prod(_abi.obs_shape(cfg)))
+        self.steps = 0
+
+    def reset(self, **kw):
+        pass
+
+    def set_autoreset(self, *a, **kw):
+        pass
+
+    def profile_enable(self, every):
+        pass
+
+    def profile_read(self):
+        return 0.0, 0
+
+    def step_device(self, d_actions, d_obs, d_reward, d_term, d_trunc, d_speed, d_crashed):
+        E, A = self.E, self.A
+        acts = np.ctypeslib.as_array(C.cast(d_actions, C.POINTER(C.c_int32)), (E * A,))
+        assert acts.min() >= 0 and acts.max() <= 4
+        self.steps += 1
+        np.ctypeslib.as_array(C.cast(d_reward, C.POINTER(C.c_double)), (E * A,))[:] = 1000.0 * self.rank + self.steps
+        np.ctypeslib.as_array(C.cast(d_obs, C.POINTER(C.c_float)), (E * A * self.obs_len,))[:] = self.rank
+        np.ctypeslib.as_array(C.cast(d_term, C.POINTER(C.c_uint8)), (E,))[:] = self.rank + 1
+        np.ctypeslib.as_array(C.cast(d_trunc, C.POINTER(C.c_uint8)), (E,))[:] = 0
+
+    def close(self):
+        pass
+
+
+class CpuPlatform:
+    backend = "gloo"
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def check(self):
+        pass
+
+    def device(self, local_rank):
+        return torch.device("cpu")
+
+    def init_process_group(self, dist, rank, world, dev):
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def make_engine(self, cfg, local_rank, dev):
+        self.engine = FakeEngine(cfg, self.rank)
+        return self.engine, None
+
+    def synchronize(self, dev):
+        pass
+
+    def event(self):
+        import time
+
+        class Ev:
+            def record(self, stream=None):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+        return Ev()
+
+
+def _rank_main(rank, world, port, argv, out_path):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    import bench
+    lines = []
+    plat = CpuPlatform(rank)
+    outs = bench.main(argv, platform=plat, emit=lines.append)
+    json.dump({"lines": lines, "steps": plat.engine.steps, "envs": plat.engine.E,
+               "gathered_rewards": ([[float(v["reward"][0, 0]) for v in o.rank0_views(0)] for o in outs] if rank == 0 else None),
+               "gathered_term": ([[int(v["terminated"][0]) for v in o.rank0_views(0)] for o in outs] if rank == 0 else None)},
+              open(f"{out_path}.{rank}", "w"))
+
+
+def _run(tmp_path, argv, world=2):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "rank")
+    mp.spawn(_rank_main, args=(world, port, argv, out), nprocs=world, join=True)
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+@pytest.mark.parametrize("scaling,envs,gather_every", [("weak", 6, 4), ("strong", 8, 1)])
+def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_every):
+    steps, warmup, repeats = 6, 3, 2   # 6 % 4 != 0: every region ends on a partly filled buffer that still has to travel
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--repeats", str(repeats), "--envs-per-gpu", str(envs),
+            "--scaling", scaling, "--gather-every", str(gather_every), "--settle-ms", "0", "--no-cpu-baseline"]
+    r0, r1 = _run(tmp_path, argv)
+    assert r1["lines"] == [] and len(r0["lines"]) == 1    # ONE JSON line, from rank 0
+    line = r0["lines"][0]
+    per_rank = envs if scaling == "weak" else envs // 2
+    assert r0["envs"] == r1["envs"] == per_rank
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warmup and line["scaling"] == scaling
+    assert line["config"]["world_size_reported_by_the_process_group"] == 2 and line["config"]["envs_per_gpu"] == per_rank
+    assert line["value"] == pytest.approx(steps * per_rank * 2 / (line["ms_per_step"] * 1e-3 * steps), rel=1e-9)
+    assert len(line["ms_per_step_repeats"]) == repeats and line["ms_per_step_device"] > 0
+    assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm"
+    # both ranks stepped the same number of times: warm-up + regions (+ the one-gather-per-step leg when gathers are batched)
+    extra = 0 if gather_every == 1 else (20 + min(steps, 300))
+    assert r0["steps"] == r1["steps"] == warmup + repeats * steps + extra
+    if gather_every == 1:
+        assert line["gather_every_1"] is None
+    else:
+        assert line["gather_every_1"]["steps"] == min(steps, 300) and line["gather_every_1"]["value"] > 0
+    # what rank 0 holds after the last gather really came from the two ranks (the stand-in engine stamps its rank)
+    for terms in r0["gathered_term"]:
+        assert terms == [1, 2]
+    for rewards in r0["gathered_rewards"]:
+        assert rewards[0] < 1000.0 <= rewards[1] < 2000.0
