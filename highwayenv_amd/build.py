@@ -85,6 +85,48 @@ def build_engine(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+ASAN_LIB_PATH = os.path.join(CSRC, "libhwy_engine_asan.so")
+
+
+def asan_runtime() -> str:
+    """ROCm clang's shared AddressSanitizer runtime (to LD_PRELOAD under an uninstrumented python)."""
+    hits = glob.glob(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "lib", "clang", "*", "lib", "linux",
+                                  "libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under $ROCM_PATH/lib/llvm")
+    return sorted(hits)[-1]
+
+
+def build_engine_asan(force: bool = False, verbose: bool = False) -> str:
+    """libhwy_engine_asan.so: the HOST side of the library (hwy_engine.hip: argument validation, staging buffers, event
+    bookkeeping, state packing; hwy_comm.hip) instrumented with AddressSanitizer; the kernels are the
+    product's own object code (ASan for gfx950 device code needs xnack+, which this part does not run with).  Test
+    infrastructure: tests/test_asan_host.py runs the ABI tests and a parity test on it with the runtime preloaded."""
+    srcs = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    if not force and os.path.exists(ASAN_LIB_PATH) and os.path.getmtime(ASAN_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs):
+        return ASAN_LIB_PATH
+    hipcc = _hipcc()
+    build_engine()  # (the kernels' object file is the product's own: hwy_kernels.o)
+    objs = []
+    for src in SOURCES:
+        if src == "hwy_kernels.hip":
+            objs.append(os.path.join(CSRC, "hwy_kernels.o"))
+            continue
+        obj = os.path.join(CSRC, src.replace(".hip", "_asan.o"))
+        flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-shared-libsan",
+                 "-fno-omit-frame-pointer", "-Wno-option-ignored"]
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-o", ASAN_LIB_PATH, *objs, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return ASAN_LIB_PATH
+
+
 def kernel_resources(lib_path: str = LIB_PATH) -> dict:
     """What the compiler allocated to every kernel of the gfx950 code object inside the built library, read from the code
     object's own metadata (NT_AMDGPU_METADATA note: the numbers the hardware dispatcher uses), keyed by demangled kernel name

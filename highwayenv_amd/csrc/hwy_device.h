@@ -145,6 +145,7 @@ struct StepParams {
   const uint8_t *reset_mask;  // reset kernel only: [E] or nullptr (= all)
   const uint64_t *reset_seeds;  // reset kernel only: [E] or nullptr (= base_seed + e)
   const uint16_t *block_env;    // one-wavefront step kernel: environment of workgroup b (hwy_set_block_order), or nullptr (= b)
+  unsigned long long *counters; // [HWY_CTR_COUNT] event counters of the engine (hwy_get_counters), nullptr = not counted
   ResetParams rp;
 };
 
@@ -815,6 +816,14 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
   }
 }
 // full = true: spawn / reset (every field); false: end of a step (dynamic fields only)
+// NaN guard: vehicles whose position / heading / speed left the finite numbers are COUNTED where the state is
+// written back (HWY_CTR_NONFINITE_STORES, hwy_get_counters) -- the simulation has no operation that recovers from a NaN (it spreads
+// through the neighbour gaps to the whole lane), so a nonzero count says the state handed to hwy_set_state, or a kernel, is broken.
+// x - x is 0 for every finite x and NaN for +-inf and NaN: one compare per thread, one ballot, an atomic only on the broken path.
+__device__ inline void count_nonfinite(unsigned long long *counters, bool bad) {
+  const unsigned long long m = __ballot(bad);
+  if (m && counters && (threadIdx.x & 63) == 0) atomicAdd(&counters[HWY_CTR_NONFINITE_STORES], (unsigned long long)__popcll(m));
+}
 template <int NW>
 __device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, bool full = true) {
   const int i = threadIdx.x;
@@ -830,6 +839,7 @@ __device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, b
       p.st.impact_y[k] = o.impy;
     }
   }
+  count_nonfinite(p.counters, i < p.N && !((o.x - o.x) + (o.y - o.y) + (o.h - o.h) + (o.v - o.v) == 0.0));
 }
 template <int NW>
 __device__ inline void publish(typename EnvBlock<NW>::Shared &sh, const Veh &me, bool active) {

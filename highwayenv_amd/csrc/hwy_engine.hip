@@ -190,6 +190,7 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.grid_ws = eng->d_grid_ws;
   p.prio_shift = eng->prio_shift;
   p.block_env = eng->d_block_env;
+  p.counters = eng->d_counters;
 }
 
 static bool is_ix(const hwy_engine *eng) { return eng->cfg.scenario == HWY_SCENARIO_INTERSECTION; }

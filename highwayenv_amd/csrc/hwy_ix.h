@@ -558,6 +558,8 @@ __device__ inline void ix_store_vehicle(const IxParams &ip, int e, const IxVeh &
       }
     }
   }
+  count_nonfinite(to_shadow ? nullptr : ip.counters, i < p.N && !(o.flags & HWY_F_ABSENT) &&
+                                                       !((o.x - o.x) + (o.y - o.y) + (o.h - o.h) + (o.v - o.v) == 0.0));
 }
 
 // ---- n_frames x { [meta-action]; Road.act(); RegulatedRoad.step(dt) } on the wave's registers + LDS --------------

@@ -165,7 +165,7 @@ class Engine:
         return out.reshape(np.shape(x))
 
     # -- misc ---------------------------------------------------------------------------------
-    COUNTERS = ("ix_spawns", "ix_spawns_dropped")
+    COUNTERS = ("ix_spawns", "ix_spawns_dropped", "nonfinite_stores")
 
     def counters(self, reset: bool = False) -> dict:
         """Event counters (hwy_get_counters): intersection scenario, device traffic -- spawns performed, and spawns

@@ -409,7 +409,9 @@ int hwy_sync(hwy_engine *eng); /* hipStreamSynchronize on the engine stream */
  * the per-step spawn and the pre-warmed next episodes alike), so a caller can size max_vehicles until the second is 0.
  * `out` receives min(n, HWY_CTR_COUNT) values.
  */
-enum { HWY_CTR_IX_SPAWNS = 0, HWY_CTR_IX_SPAWNS_DROPPED = 1, HWY_CTR_COUNT = 8 };
+/* HWY_CTR_NONFINITE_STORES (every scenario): vehicles written back by a step / frames launch with a non-finite position,
+ * heading or speed -- 0 in any healthy run; a NaN handed in through hwy_set_state (or produced by a defect) shows up here. */
+enum { HWY_CTR_IX_SPAWNS = 0, HWY_CTR_IX_SPAWNS_DROPPED = 1, HWY_CTR_NONFINITE_STORES = 2, HWY_CTR_COUNT = 8 };
 int hwy_get_counters(hwy_engine *eng, uint64_t *out, int32_t n, int32_t reset);
 
 /*

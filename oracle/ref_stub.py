@@ -127,6 +127,9 @@ class _RecordConstructorArgs:
         pass
 
 
+_CLASS_DEFAULTS = {}
+
+
 def install() -> None:
     """Put the stubs in sys.modules and the reference on sys.path (idempotent)."""
     sys.dont_write_bytecode = True  # /root/reference is read-only for us: importing it must not leave __pycache__ behind
@@ -173,4 +176,24 @@ def install() -> None:
         pg.SRCALPHA = 0
         sys.modules["pygame"] = pg
     if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+        sys.path.append(REFERENCE_ROOT)   # (at the END: the reference has a `tests` package of its own, ours must keep winning)
+    if reference_available() and not _CLASS_DEFAULTS:
+        _CLASS_DEFAULTS[None] = True   # (re-entrancy guard: restore_class_defaults calls install)
+        restore_class_defaults()       # snapshot the class attributes as imported, before any environment is created
+
+
+def restore_class_defaults() -> None:
+    """IntersectionEnv._make_vehicles writes its IDM parameters onto the vehicle CLASS (intersection_env.py:243-247:
+    DISTANCE_WANTED 7, COMFORT_ACC_MAX 6, COMFORT_ACC_MIN -3), where they stay for every environment the process creates later --
+    a highway env stepped after an intersection env in one process drives with the intersection's parameters.  The fixture
+    generators and the live-reference tests call this before every scenario so that a trace does not depend on which scenarios
+    ran before it in the same process (the values restored are the ones the classes were IMPORTED with)."""
+    if not reference_available():
+        return
+    install()
+    from highway_env.vehicle import behavior
+    for cls in (behavior.IDMVehicle, behavior.AggressiveVehicle, behavior.DefensiveVehicle, behavior.LinearVehicle):
+        saved = _CLASS_DEFAULTS.setdefault(cls.__name__, {k: v for k, v in vars(cls).items() if k.isupper()})
+        for k, v in saved.items():
+            if getattr(cls, k) is not v:
+                setattr(cls, k, v)

@@ -251,6 +251,7 @@ SCENARIOS = [
 def run_scenario(sc: dict, only_envs=None) -> dict:
     """`only_envs`: simulate only these env indices (tests/test_fixture_freshness.py regenerates env 0 of every fixture); the action
     table is drawn for all of them either way, so an env's trajectory does not depend on which others are simulated."""
+    ref_stub.restore_class_defaults()   # (an IntersectionEnv created earlier in this process has re-tuned the IDM CLASS)
     seeds, steps, n_slots = sc["seeds"], sc["steps"], sc["n_slots"]
     E = len(seeds)
     A = int(sc["config"].get("controlled_vehicles", 1))

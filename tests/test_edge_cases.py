@@ -146,3 +146,27 @@ def test_truncation_fires_exactly_at_duration(backend):
     # time += 0.5 per step; truncated <=> time >= 4  <=> from the 8th step on
     assert [bool(f.all()) for f in flags] == [False] * 7 + [True] * 2
     eng.close()
+
+
+@pytest.mark.gpu
+def test_nonfinite_state_is_counted():
+    """NaN guard (include/hwy_engine.h: HWY_CTR_NONFINITE_STORES): a healthy run counts nothing; a NaN handed in through set_state is
+    counted where the step writes the state back (and spreads to its lane mates through the gap terms)."""
+    from highwayenv_amd.engine import Engine
+    cfg_d = _abi.highway_fast_default_config()
+    cfg = _abi.make_config(cfg_d, 8, fast=True)
+    eng = Engine(cfg)
+    eng.reset(base_seed=3)
+    acts = np.ones((8, 1), np.int32)
+    for _ in range(3):
+        eng.step(acts)
+    assert eng.counters()["nonfinite_stores"] == 0
+    st = eng.get_state()
+    st["x"][5, 7] = np.nan
+    eng.set_state(st)
+    eng.step(acts)
+    n = eng.counters(reset=True)["nonfinite_stores"]
+    assert n >= 1
+    assert np.isnan(eng.get_state()["x"][5]).any() and not np.isnan(eng.get_state()["x"][[0, 1, 2, 3, 4, 6, 7]]).any()
+    assert eng.counters()["nonfinite_stores"] == 0
+    eng.close()

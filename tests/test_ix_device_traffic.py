@@ -252,7 +252,7 @@ def test_spawn_counters_report_what_the_slot_cap_drops():
         for t in range(40):
             eng.step(rng.integers(0, 3, size=(512, 1)))
         c = eng.counters()
-        assert eng.counters(reset=True) == c and eng.counters() == {"ix_spawns": 0, "ix_spawns_dropped": 0}
+        assert eng.counters(reset=True) == c and eng.counters() == {"ix_spawns": 0, "ix_spawns_dropped": 0, "nonfinite_stores": 0}
         attempts = c["ix_spawns"] + c["ix_spawns_dropped"]
         assert attempts > 512  # spawn_probability 0.6 per env-step, minus the ones too close to somebody
         rates[cap] = c["ix_spawns_dropped"] / attempts

@@ -79,8 +79,13 @@ def run_selection(lib: str, selection, env_extra) -> subprocess.CompletedProcess
 
 @pytest.mark.parametrize("mutant,selection,env_extra", CASES, ids=[c[0] for c in CASES])
 def test_seeded_bug_fails_the_comparison_that_covers_it(mutant, selection, env_extra):
-    good = run_selection(None, selection, env_extra)   # (the suite's own emulator build)
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.emu import emu
+    emu.build()   # (the suite's own emulator build, before two processes could both start building it)
+    with ThreadPoolExecutor(2) as pool:   # the control and the mutant side by side (two subprocesses)
+        f_good = pool.submit(run_selection, None, selection, env_extra)
+        f_bad = pool.submit(lambda: run_selection(build_mutant(mutant), selection, env_extra))
+        good, bad = f_good.result(), f_bad.result()
     assert good.returncode == 0, f"the selection must pass on the unmutated kernel source:\n{good.stdout[-3000:]}"
-    bad = run_selection(build_mutant(mutant), selection, env_extra)
     assert bad.returncode == 1 and "AssertionError" in bad.stdout, \
         f"mutant {mutant} SURVIVED {selection} (rc {bad.returncode}):\n{bad.stdout[-3000:]}"

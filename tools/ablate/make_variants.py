@@ -280,6 +280,7 @@ FLAG_VARIANTS = {
     "f_bias100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
     "f_nopostlicm": ["-mllvm", "-disable-postra-machine-licm"],
     "f_fma": ["-ffp-contract=fast"],
+    "f_fast": ["-ffp-contract=fast"],   # (the build contracts by source expression, -ffp-contract=on: this fuses whatever the optimiser finds)
     "f_nofma": ["-ffp-contract=off"],   # (since round 4 the build contracts: this is the round-3 arithmetic)
     "f_kcmix": ["-include", os.path.join(os.path.dirname(os.path.abspath(__file__)), "kc_mix.h")],
     "f_fma_kcmix": ["-ffp-contract=fast", "-include", os.path.join(os.path.dirname(os.path.abspath(__file__)), "kc_mix.h")],  # a*b+c fused where the compiler sees it (the build double-rounds like numpy: -ffp-contract=off)

@@ -97,12 +97,12 @@ def features(d):
     """What a wavefront could write out at the end of step t - 1 (== the state at the start of step t) + the reset flag + the
     action of step t (known before the launch)."""
     from highwayenv_amd import _abi
-    x, y, v, lane, tgt, timer, flags = d["x"], d["y"], d["speed"], d["lane"], d["target_lane"], d["timer"], d["flags"]
+    x, y, lane, tgt, flags = d["x"], d["y"], d["lane"], d["target_lane"], d["flags"]
     ctrl = (flags & _abi.F_CONTROLLED) != 0
     ego = ctrl.argmax(-1)
     T, E, N = x.shape
     tt, ee = np.meshgrid(np.arange(T), np.arange(E), indexing="ij")
-    ex, ey, ev, el = x[tt, ee, ego], y[tt, ee, ego], v[tt, ee, ego], lane[tt, ee, ego]
+    ex, ey = x[tt, ee, ego], y[tt, ee, ego]
     dx, dy = x - ex[..., None], y - ey[..., None]
     other = ~ctrl
     changing = other & (lane != tgt)
@@ -113,10 +113,7 @@ def features(d):
         "near10": (other & (np.abs(dx) < 10) & (np.abs(dy) < 3)).sum(-1),
         "near7": (other & (np.abs(dx) < 7) & (np.abs(dy) < 2.5)).sum(-1),
         "near6_lat5": (other & (np.abs(dx) < 6.5) & (np.abs(dy) < 5)).sum(-1),
-        "due": (other & (lane == tgt) & (timer >= 1.0 - 1.0 + 1e-6) & (timer + 1.0 >= 1.0)).sum(-1) * 0 + (other & (timer >= 0.0) & (timer + 1.0 >= 1.0 - 1e-9) & (lane == tgt)).sum(-1),
-        "due_soon": (other & (lane == tgt) & (timer >= 0.0)).sum(-1),
         "ego_lane_change": np.isin(d["action"], (0, 2)).astype(float),
-        "ego_changing": (el != tgt[tt, ee, ego]).astype(float),
     }
     return F
 
