@@ -327,6 +327,33 @@ def self_launch(argv, n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+SECONDARY = [("config 3 shard: highway-v0, 1024 envs x 101 vehicles", ["--workload", "v0_n100", "--envs-per-gpu", "1024"]),
+             ("config 4: intersection-v0, 2048 envs x 30 slots, OccupancyGrid", ["--workload", "intersection", "--envs-per-gpu", "2048"]),
+             ("config 5: merge-generic multi-agent, 4096 envs x 43 slots, 4 agents", ["--workload", "merge_ma4"]),
+             ("highway-v0 defaults, 4096 envs x 51 vehicles", ["--workload", "v0"])]
+
+
+def secondary_workloads(steps: int = 200, repeats: int = 3) -> dict:
+    """BASELINE's other single-GPU configurations, one short run of this same script each (its own process, after the headline's
+    timed regions; same box, same build), so that the driver's record carries their numbers too.  Never part of `value`."""
+    import subprocess
+    out = {}
+    for name, argv in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), *argv, "--steps", str(steps), "--repeats", str(repeats), "--warmup", "20",
+               "--settle-ms", "100", "--no-cpu-baseline", "--no-secondary", "--rollout-k", "0"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d["roofline"]
+            out[argv[1]] = {"workload": name, "ms_per_step": d["ms_per_step"], "ms_per_step_device": d["ms_per_step_device"],
+                            "value": d["value"], "unit": d["unit"], "vehicle_steps_per_s": d["vehicle_steps_per_s"],
+                            "steps": steps, "repeats": repeats, "avg_kernel_us": rf["avg_kernel_us"], "kernel": rf["kernel"],
+                            "roofline_frac_hbm": rf["frac"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"]}
+        except Exception as ex:  # a report next to the headline, never a reason to lose the headline
+            out[argv[1]] = {"workload": name, "error": repr(ex)[:300]}
+    return out
+
+
 class GpuPlatform:
     """What the rank body needs from the machine: a device, a stream with an engine on it, events, the process-group backend.
     tests/test_bench_dryrun.py swaps in a CPU stand-in (gloo, a fake engine) to run the WHOLE control flow of an N-rank bench --
@@ -404,6 +431,9 @@ def main(argv=None, platform=None, emit=None):
                          "round-robin: the tail of one sub-batch's launch overlaps the body of the next one's), reported as "
                          "`split_batch_sS` next to the headline.  Off by default: its launches carry the headline kernel's name, "
                          "so they would mix into a rocprofv3 --stats average of the default command")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N=1, --workload fast only: skip the short legs on BASELINE's other single-GPU configurations (config 3's "
+                         "per-GPU shard, config 4, config 5) that are reported NEXT TO the headline as `secondary_workloads`")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="hwy_config.tune_* knob (block_kernel, waves_per_eu, ix_no_helpers, ix_no_prewarm, extra_lds, prio_shift, "
                          "ix_prewarm_frames: highwayenv_amd._abi.TUNING_KEYS); selects a kernel variant, never changes a result; repeatable")
@@ -747,6 +777,8 @@ def main(argv=None, platform=None, emit=None):
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, cfg_dict, fast, scenario)
+        if world == 1 and args.workload == "fast" and not args.no_secondary and not tuning:
+            line["secondary_workloads"] = secondary_workloads()
         emit(line)
     eng.close()
     if use_dist:

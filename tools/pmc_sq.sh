@@ -11,7 +11,7 @@ P2="SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL
 P3="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE"
 k=0
 for P in "$P1" "$P2" "$P3"; do k=$((k+1))
-timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_$W/p$k -o run -- python $R/bench.py --workload $W --envs-per-gpu $E --no-cpu-baseline --steps 30 --warmup 40 --repeats 1 > /dev/null 2> $R/gpurun_out/pmc_$W/p$k.err
+timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/pmc_$W/p$k -o run -- python $R/bench.py --workload $W --envs-per-gpu $E --no-cpu-baseline --no-secondary --settle-ms 0 --steps 30 --warmup 40 --repeats 1 > /dev/null 2> $R/gpurun_out/pmc_$W/p$k.err
 done
 cd $R
 python - "$W" "$E" "$K" <<'PY'
