@@ -114,6 +114,11 @@ struct IxSharedT {
   double sx[HWY_MAX_GLANES], sy[HWY_MAX_GLANES], lhead[HWY_MAX_GLANES], dirx[HWY_MAX_GLANES], diry[HWY_MAX_GLANES],
       cx[HWY_MAX_GLANES], cy[HWY_MAX_GLANES], rad[HWY_MAX_GLANES], sph[HWY_MAX_GLANES], len[HWY_MAX_GLANES],
       wid[HWY_MAX_GLANES], lim[HWY_MAX_GLANES];
+  // 1 / radius of a CircularLane, rounded once per launch: CircularLane.position / heading_at (lane.py:341-350) divide the
+  // longitudinal coordinate by the radius -- an IEEE f64 division is ~30 dependent instructions on this hardware, and the steering
+  // of every frame and the 11 trajectory samples of the regulation each run one; the product with the rounded reciprocal is within
+  // 1 ulp of the quotient (1e-16 of an angle: the per-frame parity is held at 1e-9)
+  double irad[HWY_MAX_GLANES];
   IxRow row[HWY_MAX_GLANES];  // walk order
   u64 mask[HWY_MAX_GLANES];  // slot-space membership (on_lane, margin 1) of every lane
   // frame snapshot by slot (indexed by thread where every thread writes)
@@ -155,7 +160,7 @@ __device__ inline void ix_local(const SH &sh, int L, double x, double y, double 
 template <typename SH>
 __device__ inline double ix_heading_at(const SH &sh, int L, double s) {
   if (sh.kind[L] == 0) return sh.lhead[L];
-  const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
+  const double phi = (sh.ldir[L] * s) * sh.irad[L] + sh.sph[L];
   return phi + HWY_PI / 2 * sh.ldir[L];
 }
 // position(s, 0) (lane.py:196-201, 341-345)
@@ -165,7 +170,7 @@ __device__ inline void ix_position(const SH &sh, int L, double s, double *px, do
     *px = sh.sx[L] + s * sh.dirx[L] + 0.0 * -sh.diry[L];
     *py = sh.sy[L] + s * sh.diry[L] + 0.0 * sh.dirx[L];
   } else {
-    const double phi = sh.ldir[L] * s / sh.rad[L] + sh.sph[L];
+    const double phi = (sh.ldir[L] * s) * sh.irad[L] + sh.sph[L];
     double sn, cs;
     sincos_bounded(phi, &sn, &cs);
     *px = sh.cx[L] + (sh.rad[L] - 0.0 * sh.ldir[L]) * cs;
@@ -183,6 +188,7 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
     sh.sx[i] = l.sx; sh.sy[i] = l.sy; sh.lhead[i] = l.heading; sh.dirx[i] = l.dirx; sh.diry[i] = l.diry;
     sh.cx[i] = l.cx; sh.cy[i] = l.cy; sh.rad[i] = l.radius; sh.sph[i] = l.start_phase; sh.len[i] = l.length;
     sh.wid[i] = l.width; sh.lim[i] = l.speed_limit;
+    sh.irad[i] = l.kind != 0 ? 1.0 / l.radius : 0.0;
   }
   if (i < ip.n_lanes) {
     int n = 0;
@@ -360,7 +366,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
             double phi = atan2_bounded(dy, dx);
             phi = r.g + wrap_to_pi(phi - r.g);
             const double sa = r.d * (phi - r.g) * r.c;
-            const double lane_h = (r.d * sa / r.c + r.g) + HWY_PI / 2 * r.d;
+            const double lane_h = ((r.d * sa) * sh.irad[r.L] + r.g) + HWY_PI / 2 * r.d;  // (heading_at: see IxSharedT::irad)
             const bool on = fabs(lat) <= r.e && -5.0 <= sa && sa < r.f + 5.0;
             const double angle = fabs(wrap_to_pi(ph - lane_h));
             const double d = fabs(lat) + fmax(sa - r.f, 0.0) + fmax(0 - sa, 0.0) + 1.0 * angle;

@@ -251,6 +251,10 @@ VARIANTS = {
     "ixnointeg": [(IX, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n    }\n    __syncthreads();  // the trajectories", "    }\n    __syncthreads();  // the trajectories"))],
     "ixnoreset": [(IX, sub("  if (p.autoreset && p.st.done[e]) {  // the step after", "  if (false) {  // the step after"))],
     "ixnoact": [(IX, sub("    if (acts) {\n      // follow_road", "    if (false) {\n      // follow_road"))],
+    # (A/B, a VALID simulation) the CircularLane coordinate divided by the radius with IEEE divisions again instead of multiplied
+    # by the rounded reciprocal (IxSharedT::irad, round 4)
+    "ixdiv": [(IX, sub("(sh.ldir[L] * s) * sh.irad[L] + sh.sph[L]", "sh.ldir[L] * s / sh.rad[L] + sh.sph[L]")),
+              (IX, sub("((r.d * sa) * sh.irad[r.L] + r.g)", "(r.d * sa / r.c + r.g)"))],
     # generic workgroup kernel (hwy_device.h)
     "base": [],
     "nocollide": [(D, cutter("    if (all_check) {\n      // Full pairwise (highway-v0): outward scan", "  }  // frames", "    if (false) {}\n"))],
