@@ -217,8 +217,15 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                     # such slots are counted
                     touching = np.asarray(m1.flag_margin) < KNIFE
                     sure = fine[:, None] & ~touching
-                    for f in ("impact_x", "impact_y"):  # signed
-                        np.testing.assert_allclose(g1[f][sure], ost1[f][sure], rtol=0, atol=1e-9, err_msg=f"step {t} frame {fr}: {f}")
+                    # signed; 1e-9 + 1e-7 of the translation: when two bodies are parallel to ~1e-8 rad (a rear-end collision on one
+                    # lane centre) the projections on their two lateral normals tie in the last bit, "first minimum wins" picks either
+                    # body's normal, and the translation turns by that angle -- 4.3e-9 m of a 0.22 m push in GPU fuzz chunk 354, the one
+                    # case in 3.5 M frames; a wrong pair or a wrong sign is off by the whole translation
+                    tol = 1e-9 + 1e-7 * np.hypot(ost1["impact_x"], ost1["impact_y"])
+                    for f in ("impact_x", "impact_y"):
+                        bad_imp = sure & ~(np.abs(g1[f] - ost1[f]) <= tol)
+                        assert not bad_imp.any(), (f"step {t} frame {fr}: {f}: engine {g1[f][bad_imp]} oracle {ost1[f][bad_imp]} "
+                                                   f"(|translation| {np.hypot(ost1['impact_x'], ost1['impact_y'])[bad_imp]})")
                     hi_g, hi_o = (g1["flags"] & _abi.F_HAS_IMPACT) != 0, ost1["has_impact"] != 0
                     np.testing.assert_array_equal((hi_g | touching)[fine], (hi_o | touching)[fine], err_msg=f"step {t} frame {fr}: pending impacts")
                     tot_touch += int((touching & ((hi_g != hi_o) | (np.abs(g1["impact_x"] - ost1["impact_x"]) > 1e-9)
