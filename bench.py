@@ -555,7 +555,12 @@ def main(argv=None, platform=None, emit=None):
     # clock is still ramping up -- measured 44.4 us per step there against 41.7 us in steady state on the same box
     # (profiles/r04_history.md).  More of the same untimed warm-up steps until the GPU has been busy for --settle-ms.
     settle_steps = 0
-    while args.settle_ms > 0 and (time.perf_counter() - t_first_launch) * 1e3 < args.settle_ms:
+    while args.settle_ms > 0:
+        more = torch.tensor([1.0 if (time.perf_counter() - t_first_launch) * 1e3 < args.settle_ms else 0.0], device=dev)
+        if use_dist:  # every rank must run the SAME number of rounds (each round holds collectives): go on while any rank wants to
+            dist.all_reduce(more, op=dist.ReduceOp.MAX)
+        if more.item() == 0.0:
+            break
         for t in range(max(args.warmup, 1)):
             one_step(t)
         settle_steps += max(args.warmup, 1)

@@ -108,11 +108,11 @@ def _run(tmp_path, argv, world=2):
     return [json.load(open(f"{out}.{r}")) for r in range(world)]
 
 
-@pytest.mark.parametrize("scaling,envs,gather_every", [("weak", 6, 4), ("strong", 8, 1)])
-def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_every):
+@pytest.mark.parametrize("scaling,envs,gather_every,settle_ms", [("weak", 6, 4, 0), ("strong", 8, 1, 0), ("weak", 4, 4, 30)])
+def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_every, settle_ms):
     steps, warmup, repeats = 6, 3, 2   # 6 % 4 != 0: every region ends on a partly filled buffer that still has to travel
     argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--repeats", str(repeats), "--envs-per-gpu", str(envs),
-            "--scaling", scaling, "--gather-every", str(gather_every), "--settle-ms", "0", "--no-cpu-baseline"]
+            "--scaling", scaling, "--gather-every", str(gather_every), "--settle-ms", str(settle_ms), "--no-cpu-baseline"]
     r0, r1 = _run(tmp_path, argv)
     assert r1["lines"] == [] and len(r0["lines"]) == 1    # ONE JSON line, from rank 0
     line = r0["lines"][0]
@@ -125,7 +125,9 @@ def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_eve
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm"
     # both ranks stepped the same number of times: warm-up + regions (+ the one-gather-per-step leg when gathers are batched)
     extra = 0 if gather_every == 1 else (20 + min(steps, 300))
-    assert r0["steps"] == r1["steps"] == warmup + repeats * steps + extra
+    # (the clock-settle rounds hold collectives: both ranks must agree on their number, whatever their own clocks say)
+    assert r0["steps"] == r1["steps"] == warmup + line["settle_steps"] + repeats * steps + extra
+    assert (line["settle_steps"] > 0) == (settle_ms > 0) and line["settle_steps"] % warmup == 0
     if gather_every == 1:
         assert line["gather_every_1"] is None
     else:
