@@ -543,44 +543,50 @@ struct Veh {
 //      Vehicle.create_random's rule (vehicle/kinematics.py:50-104), IDMVehicle ctor timer
 //      (behavior.py:64), randomize_behavior (behavior.py:66-69), MDPVehicle ladder snap
 //      (controller.py:287-293).  Thread i == vehicle i.  Needs two LDS scratch arrays (N and 1 doubles).
-template <int NW>
-__device__ inline void spawn_env(const StepParams &p, double *scratch_step, double *scratch_base, int e, uint64_t seed,
-                                 uint32_t episode, Veh &o) {
-  const int i = threadIdx.x;
-  const bool active = i < p.N;
-  bool controlled = false;
-  for (int a = 0; a < p.A; ++a) controlled |= (p.agent_index[a] == i);
+// Split in two so that a kernel with several vehicles per thread (hwy_wave2.h) runs the same rule: spawn_draw = everything
+// vehicle vi can compute alone, spawn_fill = the rest once its x (the running sum of the steps in creation order) is known.
+struct SpawnDraw {
+  int lane;
+  double speed, step, offset, u_delta;
+  bool controlled;
+};
+__device__ inline SpawnDraw spawn_draw(const StepParams &p, int vi, uint64_t seed, uint32_t episode) {
+  SpawnDraw d;
+  d.controlled = false;
+  for (int a = 0; a < p.A; ++a) d.controlled |= (p.agent_index[a] == vi);
   double u_lane, u_speed, u_pos, u_delta;
-  philox_uniform2(seed, (uint32_t)i, episode, 0u, &u_lane, &u_speed);
-  philox_uniform2(seed, (uint32_t)i, episode, 1u, &u_pos, &u_delta);
+  philox_uniform2(seed, (uint32_t)vi, episode, 0u, &u_lane, &u_speed);
+  philox_uniform2(seed, (uint32_t)vi, episode, 1u, &u_pos, &u_delta);
   int lane = (int)(u_lane * p.L);
   if (lane > p.L - 1) lane = p.L - 1;
-  if (controlled && p.rp.initial_lane_id >= 0) lane = p.rp.initial_lane_id;
+  if (d.controlled && p.rp.initial_lane_id >= 0) lane = p.rp.initial_lane_id;
   // speed: ego 25.0; others uniform(0.7*limit, 0.8*limit) == low + (high-low)*u  (numpy's formula)
   const double lo = 0.7 * p.speed_limit, hi = 0.8 * p.speed_limit;
-  const double speed = controlled ? 25.0 : lo + (hi - lo) * u_speed;
-  const double spacing = controlled ? p.rp.ego_spacing : p.rp.other_spacing;
+  const double speed = d.controlled ? 25.0 : lo + (hi - lo) * u_speed;
+  const double spacing = d.controlled ? p.rp.ego_spacing : p.rp.other_spacing;
   const double default_spacing = 12 + 1.0 * speed;
   const double offset = spacing * default_spacing * p.rp.lane_factor;
-  const double step = offset * (0.9 + (1.1 - 0.9) * u_pos);  // offset * uniform(0.9, 1.1)
-  if (active) scratch_step[i] = step;
-  if (active && i == 0) scratch_base[0] = 3 * offset;  // first vehicle starts from 3*offset
-  __syncthreads();
-  // x_k = max_x(existing) + step_k == running sum in creation order (steps are positive)
-  double x = scratch_base[0];
-  for (int k = 0; k <= i && k < p.N; ++k) x += scratch_step[k];
-  __syncthreads();
+  d.lane = lane;
+  d.speed = speed;
+  d.offset = offset;
+  d.step = offset * (0.9 + (1.1 - 0.9) * u_pos);  // offset * uniform(0.9, 1.1)
+  d.u_delta = u_delta;
+  return d;
+}
+__device__ inline void spawn_fill(const StepParams &p, const SpawnDraw &d, double x, int vi, Veh &o) {
+  const int lane = d.lane;
+  const double speed = d.speed;
   o.x = x;
   o.y = lane * p.lane_width;
   o.h = 0.0;
   o.v = speed;
   o.lane = lane;
   o.tgt = lane;
-  o.rank = i & 0xff;  // x increases with the creation index: the identity is the sorted order
+  o.rank = vi & 0xff;  // x increases with the creation index: the identity is the sorted order
   o.impx = o.impy = 0.0;
   o.ch = 1.0;
   o.sh = 0.0;
-  if (controlled) {
+  if (d.controlled) {
     // MDPVehicle: speed_index = speed_to_index(target_speed=speed); target_speed = ladder[idx]
     const double xs = (speed - p.target_speeds[0]) / (p.target_speeds[p.n_ts - 1] - p.target_speeds[0]);
     o.sidx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1));
@@ -592,9 +598,24 @@ __device__ inline void spawn_env(const StepParams &p, double *scratch_step, doub
     o.sidx = 0;
     o.ts = speed;
     o.timer = py_mod_pos((o.x + o.y) * HWY_PI, HWY_LC_DELAY);
-    o.delta = 3.5 + (4.5 - 3.5) * u_delta;
+    o.delta = 3.5 + (4.5 - 3.5) * d.u_delta;
     o.flags = p.rp.fast ? 0 : HWY_F_CHECK_COLLISIONS;
   }
+}
+template <int NW>
+__device__ inline void spawn_env(const StepParams &p, double *scratch_step, double *scratch_base, int e, uint64_t seed,
+                                 uint32_t episode, Veh &o) {
+  const int i = threadIdx.x;
+  const bool active = i < p.N;
+  const SpawnDraw d = spawn_draw(p, i, seed, episode);
+  if (active) scratch_step[i] = d.step;
+  if (active && i == 0) scratch_base[0] = 3 * d.offset;  // first vehicle starts from 3*offset
+  __syncthreads();
+  // x_k = max_x(existing) + step_k == running sum in creation order (steps are positive)
+  double x = scratch_base[0];
+  for (int k = 0; k <= i && k < p.N; ++k) x += scratch_step[k];
+  __syncthreads();
+  spawn_fill(p, d, x, i, o);
   (void)e;
 }
 
@@ -797,9 +818,7 @@ __device__ inline void observe_env(const StepParams &p, typename EnvBlock<NW>::S
 // HBM traffic discipline: every dynamic word is read once and written once per policy step; the
 // pending-impact pair is only touched for vehicles that have one (flag bit), and per-vehicle constants
 // (IDM exponent, an IDM vehicle's target speed) are never written back by the step kernel.
-template <int NW>
-__device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
-  const int i = threadIdx.x;
+__device__ inline void load_vehicle_at(const StepParams &p, int e, int i, Veh &o) {  // i: vehicle index (thread i of the workgroup kernels)
   o = Veh{};
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
@@ -815,6 +834,8 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) {
     sincos_bounded(o.h, &o.sh, &o.ch);
   }
 }
+template <int NW>
+__device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) { load_vehicle_at(p, e, threadIdx.x, o); }
 // full = true: spawn / reset (every field); false: end of a step (dynamic fields only)
 // NaN guard: vehicles whose position / heading / speed left the finite numbers are COUNTED where the state is
 // written back (HWY_CTR_NONFINITE_STORES, hwy_get_counters) -- the simulation has no operation that recovers from a NaN (it spreads
@@ -824,9 +845,7 @@ __device__ inline void count_nonfinite(unsigned long long *counters, bool bad) {
   const unsigned long long m = __ballot(bad);
   if (m && counters && (threadIdx.x & 63) == 0) atomicAdd(&counters[HWY_CTR_NONFINITE_STORES], (unsigned long long)__popcll(m));
 }
-template <int NW>
-__device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, bool full = true) {
-  const int i = threadIdx.x;
+__device__ inline void store_vehicle_at(const StepParams &p, int e, int i, const Veh &o, bool full = true) {
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
     p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
@@ -840,6 +859,10 @@ __device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, b
     }
   }
   count_nonfinite(p.counters, i < p.N && !((o.x - o.x) + (o.y - o.y) + (o.h - o.h) + (o.v - o.v) == 0.0));
+}
+template <int NW>
+__device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, bool full = true) {
+  store_vehicle_at(p, e, threadIdx.x, o, full);
 }
 template <int NW>
 __device__ inline void publish(typename EnvBlock<NW>::Shared &sh, const Veh &me, bool active) {

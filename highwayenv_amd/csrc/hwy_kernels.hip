@@ -7,6 +7,7 @@
 #define HWY_HAVE_SETPRIO 1  // s_setprio / s_memtime / s_getreg exist on the device (not in the CPU emulation of tests/emu)
 #include "hwy_device.h"
 #include "hwy_wave.h"
+#include "hwy_wave2.h"
 #include "hwy_net.h"
 #include "hwy_ix.h"
 #include "hwy_launch.h"
@@ -74,10 +75,26 @@ static hipError_t launch_rollout_wpe(const StepParams &p, int num_envs, hipStrea
     HWY_LAUNCH((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
+// 64 < N <= 128 with the Kinematics observation: ONE wavefront per environment, two vehicles per thread (hwy_wave2.h)
+bool wide_kernel_applies(const StepParams &p, bool force_block_kernel) {
+  return p.N > 64 && p.N <= 128 && p.obs_type == HWY_OBS_KINEMATICS && !force_block_kernel;
+}
+// (one register-allocation variant: 177 VGPRs whatever the bound, and 18.7 KB of LDS per one-wavefront workgroup allow two per SIMD)
+static hipError_t launch_wide(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
+  (void)waves_per_eu;
+  HWY_LAUNCH((hwy_step_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+static hipError_t launch_wide_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
+  (void)waves_per_eu;
+  HWY_LAUNCH((hwy_rollout_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
 // hwy_rollout_device on the straight-road kernels: p.k_steps policy steps in one launch -- the one-wavefront kernel for N <= 64,
 // the workgroup kernel otherwise (or when forced).
 hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds,
                           bool force_block_kernel, int block_waves_per_eu) {
+  if (wide_kernel_applies(p, force_block_kernel)) return launch_wide_rollout(p, num_envs, stream, block_waves_per_eu);
   if (p.N > 64 || force_block_kernel) {
     switch (block_waves_per_eu) {
       case 1: return launch_block_rollout_wpe<1>(p, num_envs, stream);
@@ -96,6 +113,7 @@ hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream,
 // N <= 64: one wavefront per environment (hwy_wave.h); otherwise ceil(N/64) wavefronts per workgroup.
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds) {
+  if (wide_kernel_applies(p, force_block_kernel)) return launch_wide(p, num_envs, stream, waves_per_eu);
   if (p.N <= 64 && !force_block_kernel) {
     switch (waves_per_eu) {
       case 1: return launch_wave_wpe<1>(p, num_envs, stream, extra_lds);
@@ -132,6 +150,7 @@ static int block_resident_wpe(int n) {
   }
 }
 int step_resident_blocks(const StepParams &p, int waves_per_eu, bool force_block_kernel, int extra_lds) {
+  if (wide_kernel_applies(p, force_block_kernel)) return 0;  // (the wide kernel takes no issue-priority turns)
   if (p.N > 64 || force_block_kernel) {  // workgroup kernel: turns by workgroup (hwy_device.h: wave_turn_init_workgroup)
     switch (waves_per_eu) {
       case 1: return block_resident_wpe<1>(p.N);

@@ -11,6 +11,8 @@ namespace hwy {
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 hipError_t launch_step(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, bool force_block_kernel,
                        int extra_lds);
+// true where launch_step / launch_rollout run the two-vehicles-per-thread one-wavefront kernel of hwy_wave2.h
+bool wide_kernel_applies(const StepParams &p, bool force_block_kernel);
 // p.k_steps policy steps per launch (hwy_rollout_device): one-wavefront kernel (waves_per_eu, extra_lds) or workgroup kernel
 hipError_t launch_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu, int extra_lds,
                           bool force_block_kernel, int block_waves_per_eu);

@@ -50,6 +50,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, "emu_engine.cpp"), os.path.join(_HERE, "hip_emu.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_device.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave.h"),
+            os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_wave2.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_net.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_ix.h"),
             os.path.join(_ROOT, "highwayenv_amd", "csrc", "hwy_math.h"),

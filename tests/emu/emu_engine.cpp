@@ -25,6 +25,7 @@ inline double noisy(double v) {
 #endif
 #include "../../highwayenv_amd/csrc/hwy_device.h"
 #include "../../highwayenv_amd/csrc/hwy_wave.h"
+#include "../../highwayenv_amd/csrc/hwy_wave2.h"
 #include "../../highwayenv_amd/csrc/hwy_net.h"
 #include "../../highwayenv_amd/csrc/hwy_ix.h"
 #include "../../highwayenv_amd/csrc/hwy_params.h"
@@ -155,6 +156,18 @@ void dispatch(Which which, const StepParams &p, int E) {
     }
     if (p.flags & HWY_C_EGO_ONLY_COLLISIONS) emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, false>(q); }, E, 64, p);
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
+    return;
+  }
+  if (which == STEP && nw == 2 && p.obs_type == HWY_OBS_KINEMATICS && !g_force_block && !g_cfg->tune_block_kernel) {
+    // same dispatch rule as hwy_kernels.hip (wide_kernel_applies): one wavefront per environment, two vehicles per thread
+    if (g_k_steps > 0) {
+      StepParams pk = p;
+      pk.k_steps = g_k_steps;
+      pk.num_envs = E;
+      emu::launch([](const StepParams &q) { hwy::hwy_rollout_wide_kernel<2, 1>(q); }, E, 64, pk);
+      return;
+    }
+    emu::launch([](const StepParams &q) { hwy::hwy_step_wide_kernel<2, 1>(q); }, E, 64, p);
     return;
   }
 #define RUN(NW)                                                                                         \

@@ -1,0 +1,164 @@
+"""The two-vehicles-per-thread one-wavefront kernel (highwayenv_amd/csrc/hwy_wave2.h: 64 < N <= 128, BASELINE config 3's
+N = 101) against the workgroup kernel it replaces there (hwy_device.h, `tuning.block_kernel`) and against the C oracle.
+
+Both kernels call the same per-vehicle device functions on the same source expressions, so the comparison between them is
+BIT FOR BIT (state planes, rewards, flags; observations to an f64 ulp before their rounding to f32) -- across free-running episodes with device auto-resets, the
+ego-only and the full-pairwise collision paths, several controlled vehicles, equal-x ties and the multi-step launch.
+"""
+import numpy as np
+import pytest
+
+from highwayenv_amd import _abi, spawn
+from oracle import oracle
+from tests.backends import BACKENDS, make_engine
+from tests.golden_util import assert_state_close
+from tests.test_engine_parity import _random_rollout_vs_oracle
+
+STATE_KEYS = ("x", "y", "heading", "speed", "timer", "target_speed", "delta", "impact_x", "impact_y", "lane", "target_lane",
+              "speed_index", "flags")
+
+
+def _pair(backend, cfg_d, E, fast):
+    wide = make_engine(backend, _abi.make_config(cfg_d, E, fast=fast))
+    block = make_engine(backend, _abi.make_config(dict(cfg_d, tuning={"block_kernel": 1}), E, fast=fast))
+    return wide, block
+
+
+def _assert_same(a, b, what):
+    for k in STATE_KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"{what}: {k}")
+
+
+CASES = [
+    # (config overrides, fast, envs emu / hip, steps emu / hip)
+    pytest.param({"vehicles_count": 100}, False, (2, 96), (3, 30), id="v0_n101_full_pairwise"),
+    pytest.param({"vehicles_count": 99, "lanes_count": 4, "duration": 6}, True, (3, 128), (8, 40), id="fast_n100_ego_only"),
+    pytest.param({"vehicles_count": 70, "controlled_vehicles": 3, "lanes_count": 3, "duration": 8}, False, (2, 64), (3, 24),
+                 id="v0_n73_three_agents"),
+    pytest.param({"vehicles_count": 127, "lanes_count": 5, "vehicles_density": 2.0}, False, (1, 32), (2, 12), id="v0_n128_dense"),
+    pytest.param({"vehicles_count": 64, "lanes_count": 2, "vehicles_density": 2.5, "duration": 5}, True, (2, 64), (6, 30),
+                 id="fast_n65_two_lanes"),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("over,fast,envs,steps", CASES)
+def test_wide_kernel_bit_identical_to_workgroup_kernel(backend, over, fast, envs, steps):
+    cfg_d = _abi.highway_fast_default_config() if fast else _abi.highway_default_config()
+    cfg_d.update(over)
+    E, T = (envs[0], steps[0]) if backend == "emu" else (envs[1], steps[1])
+    wide, block = _pair(backend, cfg_d, E, fast)
+    cfg = _abi.make_config(cfg_d, E, fast=fast)
+    st = spawn.spawn_reference_stream(cfg, np.arange(E) + 77, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+    for eng in (wide, block):
+        eng.set_state(_abi.copy_state(st))
+        eng.set_autoreset(True, base_seed=1234, ego_spacing=cfg_d["ego_spacing"], vehicles_density=cfg_d["vehicles_density"],
+                          initial_lane_id=-1 if cfg_d["initial_lane_id"] is None else cfg_d["initial_lane_id"])
+    rng = np.random.default_rng(5)
+    n_done = n_crash = 0
+    for t in range(T):
+        acts = rng.integers(0, 5, size=(E, cfg.num_agents)).astype(np.int32)
+        ow, rw, tew, trw, iw = wide.step(acts)
+        ob, rb, teb, trb, ib = block.step(acts)
+        what = f"step {t}"
+        # (the observation's lmap: the one-wavefront kernels multiply by host-computed reciprocals of the feature ranges, the
+        # workgroup kernel divides -- an f64 ulp apart before the rounding to f32)
+        np.testing.assert_allclose(ow, ob, rtol=0, atol=1e-7, err_msg=what)
+        np.testing.assert_array_equal(rw, rb, err_msg=what)
+        np.testing.assert_array_equal(tew, teb, err_msg=what)
+        np.testing.assert_array_equal(trw, trb, err_msg=what)
+        np.testing.assert_array_equal(iw["crashed"], ib["crashed"], err_msg=what)
+        np.testing.assert_array_equal(iw["speed"], ib["speed"], err_msg=what)
+        _assert_same(wide.get_state(), block.get_state(), what)
+        n_done += int((tew | trw).sum())
+        n_crash += int(tew.sum())
+    if backend == "hip":
+        assert n_done > 0, "no episode ended: the auto-reset path of the kernel was not exercised"
+    print(f"wide == workgroup kernel over {T} steps x {E} envs ({n_done} episode ends, {n_crash} crashes)")
+    wide.close()
+    block.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_kernel_frames_only_and_observe(backend):
+    """hwy_step_frames (no observation / reward, no auto-reset) and hwy_observe after it."""
+    cfg_d = _abi.highway_default_config()
+    cfg_d.update({"vehicles_count": 100})
+    E = 2 if backend == "emu" else 32
+    wide, block = _pair(backend, cfg_d, E, False)
+    cfg = _abi.make_config(cfg_d, E, fast=False)
+    st = spawn.spawn_reference_stream(cfg, np.arange(E) + 5, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+    acts = np.full((E, 1), 3, np.int32)
+    for eng in (wide, block):
+        eng.set_state(_abi.copy_state(st))
+        eng.step_frames(acts, 4)
+        eng.step_frames(None, 3)
+    _assert_same(wide.get_state(), block.get_state(), "frames only")
+    np.testing.assert_allclose(wide.observe(), block.observe(), rtol=0, atol=1e-7)
+    wide.close()
+    block.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_kernel_equal_x_ties(backend):
+    """Vehicles at identical longitudinal coordinates, in both slots of a thread and across them: the literal-scan path."""
+    cfg_d = _abi.highway_default_config()
+    cfg_d.update({"vehicles_count": 89, "lanes_count": 3})
+    E = 2
+    cfg = _abi.make_config(cfg_d, E, fast=False)
+    st = spawn.spawn_reference_stream(cfg, [3, 4], cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+    for a, b in ((2, 3), (10, 70), (66, 67), (63, 64)):  # same slot, across slots, second slot, the slot boundary
+        st["x"][:, b] = st["x"][:, a]
+        lane_b = (st["lane"][:, a] + 1) % 3
+        st["lane"][:, b] = st["target_lane"][:, b] = lane_b
+        st["y"][:, b] = lane_b * 4.0
+    st["timer"][:, :] = 1.5  # everybody takes a MOBIL decision in the first frame
+    ref = _abi.copy_state(st)
+    wide, block = _pair(backend, cfg_d, E, False)
+    for eng in (wide, block):
+        eng.set_state(_abi.copy_state(st))
+    for f in range(3):
+        wide.step_frames(None, 1)
+        block.step_frames(None, 1)
+        oracle.frames(cfg, ref, None, 1)
+        _assert_same(wide.get_state(), block.get_state(), f"ties, frame {f}")
+        assert_state_close(wide.get_state(), ref, atol=1e-9, what=f"ties, frame {f}")
+    wide.close()
+    block.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_kernel_vs_oracle(backend):
+    """Free-running episodes against the C oracle (host re-spawns on the reference's stream), both collision modes."""
+    cfg = _abi.highway_default_config()
+    cfg.update({"vehicles_count": 100})
+    _random_rollout_vs_oracle(backend, cfg, False, 2 if backend == "emu" else 96, 2 if backend == "emu" else 12, seed=11)
+    cfg = _abi.highway_fast_default_config()
+    cfg.update({"vehicles_count": 90, "lanes_count": 4})
+    _random_rollout_vs_oracle(backend, cfg, True, 3 if backend == "emu" else 128, 6 if backend == "emu" else 30, seed=12)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_kernel_rollout_equals_single_steps(backend):
+    """hwy_rollout: K policy steps in one launch == K launches, bit for bit (auto-resets in between included)."""
+    cfg_d = _abi.highway_default_config()
+    cfg_d.update({"vehicles_count": 100, "duration": 3})
+    E, K = (2, 4) if backend == "emu" else (48, 8)
+    cfg = _abi.make_config(cfg_d, E, fast=False)
+    st = spawn.spawn_reference_stream(cfg, np.arange(E) + 9, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+    one, many = make_engine(backend, cfg), make_engine(backend, _abi.make_config(cfg_d, E, fast=False))
+    for eng in (one, many):
+        eng.set_state(_abi.copy_state(st))
+        eng.set_autoreset(True, base_seed=99, ego_spacing=cfg_d["ego_spacing"], vehicles_density=cfg_d["vehicles_density"],
+                          initial_lane_id=-1 if cfg_d["initial_lane_id"] is None else cfg_d["initial_lane_id"])
+    acts = np.random.default_rng(1).integers(0, 5, size=(K, E, 1)).astype(np.int32)
+    obs, reward, term, trunc, info = many.rollout(acts)
+    for k in range(K):
+        o, r, te, tr, i = one.step(acts[k])
+        np.testing.assert_array_equal(obs[k], o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(reward[k], r, err_msg=f"step {k}")
+        np.testing.assert_array_equal(term[k], te, err_msg=f"step {k}")
+        np.testing.assert_array_equal(trunc[k], tr, err_msg=f"step {k}")
+    _assert_same(one.get_state(), many.get_state(), "after the rollout")
+    one.close()
+    many.close()
