@@ -744,63 +744,67 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
     if (all_check) {
-      // Full pairwise (highway-v0): outward walk in the rank order of this frame's start, bounded by the frame-start distance;
-      // the walk only COLLECTS the pairs that pass the sphere pre-check and the provable-separation test, each unordered pair
-      // once (by the slot of its lower index); the SAT then runs K PAIRS per thread, and the verdicts meet per vehicle in
-      // LDS ("last pair in loop order wins" == ds_max on the partner index, then the winner's write).  hwy_wave.h has the
-      // argument; the list is a ring of 512 entries (at most 64 K - 1 + 4 x 64 K / 2 are pending at any time).
+      // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among neighbours along the
+      // road: every vehicle walks FORWARD in the rank order of this frame's start (each unordered pair is met once, from its
+      // rear end), bounded by the frame-start distance (collision radius + the most two vehicles can move relative to each
+      // other within one frame), and only COLLECTS the partners inside the reference's own pre-check sphere
+      // (objects.py:124-127) -- a dozen VALU instructions per candidate.  The list pass then runs, one PAIR per thread, the
+      // provable-separation test and -- if any pair of the wavefront survives it -- the SAT; the verdicts meet per vehicle in LDS
+      // ("last pair in loop order wins" == ds_max on the partner index, then the winner's write: hwy_wave.h has the
+      // argument).  The list is a ring.
       bool wide_any_ = false;
+      HWY_WAVE_LDS_FENCE();  // every gather of the frame-start snapshot is done: all of it but x and idx is dead from here on
 #pragma unroll
       for (int h = 0; h < K; ++h) {
-        const int v = vi[h];
+        const int v = vi[h], r = rank[h];
         sh.nx[v] = me[h].x; sh.ny[v] = me[h].y; sh.nv[v] = me[h].v; sh.nc[v] = me[h].ch; sh.ns[v] = me[h].sh;
+        // position and speed again in the rank order of this frame's start, over dead planes of the snapshot (lr <- x, c <- y,
+        // v): a walk step then needs ONE LDS round trip (frame-start x, index, position, speed of slot rank + k)
+        if (active[h]) { sh.lr[r] = me[h].x; sh.c[r] = me[h].y; sh.v[r] = me[h].v; }
         sh.jmax[v] = -1;
         sh.hit[v] = 0;
         wide_any_ = wide_any_ || (active[h] && !(fabs(me[h].x - x_old[h]) <= 50.0 * p.dt + 3.0 && fabs(me[h].v) <= 50.0));
       }
+      // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and are not faster than
+      // 50 m/s afterwards; checked on the actual values (wave-uniform) -- otherwise the walk is the literal all-pairs loop
       const bool wide = __ballot(wide_any_) != 0;
       HWY_WAVE_LDS_FENCE();
       const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
       const u64 below = ((u64)1 << l) - 1;
-      constexpr int PASS = 64 * K;
+      constexpr int PASS = 64 * K, RING = 512;  // at most PASS - 1 + 2 steps x 64 K entries are pending at any time
       int n_list = 0, head = 0, k = 1;  // wave-uniform
-      bool go_a[K], go_b[K], walking = true;
+      bool go[K], walking = true;
 #pragma unroll
-      for (int h = 0; h < K; ++h) go_a[h] = go_b[h] = active[h];
+      for (int h = 0; h < K; ++h) go[h] = active[h];
       while (walking || n_list) {
         while (walking && n_list < PASS) {
-          int qa[K], qb[K];
-          bool going = false;
+          // two walk steps per trip (k and k + 1, K slots): 2 K independent candidates whose LDS reads are in flight together
+          bool keep[2][K], going = false;
+          int q[2][K];
 #pragma unroll
-          for (int h = 0; h < K; ++h) {
-            const int ra = rank[h] - k, rb = rank[h] + k;
-            go_a[h] = go_a[h] && ra >= 0;
-            go_b[h] = go_b[h] && rb < N;
-            const int ia_ = go_a[h] ? ra : 0, ib_ = go_b[h] ? rb : 0;
-            go_a[h] = go_a[h] && !(fabs(sh.x[ia_] - x_old[h]) > reach);  // sh.x: frame-start x in rank order
-            go_b[h] = go_b[h] && !(fabs(sh.x[ib_] - x_old[h]) > reach);
-            qa[h] = sh.idx[ia_];
-            qb[h] = sh.idx[ib_];
-            going = going || go_a[h] || go_b[h];
-          }
-          ++k;
-          if (__ballot(going) == 0 || k > N) walking = false;
-#pragma unroll
-          for (int side = 0; side < 2; ++side) {
+          for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int h = 0; h < K; ++h) {
-              const int q = side ? qb[h] : qa[h];
-              bool keep = false;
-              if ((side ? go_b[h] : go_a[h]) && vi[h] < q) {
-                const Body mine{me[h].x, me[h].y, me[h].v, me[h].ch, me[h].sh};
-                const Body other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q]};
-                const double dx = other.x - mine.x, dy = other.y - mine.y;
-                const double lim = 5.5 + fmax(fabs(mine.v), fabs(other.v)) * p.dt;
-                keep = !(dx * dx + dy * dy > lim * lim) && !surely_apart(mine, other, p.dt);
-              }
-              const u64 km = __ballot(keep);
+              const int rb = rank[h] + (k + u);
+              go[h] = go[h] && rb < N;
+              const int r = go[h] ? rb : 0;
+              go[h] = go[h] && !(fabs(sh.x[r] - x_old[h]) > reach);  // sh.x: frame-start x in rank order
+              if (u == 1) going = going || go[h];
+              const double dx = sh.lr[r] - me[h].x, dy = sh.c[r] - me[h].y;
+              const double lim = 5.5 + fmax(fabs(me[h].v), fabs(sh.v[r])) * p.dt;
+              q[u][h] = sh.idx[r];
+              keep[u][h] = go[h] && !(dx * dx + dy * dy > lim * lim);
+            }
+          }
+          k += 2;
+          if (__ballot(going) == 0 || k > N) walking = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int h = 0; h < K; ++h) {
+              const u64 km = __ballot(keep[u][h]);
               if (km) {
-                if (keep) sh.plist[(head + n_list + __popcll(km & below)) & 511] = (unsigned short)(vi[h] | (q << 8));
+                if (keep[u][h]) sh.plist[(head + n_list + __popcll(km & below)) & (RING - 1)] = (unsigned short)(vi[h] | (q[u][h] << 8));
                 n_list += __popcll(km);
               }
             }
@@ -810,35 +814,52 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
         HWY_WAVE_LDS_FENCE();
         int pa[K], pb[K], r[K];
         double tx[K], ty[K];
+        bool cand[K], any_cand = false;
+        Body A[K], Bb[K];
 #pragma unroll
         for (int h = 0; h < K; ++h) {
-          const int t = h * 64 + l;
-          const int pair = t < count ? (int)sh.plist[(head + t) & 511] : -1;
-          pa[h] = pair & 255;
-          pb[h] = pair >> 8;  // a < b: the reference's `self` and `other`
           r[h] = 0;
           tx[h] = ty[h] = 0.0;
-          if (pair >= 0) {
-            const int a = pa[h], b = pb[h];
-            const Body A{sh.nx[a], sh.ny[a], sh.nv[a], sh.nc[a], sh.ns[a]}, Bb{sh.nx[b], sh.ny[b], sh.nv[b], sh.nc[b], sh.ns[b]};
-            r[h] = pair_collide(A, Bb, p.dt, &tx[h], &ty[h]);
-            if (r[h] & 1) sh.hit[a] = sh.hit[b] = 1;
-            if (r[h] & 2) {  // "last pair in loop order wins" == the partner with the highest index
-              __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          cand[h] = false;
+          pa[h] = pb[h] = 0;
+          if (count > 64 * h) {  // wave-uniform: the second slot only when the list holds more than 64 pairs
+            const int t = h * 64 + l;
+            const int pair = t < count ? (int)sh.plist[(head + t) & (RING - 1)] : -1;
+            const int u0 = pair & 255, u1 = (pair >> 8) & 255;
+            const int a = u0 < u1 ? u0 : u1, b = u0 < u1 ? u1 : u0;  // a < b: the reference's `self` and `other`
+            pa[h] = a;
+            pb[h] = b;
+            A[h] = Body{sh.nx[a], sh.ny[a], sh.nv[a], sh.nc[a], sh.ns[a]};
+            Bb[h] = Body{sh.nx[b], sh.ny[b], sh.nv[b], sh.nc[b], sh.ns[b]};
+            cand[h] = pair >= 0 && !surely_apart(A[h], Bb[h], p.dt);
+            any_cand = any_cand || cand[h];
+          }
+        }
+        const bool any_sat = __ballot(any_cand) != 0;  // wave-uniform
+        if (any_sat) {
+#pragma unroll
+          for (int h = 0; h < K; ++h) {
+            if (count > 64 * h && cand[h]) {
+              const int a = pa[h], b = pb[h];
+              r[h] = pair_collide(A[h], Bb[h], p.dt, &tx[h], &ty[h]);
+              if (r[h] & 1) sh.hit[a] = sh.hit[b] = 1;
+              if (r[h] & 2) {  // "last pair in loop order wins" == the partner with the highest index
+                __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          }
+          HWY_WAVE_LDS_FENCE();
+#pragma unroll
+          for (int h = 0; h < K; ++h) {
+            if (r[h] & 2) {
+              const int a = pa[h], b = pb[h];
+              if (sh.jmax[a] == b) { sh.impx[a] = tx[h] / 2; sh.impy[a] = ty[h] / 2; }
+              if (sh.jmax[b] == a) { sh.impx[b] = -tx[h] / 2; sh.impy[b] = -ty[h] / 2; }
             }
           }
         }
-        HWY_WAVE_LDS_FENCE();
-#pragma unroll
-        for (int h = 0; h < K; ++h) {
-          if (r[h] & 2) {
-            const int a = pa[h], b = pb[h];
-            if (sh.jmax[a] == b) { sh.impx[a] = tx[h] / 2; sh.impy[a] = ty[h] / 2; }
-            if (sh.jmax[b] == a) { sh.impx[b] = -tx[h] / 2; sh.impy[b] = -ty[h] / 2; }
-          }
-        }
-        head = (head + count) & 511;
+        head = (head + count) & (RING - 1);
         n_list -= count;
         HWY_WAVE_LDS_FENCE();
       }

@@ -24,9 +24,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "highwayenv_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_comm.hip", "hwy_comm.h", "hwy_launch.h", "hwy_params.h", "hwy_wave.h",
+FILES = ("hwy_kernels.hip", "hwy_engine.hip", "hwy_comm.hip", "hwy_comm.h", "hwy_launch.h", "hwy_params.h", "hwy_wave.h", "hwy_wave2.h",
          "hwy_device.h", "hwy_math.h", "hwy_net.h", "hwy_ix.h")
 W, D, NET, IX = "hwy_wave.h", "hwy_device.h", "hwy_net.h", "hwy_ix.h"
+W2 = "hwy_wave2.h"
 
 
 class Stale(Exception):
@@ -82,6 +83,37 @@ def ticks(text):
             "  store_vehicle<1>(q, e, me, false);\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
             "    p.obs[(size_t)e * p.A * p.V * p.F + 12] = n_recount; }\n}")(t)
+    return t
+
+
+def wide_ticks(text):
+    """s_memtime stamps around the sections of the two-vehicles-per-thread kernel (hwy_wave2.h); totals through the obs buffer
+    (tools/wide_section_cycles.py)."""
+    t = sub("  // the meta-actions are requested BEFORE the state (lane a fetches agent a's)\n  const int act_lane",
+            "  long long t_prev = clock64(); long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};\n"
+            "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
+            "  const int act_lane")(text)
+    marks = ["    // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315)",
+             "    // ---- C. rank along the road, lane membership masks, frame-start snapshot",
+             "    double log_ratio[K];",
+             "    // ---- D. Road.act: lane-change policy (behavior.py:219-263)",
+             "    // Straight-line evaluation for every slot",
+             "    // safety of the new follower, only for candidates",
+             "    // abort rule for ongoing lane changes: ordered chain over Road.vehicles",
+             "    // ---- E. Road.act: low-level control, F. Road.step: integrate",
+             "    // ---- G. Road.step: collisions (road.py:477-481",
+             "  }  // frames\n\n  // ---- H. observe"]
+    for k, m in enumerate(marks):
+        t = sub(m, f"    TICK({k})\n" + m)(t)
+    t = sub("    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n",
+            "    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n  TICK(10)\n"
+            "  if (l == 0 && q.obs) { for (int k = 0; k < 16; ++k) q.obs[(size_t)eo * q.A * q.V * q.F + k] = (float)acc[k]; }\n")(t)
+    # collisions split: [11] = publish + walk trips, [12] = SAT passes; [13] walk trips, [14] SAT passes with >= 1 pair, [15] pairs
+    t = sub("long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};", "long long acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
+    t = sub("        const int count = n_list < PASS ? n_list : PASS;\n",
+            "        const int count = n_list < PASS ? n_list : PASS;\n        TICK(11)\n        acc[14] += count > 0; acc[15] += count;\n")(t)
+    t = sub("        head = (head + count) & (RING - 1);\n", "        head = (head + count) & (RING - 1);\n        TICK(12)\n")(t)
+    t = sub("          k += 2;\n          if (__ballot(going) == 0 || k > N) walking = false;", "          k += 2;\n          acc[13] += 1;\n          if (__ballot(going) == 0 || k > N) walking = false;")(t)
     return t
 
 
@@ -188,6 +220,7 @@ VARIANTS = {
     "wnosteer": [(W, sub("    double tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "    double tb = inv_v * 1e-9;"))],
     "wnoobs": [(W, sub("    observe_wave<true>(q, e, eo, me, true, rank);\n", ""))],
     "wticks": [(W, ticks)],
+    "w2ticks": [(W2, wide_ticks)],
     "wreload": [(W, wave_reload)],
     # road-network kernel (hwy_net.h)
     "nticks": [(NET, net_ticks)],
