@@ -26,8 +26,8 @@ struct WideShared {
   int idx[NV];
   int sbits[NV];                          // scratch in rank order: lane-membership bits / observation classes
   u64 lane_mask[HWY_MAX_LANES + 2][K];    // rank-space membership mask of road lane L in row L+1; 0 in rows 0 and L+1
-  // per-vehicle state touched once per frame (slot vi is private to its thread)
-  double timer[NV], ts[NV], delta[NV], impx[NV], impy[NV];
+  // collision translations by vehicle index: written by the thread that evaluated the winning pair, read by the owner
+  double impx[NV], impy[NV];
   // post-integration bodies by vehicle index (full pairwise collisions), their verdict slots and the pair list (a ring)
   double nx[NV], ny[NV], nv[NV], nc[NV], ns[NV];
   int jmax[NV], hit[NV];
@@ -464,8 +464,6 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
   }
 #pragma unroll
   for (int h = 0; h < K; ++h) {
-    sh.timer[vi[h]] = me[h].timer; sh.ts[vi[h]] = me[h].ts; sh.delta[vi[h]] = me[h].delta;
-    sh.impx[vi[h]] = me[h].impx; sh.impy[vi[h]] = me[h].impy;
     i_check[h] = (me[h].flags & HWY_F_CHECK_COLLISIONS) != 0;
     chk[h] = __ballot(active[h] && i_check[h]);
     rank[h] = active[h] ? me[h].rank : vi[h];  // idle slots keep their own so that the table stays a bijection
@@ -488,7 +486,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
           int idx = (int)clipd(rint(xs * (p.n_ts - 1)), 0.0, (double)(p.n_ts - 1)) + (act == HWY_FASTER ? 1 : -1);
           idx = idx < 0 ? 0 : (idx > p.n_ts - 1 ? p.n_ts - 1 : idx);
           me[h].sidx = idx;
-          sh.ts[vi[h]] = p.target_speeds[idx];
+          me[h].ts = p.target_speeds[idx];
         } else if (act == HWY_LANE_LEFT || act == HWY_LANE_RIGHT) {
           int id = me[h].tgt + (act == HWY_LANE_RIGHT ? 1 : -1);
           id = id < 0 ? 0 : (id > p.L - 1 ? p.L - 1 : id);
@@ -507,7 +505,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       int bits = 0;
       for (int L = 0; L < p.L; ++L)
         bits |= (inr && (fabs(me[h].y - L * p.lane_width) <= p.lane_width / 2 + 1.0)) ? (1 << L) : 0;
-      if (fr == 0) inv_v0[h] = B::idm_inv_v0(p, sh.ts[vi[h]]);  // (after the meta-action: the target speed is fixed for the step)
+      if (fr == 0) inv_v0[h] = B::idm_inv_v0(p, me[h].ts);  // (after the meta-action: the target speed is fixed for the step)
       log_ratio[h] = active[h] ? B::idm_log_ratio_inv(me[h].v, inv_v0[h]) : 0.0;
       const int r = rank[h];
       sh.sbits[r] = bits;
@@ -549,10 +547,10 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       drives[h] = idm[h] && !crashed0[h];
       tgt_old[h] = mv.tgt;
       changer[h] = drives[h] && mv.lane != mv.tgt;
-      const double timer = sh.timer[vi[h]];
+      const double timer = mv.timer;
       decide[h] = drives[h] && mv.lane == mv.tgt && (HWY_LC_DELAY < timer);
       // IDMVehicle timer: reset by a decision (behavior.py:248), then += dt in step (behavior.py:147)
-      sh.timer[vi[h]] = idm[h] ? (decide[h] ? 0.0 : timer) + p.dt : timer;
+      mv.timer = idm[h] ? (decide[h] ? 0.0 : timer) + p.dt : timer;
       left_ok[h] = mv.lane - 1 >= 0;
       right_ok[h] = mv.lane + 1 < p.L;
       int ro, rt_;
@@ -602,7 +600,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       const double fo_x = sh.x[g_fo], fo_v = sh.v[g_fo], fo_c = sh.c[g_fo], fo_s = sh.s[g_fo];
       const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
       const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
-      delta[h] = sh.delta[vi[h]];
+      delta[h] = mv.delta;
       free_self[h] = B::idm_free_from_log(log_ratio[h], delta[h]);
       gap_own[h] = fo[h] >= 0 ? B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
       // MOBIL (behavior.py:265-324), both candidates side by side
@@ -661,7 +659,21 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       if (ok_l[h]) me[h].tgt = me[h].lane - 1;
       if (ok_r[h]) me[h].tgt = me[h].lane + 1;
     }
-    // abort rule for ongoing lane changes: ordered chain over Road.vehicles order (ascending word, then bit)
+    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain over Road.vehicles.
+    // A changer c (on its way to lane T since an earlier frame) aborts if ANOTHER vehicle r heading for T from a third lane --
+    // with the target r has when c acts: its current one for r before c in the list, the frame-start one for r after c -- is
+    // ahead of it by less than the desired gap d*(c, r).  Literally that is one link per changer, each reading the targets the
+    // earlier links left behind (hwy_wave.h: ~25 instructions per link, ~60 more with a rival; an environment of 101 vehicles
+    // holds up to a dozen changers per frame and the slowest wavefronts of a launch spent a quarter of their lifetime here).
+    // Three facts make it a per-THREAD computation without any loop over the changers:
+    //  * a rival must be AHEAD and closer than d*, and d* <= 10 + 1.5 v + v (v + 5) / (2 sqrt(ab)) for every possible rival as long
+    //    as no vehicle of the environment drives backwards or sideways faster than 5 m/s (checked, wave-uniform: otherwise the
+    //    bound is infinite): in the rank order of the snapshot a changer walks the members of "heading for T" ahead of it and
+    //    stops at the first one beyond that bound -- usually the very first (measured: 30 listed pairs per step, 0.0 inside);
+    //  * the links only interact through ABORTS, and an abort can only REMOVE a rival (its target becomes its own lane): a
+    //    blocking rival that is itself an EARLIER changer counts only while it has not aborted, every other one for good;
+    //  * a link depends on earlier links only, so iterating "aborts = blocked for good, or blocked by an earlier changer that
+    //    does not abort" from "nobody aborts" reaches the literal chain's result after (depth + 1) rounds -- ballots only.
     {
       u64 cm[K], mv_m[K];
 #pragma unroll
@@ -671,33 +683,123 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       }
       // with a single vehicle on its way to another lane (the changer itself) no link can block
       const bool chain = wide_any<K>(cm) && wide_popc<K>(mv_m) > 1;
+      if (chain) {  // wave-uniform
+        // (1) into rank space: target lane | heads for it from another lane << 4 | decided in this frame << 5 | changer << 6
+        bool insane = false;
+        HWY_WAVE_LDS_FENCE();  // (earlier readers of sbits are done)
 #pragma unroll
-      for (int hc = 0; hc < K; ++hc) {
-        u64 m = chain ? cm[hc] : 0;
-        while (m) {  // wave-uniform
-          const int lc = ctz64(m), ci = hc * 64 + lc;
-          m &= m - 1;
-          const int Tc = wave_bcast_i(tgt_old[hc], lc);
-          bool rival[K], any_rival = false;
+        for (int h = 0; h < K; ++h) {
+          const int mover = (active[h] && me[h].lane != me[h].tgt) ? 1 : 0, decided = (me[h].tgt != tgt_old[h]) ? 1 : 0;
+          sh.sbits[rank[h]] = me[h].tgt | (mover << 4) | (decided << 5) | ((changer[h] ? 1 : 0) << 6);
+          insane = insane || (active[h] && !(me[h].v * me[h].ch >= 0.0 && fabs(me[h].v * me[h].sh) <= 5.0));
+        }
+        const bool sane = __ballot(insane) == 0;
+        HWY_WAVE_LDS_FENCE();
+        u64 Dr[K], Cr[K], Rem[K][K], Bc[K][K];
+        int code[K];
 #pragma unroll
-          for (int h = 0; h < K; ++h) {
-            const int my_tgt_seen = (vi[h] < ci) ? me[h].tgt : tgt_old[h];
-            rival[h] = active[h] && vi[h] != ci && me[h].lane != Tc && my_tgt_seen == Tc;
-            any_rival = any_rival || rival[h];
+        for (int w = 0; w < K; ++w) {
+          code[w] = sh.sbits[w * 64 + l];
+          Dr[w] = __ballot((code[w] >> 5) & 1);
+          Cr[w] = __ballot((code[w] >> 6) & 1);
+#pragma unroll
+          for (int h = 0; h < K; ++h) Rem[h][w] = Bc[h][w] = 0;
+        }
+        // S_T (rank space) = the vehicles heading for lane T from another lane; every changer keeps the members AHEAD of it
+        for (int T = 0; T < p.L; ++T) {  // wave-uniform
+#pragma unroll
+          for (int w = 0; w < K; ++w) {
+            const u64 sT = __ballot(((code[w] >> 4) & 1) && (code[w] & 15) == T);
+#pragma unroll
+            for (int h = 0; h < K; ++h) Rem[h][w] = (changer[h] && tgt_old[h] == T) ? sT : Rem[h][w];
           }
-          if (__ballot(any_rival) == 0) continue;
-          const double xc = wave_bcast(me[hc].x, lc), vc = wave_bcast(me[hc].v, lc);
-          const double cc = wave_bcast(me[hc].ch, lc), sc = wave_bcast(me[hc].sh, lc);
-          bool blk = false;
+        }
+        bool fixed[K], any_left = false;
+        double bound[K];
+#pragma unroll
+        for (int h = 0; h < K; ++h) {
+          const int rw = rank[h] >> 6, rb = rank[h] & 63;
+#pragma unroll
+          for (int w = 0; w < K; ++w) {
+            const u64 ahead = (w > rw) ? ~(u64)0 : ((w == rw) ? ~(((u64)2 << rb) - 1) : 0);  // ranks above mine (2 << 63 wraps to 0)
+            Rem[h][w] &= ahead;
+            any_left = any_left || Rem[h][w] != 0;
+          }
+          fixed[h] = false;
+          // d*(c, r) = 10 + 1.5 v + v dv / (2 sqrt(ab)) with dv = v (cc^2 + sc^2) - v_r (c_r cc + s_r sc) <= v + 5 + (rounding) when v_r c_r >= 0,
+          // |v_r s_r| <= 5 (sane) and cc >= 0, v >= 0; 1e-6 relative + absolute on top of the bound, far above any rounding in d*
+          const double v = me[h].v;
+          bound[h] = (sane && v >= 0.0 && me[h].ch >= 0.0)
+                         ? (HWY_DISTANCE_WANTED + v * HWY_TIME_WANTED + v * (v + 5.0) * 0.12909944487358055) * (1.0 + 1e-6) + 1e-6
+                         : __builtin_inf();
+        }
+        // (2) the walk: nearest remaining member ahead first; beyond the bound everything farther is beyond it too
+        while (__ballot(any_left) != 0) {  // wave-uniform
+          any_left = false;
 #pragma unroll
           for (int h = 0; h < K; ++h) {
-            if (rival[h]) {
-              const double d = me[h].x - xc;
-              const double d_star = B::desired_gap(vc, cc, sc, me[h].v, me[h].ch, me[h].sh);
-              blk = blk || ((0 < d) && (d < d_star));
+            int rr = 0;
+            bool go = false;
+#pragma unroll
+            for (int w = 0; w < K; ++w) {
+              const bool take = !go && Rem[h][w] != 0;
+              rr = take ? w * 64 + ctz64(Rem[h][w]) : rr;
+              Rem[h][w] = take ? (Rem[h][w] & (Rem[h][w] - 1)) : Rem[h][w];
+              go = go || take;
+            }
+            const double xr = sh.x[rr], vr = sh.v[rr], cr = sh.c[rr], sr = sh.s[rr];
+            const int ir = sh.idx[rr];
+            const double d = xr - me[h].x;
+            const bool inside = go && d < bound[h];
+            // the target r shows to c: its current one if it comes before c in the list, else the frame-start one -- and a vehicle
+            // that decided in this very frame headed nowhere with that one
+            const bool valid = inside && (ir < vi[h] || !wide_test<K>(Dr, rr));
+            const double d_star = B::desired_gap(me[h].v, me[h].ch, me[h].sh, vr, cr, sr);
+            const bool blk = valid && (0 < d) && (d < d_star);
+            const bool cond = ir < vi[h] && wide_test<K>(Cr, rr);  // an earlier changer: it may abort
+            fixed[h] = fixed[h] || (blk && !cond);
+#pragma unroll
+            for (int w = 0; w < K; ++w) {
+              Bc[h][w] |= (blk && cond && (ir >> 6) == w) ? ((u64)1 << (ir & 63)) : 0;
+              Rem[h][w] = (go && !inside) || fixed[h] ? 0 : Rem[h][w];
+              any_left = any_left || Rem[h][w] != 0;
             }
           }
-          if (__ballot(blk) != 0 && l == lc) me[hc].tgt = me[hc].lane;  // abort
+        }
+        // (3) the changers that abort (index space: the ballot of slot w is word w), to the fixed point
+        bool any_blk = false;
+#pragma unroll
+        for (int h = 0; h < K; ++h) {
+          any_blk = any_blk || fixed[h];
+#pragma unroll
+          for (int w = 0; w < K; ++w) any_blk = any_blk || Bc[h][w] != 0;
+        }
+        if (__ballot(any_blk) != 0) {  // wave-uniform
+          u64 A[K];
+#pragma unroll
+          for (int w = 0; w < K; ++w) A[w] = 0;
+          for (;;) {
+            u64 nA[K];
+            bool same = true;
+#pragma unroll
+            for (int h = 0; h < K; ++h) {
+              bool fire = fixed[h];
+#pragma unroll
+              for (int w = 0; w < K; ++w) fire = fire || (Bc[h][w] & ~A[w]) != 0;
+              nA[h] = __ballot(fire);
+            }
+#pragma unroll
+            for (int w = 0; w < K; ++w) {
+              same = same && nA[w] == A[w];
+              A[w] = nA[w];
+            }
+            if (same) break;
+          }
+#ifndef HWY_WIDE_MUTANT_NO_ABORT  // (tests/test_wide_kernel.py: a build that never applies the verdict must fail the comparison)
+#pragma unroll
+          for (int h = 0; h < K; ++h)
+            if ((A[h] >> l) & 1) me[h].tgt = me[h].lane;  // abort
+#endif
         }
       }
     }
@@ -710,15 +812,17 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       const double inv_v = fast_rcp(not_zero(mv.v));
       double tb = B::steer_tan_beta(p, mv.y, mv.h, inv_v, mv.tgt);
       double accel = free_self[h] - gap_own[h];
-      if (drives[h] && mv.lane != mv.tgt) {
+      {
         // leader on the target lane: that lane's mask for an ongoing change, the left / right lane evaluated above otherwise
+        // (gathered unconditionally -- a conditional LDS read is a branch with its own round trip -- and selected)
         const int f2 = (mv.tgt == tgt_old[h]) ? ft[h] : (mv.tgt == mv.lane - 1 ? fl[h] : frt[h]);
-        double a2 = free_self[h];
-        if (f2 >= 0) a2 = free_self[h] - B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, sh.x[f2], sh.v[f2], sh.c[f2], sh.s[f2]);
-        accel = (a2 < accel) ? a2 : accel;  // Python min(a, b)
+        const int g2 = f2 < 0 ? 0 : f2;
+        const double g2x = sh.x[g2], g2v = sh.v[g2], g2c = sh.c[g2], g2s = sh.s[g2];
+        const double a2 = f2 >= 0 ? free_self[h] - B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, g2x, g2v, g2c, g2s) : free_self[h];
+        accel = (drives[h] && mv.lane != mv.tgt && a2 < accel) ? a2 : accel;  // Python min(a, b)
       }
       accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);
-      accel = controlled[h] ? HWY_KP_A * (sh.ts[vi[h]] - mv.v) : accel;  // speed_control (controller.py:189-198), not clipped
+      accel = controlled[h] ? HWY_KP_A * (mv.ts - mv.v) : accel;  // speed_control (controller.py:189-198), not clipped
 
       x_old[h] = mv.x;
       // clip_actions (kinematics.py:155-168): a crashed vehicle has steering 0 (tan(beta) = 0), accel = -speed
@@ -731,10 +835,10 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       mv.x += vx * p.dt;
       mv.y += vy * p.dt;
       if (mv.flags & HWY_F_HAS_IMPACT) {
-        mv.x += sh.impx[vi[h]];
-        mv.y += sh.impy[vi[h]];
+        mv.x += mv.impx;
+        mv.y += mv.impy;
         mv.flags = (mv.flags | HWY_F_CRASHED) & ~HWY_F_HAS_IMPACT;
-        sh.impx[vi[h]] = sh.impy[vi[h]] = 0.0;
+        mv.impx = mv.impy = 0.0;
       }
       mv.h += mv.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       mv.v += accel * p.dt;
@@ -779,21 +883,33 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       while (walking || n_list) {
         while (walking && n_list < PASS) {
           // two walk steps per trip (k and k + 1, K slots): 2 K independent candidates whose LDS reads are in flight together
+          // (every LDS read of the trip is issued before anything depends on one: the slots are clamped by the range alone, the
+          // `go` flags -- which depend on what is read -- are folded in afterwards; a conditional read would be a branch with
+          // its own round trip)
           bool keep[2][K], going = false;
-          int q[2][K];
+          int q[2][K], rb[2][K];
+          double x0[2][K], px[2][K], py[2][K], pv[2][K];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int h = 0; h < K; ++h) {
-              const int rb = rank[h] + (k + u);
-              go[h] = go[h] && rb < N;
-              const int r = go[h] ? rb : 0;
-              go[h] = go[h] && !(fabs(sh.x[r] - x_old[h]) > reach);  // sh.x: frame-start x in rank order
-              if (u == 1) going = going || go[h];
-              const double dx = sh.lr[r] - me[h].x, dy = sh.c[r] - me[h].y;
-              const double lim = 5.5 + fmax(fabs(me[h].v), fabs(sh.v[r])) * p.dt;
+              rb[u][h] = rank[h] + (k + u);
+              const int r = rb[u][h] < N ? rb[u][h] : 0;
+              x0[u][h] = sh.x[r];  // frame-start x in rank order
+              px[u][h] = sh.lr[r]; py[u][h] = sh.c[r]; pv[u][h] = sh.v[r];
               q[u][h] = sh.idx[r];
-              keep[u][h] = go[h] && !(dx * dx + dy * dy > lim * lim);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int h = 0; h < K; ++h) {
+              const bool near = !(fabs(x0[u][h] - x_old[h]) > reach);
+              go[h] = go[h] & (rb[u][h] < N) & near;
+              if (u == 1) going = going || go[h];
+              const double dx = px[u][h] - me[h].x, dy = py[u][h] - me[h].y;
+              const double lim = 5.5 + fmax(fabs(me[h].v), fabs(pv[u][h])) * p.dt;
+              keep[u][h] = go[h] & !(dx * dx + dy * dy > lim * lim);
             }
           }
           k += 2;
@@ -865,8 +981,14 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       }
 #pragma unroll
       for (int h = 0; h < K; ++h) {
-        if (active[h] && sh.jmax[vi[h]] >= 0) me[h].flags |= HWY_F_HAS_IMPACT;
-        if (active[h] && sh.hit[vi[h]]) me[h].flags |= HWY_F_CRASHED;
+        // (the four reads are issued together; the translation slots only hold something where a pair of THIS frame wrote it)
+        const int jm = sh.jmax[vi[h]], ht = sh.hit[vi[h]];
+        const double ix = sh.impx[vi[h]], iy = sh.impy[vi[h]];
+        const bool pushed = active[h] && jm >= 0;
+        me[h].impx = pushed ? ix : me[h].impx;
+        me[h].impy = pushed ? iy : me[h].impy;
+        if (pushed) me[h].flags |= HWY_F_HAS_IMPACT;
+        if (active[h] && ht) me[h].flags |= HWY_F_CRASHED;
       }
     } else {
       // sparse checkers (highway-fast-v0 semantics: the controlled vehicles only), ascending index == loop order
@@ -896,8 +1018,8 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
                   r[h] = pair_collide(A, Bb, p.dt, &tx[h], &ty[h]);
                   if (!i_check[h]) {  // my only partners are the checkers (ascending c == loop order)
                     if (r[h] & 2) {
-                      sh.impx[vi[h]] = i_first ? tx[h] / 2 : -tx[h] / 2;
-                      sh.impy[vi[h]] = i_first ? ty[h] / 2 : -ty[h] / 2;
+                      me[h].impx = i_first ? tx[h] / 2 : -tx[h] / 2;
+                      me[h].impy = i_first ? ty[h] / 2 : -ty[h] / 2;
                       me[h].flags |= HWY_F_HAS_IMPACT;
                     }
                     if (r[h] & 1) me[h].flags |= HWY_F_CRASHED;
@@ -916,8 +1038,8 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
             if (l == lc) {
               if (wide_any<K>(im)) me[hc].flags |= HWY_F_CRASHED;
               if (wide_any<K>(wm)) {
-                sh.impx[c] = (c < q) ? qx / 2 : -qx / 2;
-                sh.impy[c] = (c < q) ? qy / 2 : -qy / 2;
+                me[hc].impx = (c < q) ? qx / 2 : -qx / 2;
+                me[hc].impy = (c < q) ? qy / 2 : -qy / 2;
                 me[hc].flags |= HWY_F_HAS_IMPACT;
               }
             }
@@ -936,8 +1058,6 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
 #pragma unroll
   for (int h = 0; h < K; ++h) {
     me[h].rank = rank[h];
-    me[h].timer = sh.timer[vi[h]]; me[h].ts = sh.ts[vi[h]]; me[h].delta = sh.delta[vi[h]];
-    me[h].impx = sh.impx[vi[h]]; me[h].impy = sh.impy[vi[h]];
     store_vehicle_at(q, e, vi[h], me[h], false);
   }
 }

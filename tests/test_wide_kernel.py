@@ -162,3 +162,47 @@ def test_wide_kernel_rollout_equals_single_steps(backend):
     _assert_same(one.get_state(), many.get_state(), "after the rollout")
     one.close()
     many.close()
+
+
+def test_abort_chain_on_the_emulator():
+    """The abort rule of ongoing lane changes runs per thread in rank space and is resolved to its fixed point by ballots
+    (hwy_wave2.h section D) -- against the workgroup kernel's literal link-by-link chain on dense traffic with many
+    simultaneous lane changes; a mutant that never applies a verdict must fail the same comparison."""
+    import ctypes as C
+    import tests.emu.emu as emu
+
+    def soak(E, T):
+        cfg_d = _abi.highway_default_config()
+        cfg_d.update({"vehicles_count": 110, "lanes_count": 3, "vehicles_density": 2.2, "duration": 12})
+        wide, block = _pair("emu", cfg_d, E, False)
+        cfg = _abi.make_config(cfg_d, E, fast=False)
+        st = spawn.spawn_reference_stream(cfg, np.arange(E) + 31, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+        for eng in (wide, block):
+            eng.set_state(_abi.copy_state(st))
+            eng.set_autoreset(True, base_seed=7, ego_spacing=cfg_d["ego_spacing"], vehicles_density=cfg_d["vehicles_density"])
+        rng = np.random.default_rng(3)
+        changing = 0
+        for t in range(T):
+            acts = rng.integers(0, 5, size=(E, 1)).astype(np.int32)
+            wide.step(acts)
+            block.step(acts)
+            a = wide.get_state()
+            _assert_same(a, block.get_state(), f"step {t}")
+            changing += int((a["lane"] != a["target_lane"]).sum())
+        wide.close()
+        block.close()
+        return changing
+
+    emu.build()
+    assert soak(6, 14) > 20  # ongoing lane changes at the step boundaries alone (the mutant below shows that links do abort)
+    src = emu.os.path.join(emu._HERE, "emu_engine.cpp")
+    saved = emu._lib
+    try:
+        mutant = emu.os.path.join(emu._HERE, "_build", "libhwy_emu_noabort.so")
+        emu.compile_emulator(src, mutant, ["-DHWY_WIDE_MUTANT_NO_ABORT=1"])
+        emu._lib = C.CDLL(mutant)
+        emu._lib.emu_config_size.restype = C.c_size_t
+        with pytest.raises(AssertionError):
+            soak(6, 14)
+    finally:
+        emu._lib = saved

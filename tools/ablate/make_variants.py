@@ -99,7 +99,7 @@ def wide_ticks(text):
              "    // ---- D. Road.act: lane-change policy (behavior.py:219-263)",
              "    // Straight-line evaluation for every slot",
              "    // safety of the new follower, only for candidates",
-             "    // abort rule for ongoing lane changes: ordered chain over Road.vehicles",
+             "    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain over Road.vehicles",
              "    // ---- E. Road.act: low-level control, F. Road.step: integrate",
              "    // ---- G. Road.step: collisions (road.py:477-481",
              "  }  // frames\n\n  // ---- H. observe"]
@@ -108,12 +108,18 @@ def wide_ticks(text):
     t = sub("    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n",
             "    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n  TICK(10)\n"
             "  if (l == 0 && q.obs) { for (int k = 0; k < 16; ++k) q.obs[(size_t)eo * q.A * q.V * q.F + k] = (float)acc[k]; }\n")(t)
-    # collisions split: [11] = publish + walk trips, [12] = SAT passes; [13] walk trips, [14] SAT passes with >= 1 pair, [15] pairs
-    t = sub("long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};", "long long acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
+    # collisions split: [11] = publish, [12] = walk trips, [13] = list passes, (G itself: the verdict reads); [14] walk trips, [15] list passes with >= 1 pair, [18] pairs
+    t = sub("long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};", "long long acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
+    t = sub("for (int k = 0; k < 16; ++k) q.obs", "for (int k = 0; k < 24; ++k) q.obs")(t)
+    t = sub("      const double reach = wide ? __builtin_inf()", "      TICK(11)\n      const double reach = wide ? __builtin_inf()")(t)
     t = sub("        const int count = n_list < PASS ? n_list : PASS;\n",
-            "        const int count = n_list < PASS ? n_list : PASS;\n        TICK(11)\n        acc[14] += count > 0; acc[15] += count;\n")(t)
-    t = sub("        head = (head + count) & (RING - 1);\n", "        head = (head + count) & (RING - 1);\n        TICK(12)\n")(t)
-    t = sub("          k += 2;\n          if (__ballot(going) == 0 || k > N) walking = false;", "          k += 2;\n          acc[13] += 1;\n          if (__ballot(going) == 0 || k > N) walking = false;")(t)
+            "        const int count = n_list < PASS ? n_list : PASS;\n        TICK(12)\n        acc[15] += count > 0; acc[18] += count;\n")(t)
+    t = sub("        head = (head + count) & (RING - 1);\n", "        head = (head + count) & (RING - 1);\n        TICK(13)\n")(t)
+    t = sub("          k += 2;\n          if (__ballot(going) == 0 || k > N) walking = false;", "          k += 2;\n          acc[14] += 1;\n          if (__ballot(going) == 0 || k > N) walking = false;")(t)
+    # abort chain: [16] changers, [17] frames with a chain, [20] walk trips, [21] fixed-point rounds
+    t = sub("      if (chain) {  // wave-uniform\n", "      if (chain) {  // wave-uniform\n        acc[16] += wide_popc<K>(cm); acc[17] += 1;\n")(t)
+    t = sub("        while (__ballot(any_left) != 0) {  // wave-uniform\n", "        while (__ballot(any_left) != 0) {  // wave-uniform\n          acc[20] += 1;\n")(t)
+    t = sub("            if (same) break;", "            acc[21] += 1;\n            if (same) break;")(t)
     return t
 
 
