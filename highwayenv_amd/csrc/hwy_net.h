@@ -910,28 +910,22 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
       const bool wide = !calm && __ballot(present && !(fabs(me.v) <= 50.0 && moved <= 50.0 * p.dt + 3.0)) != 0;
       const double vb = (calm ? 36.0 : 50.0) * p.dt;
       const double reach = wide ? __builtin_inf() : (5.5 + vb) + 2.0 * (vb + (calm ? 0.0 : 3.0));
+      // (FORWARD only since round 4: every unordered pair is met once, from its rear end -- half the walk, half the candidates)
       u64 cand = 0;
-      bool go_a = present, go_b = present;
+      bool go_b = present;
       for (int k = 1; k < n_present; ++k) {
-        const int ra = rank - k, rb = rank + k;
-        go_a = go_a && ra >= 0;
+        const int rb = rank + k;
         go_b = go_b && rb < n_present;
-        const int ia_ = go_a ? ra : 0, ib_ = go_b ? rb : 0;
-        go_a = go_a && !(fabs(sh.x[ia_] - x_old) > reach);
-        go_b = go_b && !(fabs(sh.x[ib_] - x_old) > reach);
-        if (__ballot(go_a || go_b) == 0) break;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          const bool go = side ? go_b : go_a;
-          const int r2 = side ? ib_ : ia_;
-          const double dx = sh.nx[r2] - me.x, dy = sh.ny[r2] - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.nv[r2])) * p.dt;
-          const bool near = go && !(dx * dx + dy * dy > lim * lim);
-          cand |= near ? ((u64)1 << r2) : 0;
-        }
+        const int r2 = go_b ? rb : 0;
+        go_b = go_b && !(fabs(sh.x[r2] - x_old) > reach);
+        if (__ballot(go_b) == 0) break;
+        const double dx = sh.nx[r2] - me.x, dy = sh.ny[r2] - me.y;
+        const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.nv[r2])) * p.dt;
+        const bool near = go_b && !(dx * dx + dy * dy > lim * lim);
+        cand |= near ? ((u64)1 << r2) : 0;
       }
       // Phase 2: the collected partners are filtered (pair type, checkers, provable separation) and every unordered pair
-      // that survives is listed ONCE, by the thread of its lower slot; phase 3 runs the SAT one PAIR per thread -- one pass
+      // that survives is listed, lower slot first; phase 3 runs the SAT one PAIR per thread -- one pass
       // for the whole wave instead of one pass per partner rank -- and the verdicts meet per slot in LDS: crashed flags,
       // the highest partner slot with a pending impact ("last pair in loop order wins") and that pair's translation.
       // (the snapshot arrays of this frame are dead here: they hold the per-slot results and the pair list)
@@ -947,14 +941,14 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
       while (pending || n_list) {
         while (pending && n_list < 64) {
           bool keep = false;
-          int r2 = 0;
+          int r2 = 0, q = 0;
           if (cand != 0) {
             r2 = ctz64(cand);
             cand &= cand - 1;
-            const int q = sh.idx[r2];
+            q = sh.idx[r2];
             const bool q_obs = sh.kind[r2] == 0;
-            // every pair once (lower slot); road.py:477-481: vehicle-vehicle and vehicle-object pairs only; objects.py:98
-            if (i < q && !(obstacle && q_obs) && (i_check || ((chk >> q) & 1))) {
+            // road.py:477-481: vehicle-vehicle and vehicle-object pairs only; objects.py:98
+            if (!(obstacle && q_obs) && (i_check || ((chk >> q) & 1))) {
               const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
                                   q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
               // provable separation on MY two body axes (any axis of either rectangle is one of the SAT's axes)
@@ -963,7 +957,7 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
           }
           const u64 km = __ballot(keep);
           if (km) {
-            if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(rank | (r2 << 8));
+            if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q ? (rank | (r2 << 8)) : (r2 | (rank << 8)));
             n_list += __popcll(km);
           }
           pending = __ballot(cand != 0);

@@ -545,20 +545,20 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
     const Body mine{me.x, me.y, me.v, me.ch, me.sh};
     if (all_check) {
-      // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among my
-      // neighbours along the road, so instead of walking all N partners each thread scans outward from its
-      // own rank, in both directions, in the rank order established at the start of this frame, and stops
-      // when the partner's FRAME-START distance exceeds the collision radius plus the most two vehicles can
-      // have moved relative to each other within one frame.  Everything within reach is visited, so the
-      // result equals the full loop; "last pair in loop order wins" == the partner with the highest index.
+      // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among neighbours along
+      // the road: every vehicle walks FORWARD in the rank order established at the start of this frame (each unordered pair is
+      // met once, from its rear end; rounds 1-3 walked both ways and dropped half of what they met), and stops when the
+      // partner's FRAME-START distance exceeds the collision radius plus the most two vehicles can have moved relative to each
+      // other within one frame.  Everything within reach is visited, so the result equals the full loop; "last pair in loop
+      // order wins" == the partner with the highest index.
       sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
       const bool wide = __ballot(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
       HWY_WAVE_LDS_FENCE();
-      // Every unordered pair once, by the thread of its lower slot: the walk only COLLECTS the pairs that pass the sphere
-      // pre-check and the provable-separation test; the SAT then runs one PAIR per thread -- one pass for the whole wave
-      // instead of one per walk step in which some thread met a close partner -- and the verdicts meet per slot in LDS
-      // (crashed flags, the highest partner slot with a pending impact, that pair's translation).  The rank-ordered
-      // snapshot of this frame (v, lr) is dead here and holds the pair list and the per-slot results.
+      // The walk only COLLECTS the partners inside the reference's own pre-check sphere (objects.py:124-127), a dozen VALU
+      // instructions per candidate; the list pass then runs, one PAIR per thread, the provable-separation test and -- if any
+      // pair of the wavefront survives it -- the SAT, and the verdicts meet per slot in LDS (crashed flags, the highest partner
+      // slot with a pending impact, that pair's translation).  The rank-ordered snapshot of this frame (v, lr) is dead here
+      // and holds the pair list and the per-slot results.
       int *const jmax = reinterpret_cast<int *>(sh.lr), *const hit = jmax + 64;
       unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.v);  // 256 entries: lower slot | higher slot << 8
       jmax[i] = -1;
@@ -570,30 +570,36 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
       const u64 below = ((u64)1 << i) - 1;
       int n_list = 0, k = 1;  // wave-uniform
-      bool go_a = active, go_b = active, walking = true;
+      bool go_b = active, walking = true;
       while (walking || n_list) {
         while (walking && n_list < 64) {
-          const int ra = rank - k, rb = rank + k;
-          go_a = go_a && ra >= 0;
-          go_b = go_b && rb < N;
-          const int ia_ = go_a ? ra : 0, ib_ = go_b ? rb : 0;
-          go_a = go_a && !(fabs(sh.x[ia_] - x_old) > reach);  // sh.x: frame-start x in rank order
-          go_b = go_b && !(fabs(sh.x[ib_] - x_old) > reach);
-          ++k;
-          if (__ballot(go_a || go_b) == 0 || k > N) walking = false;
+          // two walk steps per trip; the slots are clamped by the range alone so that every LDS read of the trip is issued
+          // before anything depends on one (a conditional read is a branch with its own round trip)
+          bool keep[2];
+          int q[2];
+          double x0[2], px[2], py[2], pv[2];
 #pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const int q = sh.idx[side ? ib_ : ia_];
-            bool keep = false;
-            if ((side ? go_b : go_a) && i < q) {
-              const Body other{sh.nx[q], sh.ny[q], sh.nv[q], sh.nc[q], sh.ns[q]};
-              const double dx = other.x - me.x, dy = other.y - me.y;
-              const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
-              keep = !(dx * dx + dy * dy > lim * lim) && !surely_apart(mine, other, p.dt);
-            }
-            const u64 km = __ballot(keep);
+          for (int u = 0; u < 2; ++u) {
+            const int rb = rank + k + u, r = rb < N ? rb : 0;
+            q[u] = sh.idx[r];
+            x0[u] = sh.x[r];  // sh.x: frame-start x in rank order
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) { px[u] = sh.nx[q[u]]; py[u] = sh.ny[q[u]]; pv[u] = sh.nv[q[u]]; }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            go_b = go_b & (rank + k + u < N) & !(fabs(x0[u] - x_old) > reach);
+            const double dx = px[u] - me.x, dy = py[u] - me.y;
+            const double lim = 5.5 + fmax(fabs(me.v), fabs(pv[u])) * p.dt;
+            keep[u] = go_b & !(dx * dx + dy * dy > lim * lim);
+          }
+          k += 2;
+          if (__ballot(go_b) == 0 || k > N) walking = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const u64 km = __ballot(keep[u]);
             if (km) {
-              if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i | (q << 8));
+              if (keep[u]) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q[u] ? (i | (q[u] << 8)) : (q[u] | (i << 8)));
               n_list += __popcll(km);
             }
           }
@@ -602,22 +608,25 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
         HWY_WAVE_LDS_FENCE();
         const int pair = i < count ? (int)plist[i] : -1;
         const int c0 = i < left ? (int)plist[count + i] : 0, c1 = 64 + i < left ? (int)plist[count + 64 + i] : 0;
-        const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+        const int a = pair < 0 ? 0 : (pair & 255), b = pair < 0 ? 0 : (pair >> 8);  // a < b: the reference's `self` and `other`
         int r = 0;
         double tx = 0.0, ty = 0.0;
-        if (pair >= 0) {
-          const Body A{sh.nx[a], sh.ny[a], sh.nv[a], sh.nc[a], sh.ns[a]}, Bb{sh.nx[b], sh.ny[b], sh.nv[b], sh.nc[b], sh.ns[b]};
-          r = pair_collide(A, Bb, p.dt, &tx, &ty);
-          if (r & 1) hit[a] = hit[b] = 1;
-          if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
-            __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const Body A{sh.nx[a], sh.ny[a], sh.nv[a], sh.nc[a], sh.ns[a]}, Bb{sh.nx[b], sh.ny[b], sh.nv[b], sh.nc[b], sh.ns[b]};
+        const bool cand = pair >= 0 && !surely_apart(A, Bb, p.dt);
+        if (__ballot(cand) != 0) {  // wave-uniform
+          if (cand) {
+            r = pair_collide(A, Bb, p.dt, &tx, &ty);
+            if (r & 1) hit[a] = hit[b] = 1;
+            if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
+              __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
-        }
-        HWY_WAVE_LDS_FENCE();
-        if (r & 2) {
-          if (jmax[a] == b) { sh.impx[a] = tx / 2; sh.impy[a] = ty / 2; }
-          if (jmax[b] == a) { sh.impx[b] = -tx / 2; sh.impy[b] = -ty / 2; }
+          HWY_WAVE_LDS_FENCE();
+          if (r & 2) {
+            if (jmax[a] == b) { sh.impx[a] = tx / 2; sh.impy[a] = ty / 2; }
+            if (jmax[b] == a) { sh.impx[b] = -tx / 2; sh.impy[b] = -ty / 2; }
+          }
         }
         if (i < left) plist[i] = (unsigned short)c0;
         if (64 + i < left) plist[64 + i] = (unsigned short)c1;
