@@ -79,3 +79,15 @@ def test_workgroup_kernel_allocation(res):
         assert r3["workgroup"] == 64 * w and r3["lds"] == r4["lds"]
         # LDS never limits below what the registers allow: (waves/SIMD x 4 SIMDs) / W workgroups per CU
         assert (12 // w) * r3["lds"] <= LDS_PER_CU and (16 // w) * r4["lds"] <= LDS_PER_CU, (r3, r4)
+
+
+def test_wide_kernel_allocation(res):
+    """hwy_step_wide_kernel<2, 2> (64 < N <= 128: BASELINE config 3, one wavefront per environment with two vehicles per thread):
+    no spills, registers for two wavefronts per SIMD (1024 environments hold one, 2048 two) and LDS for the eight one-wavefront
+    workgroups per CU that go with them."""
+    for fam in ("hwy_step_wide_kernel", "hwy_rollout_wide_kernel"):
+        r = res[f"hwy::{fam}<2, 2>"]
+        assert r["vgpr_spill"] == 0 and r["scratch"] <= 36, r
+        assert waves_per_simd(r["vgpr"]) >= 2, r
+        assert 8 * r["lds"] <= LDS_PER_CU, r
+        assert r["workgroup"] == 64
