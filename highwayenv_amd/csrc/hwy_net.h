@@ -897,10 +897,9 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
     if (present) { sh.nx[rank] = me.x; sh.ny[rank] = me.y; sh.nv[rank] = me.v; sh.nc[rank] = me.ch; sh.ns[rank] = me.sh; }
     HWY_WAVE_LDS_FENCE();
     {
-      // Phase 1, wave-uniform walk outwards in rank order (partners at rank - k and rank + k), bounded by the
-      // frame-start distance: lim of the sphere pre-check below + what two bodies can move towards each other in
-      // one frame (speed * dt each, + a pending impact each).  Speeds stay below 36 m/s in practice; the bound falls
-      // back to 50 m/s if any body is faster.  Close pairs are only COLLECTED here (bit r2 of `cand`, rank space).
+      // A wave-uniform walk in rank order (partners at rank + k), bounded by the frame-start distance: lim of the
+      // sphere pre-check below + what two bodies can move towards each other in one frame (speed * dt each, + a
+      // pending impact each).  Speeds stay below 36 m/s in practice; the bound falls back to 50 m/s if any body is faster.
       // Both tiers are checked on the ACTUAL values of this frame (`moved` = what the integration, pending impact
       // included, did to x; the speed afterwards for the radius term): nothing clamps speeds in the reference
       // (kinematics.py:155-168 only pulls them back) and an Obstacle hands the vehicle the whole translation, so a body
@@ -910,85 +909,69 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
       const bool wide = !calm && __ballot(present && !(fabs(me.v) <= 50.0 && moved <= 50.0 * p.dt + 3.0)) != 0;
       const double vb = (calm ? 36.0 : 50.0) * p.dt;
       const double reach = wide ? __builtin_inf() : (5.5 + vb) + 2.0 * (vb + (calm ? 0.0 : 3.0));
-      // (FORWARD only since round 4: every unordered pair is met once, from its rear end -- half the walk, half the candidates)
-      u64 cand = 0;
-      bool go_b = present;
-      for (int k = 1; k < n_present; ++k) {
-        const int rb = rank + k;
-        go_b = go_b && rb < n_present;
-        const int r2 = go_b ? rb : 0;
-        go_b = go_b && !(fabs(sh.x[r2] - x_old) > reach);
-        if (__ballot(go_b) == 0) break;
-        const double dx = sh.nx[r2] - me.x, dy = sh.ny[r2] - me.y;
-        const double lim = 5.5 + fmax(fabs(me.v), fabs(sh.nv[r2])) * p.dt;
-        const bool near = go_b && !(dx * dx + dy * dy > lim * lim);
-        cand |= near ? ((u64)1 << r2) : 0;
-      }
-      // Phase 2: the collected partners are filtered (pair type, checkers, provable separation) and every unordered pair
-      // that survives is listed, lower slot first; phase 3 runs the SAT one PAIR per thread -- one pass
-      // for the whole wave instead of one pass per partner rank -- and the verdicts meet per slot in LDS: crashed flags,
-      // the highest partner slot with a pending impact ("last pair in loop order wins") and that pair's translation.
+      // FORWARD only (round 4): every unordered pair is met once, from its rear end -- half the walk of rounds 1-3, which went
+      // both ways and dropped half of what they met.  A walk step only COLLECTS the partner inside the reference's pre-check
+      // sphere, as a list entry (lower slot's rank | higher slot's rank << 8); the list pass then filters one PAIR per thread
+      // (pair type, checkers, provable separation) and runs the SAT if any pair of the wavefront survives -- one pass for the
+      // whole wave instead of one trip per candidate of the busiest thread -- and the verdicts meet per slot in LDS: crashed
+      // flags, the highest partner slot with a pending impact ("last pair in loop order wins") and that pair's translation.
       // (the snapshot arrays of this frame are dead here: they hold the per-slot results and the pair list)
-      const NetBody mine{me.x, me.y, me.v, me.ch, me.sh, obstacle ? 1.0 : HWY_VEH_LENGTH / 2, obstacle ? 1.0 : HWY_VEH_WIDTH / 2};
       int *const jmax = reinterpret_cast<int *>(sh.lr), *const hit = reinterpret_cast<int *>(sh.ox);
       double *const ipx = sh.v, *const ipy = sh.c;
-      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.scratch);  // 128 entries: rank | partner rank << 8
+      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.scratch);  // 128 entries
       jmax[i] = -1;
       hit[i] = 0;
       const u64 below = ((u64)1 << i) - 1;
-      int n_list = 0;  // wave-uniform
-      u64 pending = __ballot(cand != 0);
-      while (pending || n_list) {
-        while (pending && n_list < 64) {
-          bool keep = false;
-          int r2 = 0, q = 0;
-          if (cand != 0) {
-            r2 = ctz64(cand);
-            cand &= cand - 1;
-            q = sh.idx[r2];
-            const bool q_obs = sh.kind[r2] == 0;
-            // road.py:477-481: vehicle-vehicle and vehicle-object pairs only; objects.py:98
-            if (!(obstacle && q_obs) && (i_check || ((chk >> q) & 1))) {
-              const NetBody other{sh.nx[r2], sh.ny[r2], sh.nv[r2], sh.nc[r2], sh.ns[r2], q_obs ? 1.0 : HWY_VEH_LENGTH / 2,
-                                  q_obs ? 1.0 : HWY_VEH_WIDTH / 2};
-              // provable separation on MY two body axes (any axis of either rectangle is one of the SAT's axes)
-              keep = !net_surely_apart(mine, other, p.dt);
-            }
-          }
-          const u64 km = __ballot(keep);
+      int n_list = 0, k = 1;  // wave-uniform
+      bool go_b = present, walking = true;
+      while (walking || n_list) {
+        while (walking && n_list < 64) {
+          const int rb = rank + k;
+          const int r2 = rb < n_present ? rb : 0;
+          // (all four reads are issued before anything depends on one)
+          const double x0 = sh.x[r2], px = sh.nx[r2], py = sh.ny[r2], pv = sh.nv[r2];
+          const int q = sh.idx[r2];
+          go_b = go_b & (rb < n_present) & !(fabs(x0 - x_old) > reach);
+          ++k;
+          if (__ballot(go_b) == 0 || k >= n_present) walking = false;
+          const double dx = px - me.x, dy = py - me.y;
+          const double lim = 5.5 + fmax(fabs(me.v), fabs(pv)) * p.dt;
+          const bool near = go_b & !(dx * dx + dy * dy > lim * lim);
+          const u64 km = __ballot(near);
           if (km) {
-            if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q ? (rank | (r2 << 8)) : (r2 | (rank << 8)));
+            if (near) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q ? (rank | (r2 << 8)) : (r2 | (rank << 8)));
             n_list += __popcll(km);
           }
-          pending = __ballot(cand != 0);
         }
-        const int count = n_list < 64 ? n_list : 64, left = n_list - count;
+        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64
         HWY_WAVE_LDS_FENCE();
         const int pair = i < count ? (int)plist[i] : -1;
         const int carry = i < left ? (int)plist[count + i] : 0;
-        int r = 0, a = 0, b = 0;
-        bool a_veh = false, b_veh = false;
+        const int ra = pair < 0 ? 0 : (pair & 255), rb = pair < 0 ? 0 : (pair >> 8);
+        const int a = sh.idx[ra], b = sh.idx[rb];  // a < b: the reference's `self` and `other`
+        const bool a_veh = sh.kind[ra] != 0, b_veh = sh.kind[rb] != 0;
+        const NetBody A{sh.nx[ra], sh.ny[ra], sh.nv[ra], sh.nc[ra], sh.ns[ra], a_veh ? HWY_VEH_LENGTH / 2 : 1.0, a_veh ? HWY_VEH_WIDTH / 2 : 1.0};
+        const NetBody Bb{sh.nx[rb], sh.ny[rb], sh.nv[rb], sh.nc[rb], sh.ns[rb], b_veh ? HWY_VEH_LENGTH / 2 : 1.0, b_veh ? HWY_VEH_WIDTH / 2 : 1.0};
+        // road.py:477-481: vehicle-vehicle and vehicle-object pairs only; objects.py:98: one of the two must check collisions;
+        // provable separation on the lower slot's two body axes (any axis of either rectangle is one of the SAT's axes)
+        const bool cnd = pair >= 0 && (a_veh || b_veh) && ((((chk >> a) | (chk >> b)) & 1) != 0) && !net_surely_apart(A, Bb, p.dt);
+        int r = 0;
         double tx = 0.0, ty = 0.0;
-        if (pair >= 0) {
-          const int ra = pair & 255, rb = pair >> 8;
-          a = sh.idx[ra];
-          b = sh.idx[rb];  // a < b: the reference's `self` and `other`
-          a_veh = sh.kind[ra] != 0;
-          b_veh = sh.kind[rb] != 0;
-          const NetBody A{sh.nx[ra], sh.ny[ra], sh.nv[ra], sh.nc[ra], sh.ns[ra], a_veh ? HWY_VEH_LENGTH / 2 : 1.0, a_veh ? HWY_VEH_WIDTH / 2 : 1.0};
-          const NetBody Bb{sh.nx[rb], sh.ny[rb], sh.nv[rb], sh.nc[rb], sh.ns[rb], b_veh ? HWY_VEH_LENGTH / 2 : 1.0, b_veh ? HWY_VEH_WIDTH / 2 : 1.0};
-          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
-          if (r & 1) hit[a] = hit[b] = 1;
-          if (r & 2) {
-            if (a_veh) __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (b_veh) __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__ballot(cnd) != 0) {  // wave-uniform
+          if (cnd) {
+            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);
+            if (r & 1) hit[a] = hit[b] = 1;
+            if (r & 2) {
+              if (a_veh) __hip_atomic_fetch_max(&jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (b_veh) __hip_atomic_fetch_max(&jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
-        }
-        HWY_WAVE_LDS_FENCE();
-        if (r & 2) {  // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
-          const double sa = b_veh ? 0.5 : 1.0, sb = a_veh ? 0.5 : 1.0;
-          if (a_veh && jmax[a] == b) { ipx[a] = tx * sa; ipy[a] = ty * sa; }
-          if (b_veh && jmax[b] == a) { ipx[b] = -tx * sb; ipy[b] = -ty * sb; }
+          HWY_WAVE_LDS_FENCE();
+          if (r & 2) {  // objects.py:103-113: against an Obstacle the vehicle takes the whole translation
+            const double sa = b_veh ? 0.5 : 1.0, sb = a_veh ? 0.5 : 1.0;
+            if (a_veh && jmax[a] == b) { ipx[a] = tx * sa; ipy[a] = ty * sa; }
+            if (b_veh && jmax[b] == a) { ipx[b] = -tx * sb; ipy[b] = -ty * sb; }
+          }
         }
         if (i < left) plist[i] = (unsigned short)carry;
         n_list = left;

@@ -146,7 +146,7 @@ def net_ticks(text):
     t = sub("      // Phase 2: the collected partners are filtered", "      TICK(10)\n      // Phase 2: the collected partners are filtered")(t)
     t = sub("  }  // frames\n\n  // ---- G. observe", "  TICK(12)\n  }  // frames\n\n  // ---- G. observe")(t)
     t = sub("    TICK(10)\n  TICK(12)\n  }  // frames", "  TICK(12)\n  }  // frames")(t)
-    t = sub("        if (__ballot(go_a || go_b) == 0) break;", "        if (__ballot(go_a || go_b) == 0) break;\n        n_walk += 1.0f;")(t)
+    t = sub("        if (__ballot(go_b) == 0) break;", "        if (__ballot(go_b) == 0) break;\n        n_walk += 1.0f;")(t)
     t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count",
             "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        n_trip += 1.0f;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count")(t)
     t = sub("          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "          n_sat += 1.0f;\n          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
