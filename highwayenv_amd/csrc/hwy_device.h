@@ -1414,6 +1414,22 @@ __device__ inline double math_probe(int op, double x) {
     case 9: return atan2_bounded(x, 0.75);
     case 10: return atan2_bounded(0.5, x);
     case 11: return atan2_bounded(-0.5, x);
+    // the paired forms (hwy_math.h: two evaluations sharing every coefficient) against the scalar ones: ops 20 + 2 k / 21 + 2 k
+    // return the first / second result of routine k for the arguments (x, f(x)) / (f(x), x), f = another point of the domain
+    case 20: { double a, b; log_pos2(x, 0.37 * x + 0.011, a, b); return a; }
+    case 21: { double a, b; log_pos2(0.37 * x + 0.011, x, a, b); return b; }
+    case 22: { double a, b; exp_bounded2(x, 0.5 * x - 1.25, a, b); return a; }
+    case 23: { double a, b; exp_bounded2(0.5 * x - 1.25, x, a, b); return b; }
+    case 24: { double a, b, c2, d; sincos_bounded2(x, 1.0 - x, &a, &b, &c2, &d); return a; }
+    case 25: { double a, b, c2, d; sincos_bounded2(x, 1.0 - x, &a, &b, &c2, &d); return b; }
+    case 26: { double a, b, c2, d; sincos_bounded2(1.0 - x, x, &a, &b, &c2, &d); return c2; }
+    case 27: { double a, b, c2, d; sincos_bounded2(1.0 - x, x, &a, &b, &c2, &d); return d; }
+    case 28: { double a, b; asin_bounded2(x, -0.6 * x, a, b); return a; }
+    case 29: { double a, b; asin_bounded2(-0.6 * x, x, a, b); return b; }
+    case 30: { double a, b; fast_rcp2(x, 3.0 * x, a, b); return a; }
+    case 31: { double a, b; fast_rcp2(3.0 * x, x, a, b); return b; }
+    case 32: { double a, b; fast_rsqrt2(x, 3.0 * x, a, b); return a; }
+    case 33: { double a, b; fast_rsqrt2(3.0 * x, x, a, b); return b; }
     default: return wrap_to_pi(x);
   }
 }

@@ -831,26 +831,31 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
             const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
             const double dx = other.x - mine.x, dy = other.y - mine.y;
             const double lim = 5.5 + fmax(fabs(mine.v), fabs(other.v)) * p.dt;
-            if (!(dx * dx + dy * dy <= lim * lim)) return false;  // objects.py:124-127
-            return !surely_apart(mine, other, p.dt);  // (hwy_device.h: provably (False, False) without the SAT)
+            return dx * dx + dy * dy <= lim * lim;  // objects.py:124-127 (the pre-check sphere: a dozen instructions per trip)
           },
           [&](int pair, bool) {
-            const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+            // one PAIR per thread: the provable-separation test (hwy_device.h: provably (False, False) without the SAT) and, if
+            // any pair of the wavefront survives it, the SAT.  (Rounds 1-3 ran the separation test inside the partner loop,
+            // under divergence, once per trip in which any thread had a partner inside its sphere: nearly every trip in a queue.)
+            const int a = pair < 0 ? 0 : (pair & 255), b = pair < 0 ? 0 : (pair >> 8);  // a < b: the reference's `self` and `other`
+            const Body A{sh.x[a], sh.y[a], sh.v[a], sh.c[a], sh.s[a]}, Bb{sh.x[b], sh.y[b], sh.v[b], sh.c[b], sh.s[b]};
+            const bool cnd = pair >= 0 && !surely_apart(A, Bb, p.dt);
             int r = 0;
             double tx = 0.0, ty = 0.0;
-            if (pair >= 0) {
-              const Body A{sh.x[a], sh.y[a], sh.v[a], sh.c[a], sh.s[a]}, Bb{sh.x[b], sh.y[b], sh.v[b], sh.c[b], sh.s[b]};
-              r = pair_collide(A, Bb, p.dt, &tx, &ty);
-              if (r & 1) sh.flag[a] = sh.flag[b] = 1;
-              if (r & 2) {  // the impact of the HIGHEST partner slot stays (the reference's loop overwrites)
-                __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__ballot(cnd) != 0) {  // wave-uniform
+              if (cnd) {
+                r = pair_collide(A, Bb, p.dt, &tx, &ty);
+                if (r & 1) sh.flag[a] = sh.flag[b] = 1;
+                if (r & 2) {  // the impact of the HIGHEST partner slot stays (the reference's loop overwrites)
+                  __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
               }
-            }
-            HWY_WAVE_LDS_FENCE();
-            if (r & 2) {
-              if (sh.jmax[a] == b) { sh.bcx[a] = tx / 2; sh.bcy[a] = ty / 2; }
-              if (sh.jmax[b] == a) { sh.bcx[b] = -tx / 2; sh.bcy[b] = -ty / 2; }
+              HWY_WAVE_LDS_FENCE();
+              if (r & 2) {
+                if (sh.jmax[a] == b) { sh.bcx[a] = tx / 2; sh.bcy[a] = ty / 2; }
+                if (sh.jmax[b] == a) { sh.bcx[b] = -tx / 2; sh.bcy[b] = -ty / 2; }
+              }
             }
           });
       HWY_WAVE_LDS_FENCE();

@@ -18,6 +18,42 @@
 
 namespace hwy {
 
+// ---- paired forms of the per-vehicle routines (hwy_math.h: the two vehicles of a thread share every coefficient and their
+//      chains are interleaved by construction); statement by statement the scalar ones, bit-identical results -------------------
+__device__ inline void wrap_to_pi2(double x0, double x1, double &o0, double &o1) {
+  const double a0 = x0 + HWY_PI, a1 = x1 + HWY_PI;
+  double m0 = a0, m1 = a1;
+  if (!(a0 >= 0 && a0 < 2 * HWY_PI && a1 >= 0 && a1 < 2 * HWY_PI)) {  // (py_mod_pos returns an already reduced argument as it is)
+    m0 = py_mod_pos(a0, 2 * HWY_PI);
+    m1 = py_mod_pos(a1, 2 * HWY_PI);
+  }
+  o0 = m0 - HWY_PI;
+  o1 = m1 - HWY_PI;
+}
+// EnvBlock::steer_tan_beta for two vehicles
+__device__ inline void steer_tan_beta2(const StepParams &p, double y0, double h0, double iv0, int tgt0, double y1, double h1, double iv1,
+                                       int tgt1, double &o0, double &o1) {
+  const double lat0 = y0 - tgt0 * p.lane_width, lat1 = y1 - tgt1 * p.lane_width;
+  const double a0 = clipd((-HWY_KP_LATERAL * lat0) * iv0, -1.0, 1.0), a1 = clipd((-HWY_KP_LATERAL * lat1) * iv1, -1.0, 1.0);
+  const double s45 = 0.7071067811865476;  // sin(pi/4) rounded up: |a| >= s45 => |asin a| >= pi/4 (clipped)
+  double as0, as1;
+  asin_bounded2(a0, a1, as0, as1);
+  const double hr0 = a0 >= s45 ? HWY_PI / 4 : (a0 <= -s45 ? -HWY_PI / 4 : clipd(as0, -HWY_PI / 4, HWY_PI / 4));
+  const double hr1 = a1 >= s45 ? HWY_PI / 4 : (a1 <= -s45 ? -HWY_PI / 4 : clipd(as1, -HWY_PI / 4, HWY_PI / 4));
+  double wr0, wr1;
+  wrap_to_pi2(hr0 - h0, hr1 - h1, wr0, wr1);
+  const double c0 = HWY_KP_HEADING * wr0, c1 = HWY_KP_HEADING * wr1;
+  const double w0 = clipd((HWY_VEH_LENGTH / 2 * iv0) * c0, -1.0, 1.0), w1 = clipd((HWY_VEH_LENGTH / 2 * iv1) * c1, -1.0, 1.0);
+  const double tan_max = 1.7320508075688767;  // tan(MAX_STEERING_ANGLE = fl(pi/3)) in f64
+  const double w20 = 1 - w0 * w0, w21 = 1 - w1 * w1;
+  double rs0, rs1;
+  fast_rsqrt2(w20 <= 1e-12 ? 1.0 : w20, w21 <= 1e-12 ? 1.0 : w21, rs0, rs1);
+  const double ts0 = (w20 <= 1e-12) ? copysign(tan_max, w0) : clipd((2 * w0) * rs0, -tan_max, tan_max);
+  const double ts1 = (w21 <= 1e-12) ? copysign(tan_max, w1) : clipd((2 * w1) * rs1, -tan_max, tan_max);
+  o0 = 0.5 * ts0;
+  o1 = 0.5 * ts1;
+}
+
 template <int K>
 struct WideShared {
   static constexpr int NV = 64 * K;
@@ -109,6 +145,19 @@ __device__ __forceinline__ void wide_mask_neighbours(const u64 (&m)[K], int r, i
   }
   *front = f;
   *rear = b;
+}
+
+// the front rank only (the own lane and the target lane are never asked for a follower)
+template <int K>
+__device__ __forceinline__ int wide_mask_front(const u64 (&m)[K], int r) {
+  const int rw = r >> 6, rb = r & 63;
+  int f = -1;
+#pragma unroll
+  for (int h = K - 1; h >= 0; --h) {
+    const u64 mm = (h == rw) ? (m[h] & ~(((u64)2 << rb) - 1)) : ((h < rw) ? 0 : m[h]);
+    f = mm ? h * 64 + ctz64(mm) : f;
+  }
+  return f;
 }
 
 // Road.neighbour_vehicles literal scan for the equal-x case (wave_neighbours_scan of hwy_wave.h over K slots per thread)
@@ -498,6 +547,17 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
     // ---- C. rank along the road, lane membership masks, frame-start snapshot ------------------------------
     wide_update_rank<K>(sh, me, N, rank, has_tie);
     double log_ratio[K];
+    if (fr == 0) {  // (after the meta-action: the target speed is fixed for the step)
+#pragma unroll
+      for (int h = 0; h < K; ++h) inv_v0[h] = B::idm_inv_v0(p, me[h].ts);
+    }
+    if constexpr (K == 2) {  // EnvBlock::idm_log_ratio_inv for both vehicles at once (log_pos2: hwy_math.h)
+      const double r0 = fmax(me[0].v, 0.0) * inv_v0[0], r1 = fmax(me[1].v, 0.0) * inv_v0[1];
+      double l0, l1;
+      log_pos2(r0 > 0.0 ? r0 : 1.0, r1 > 0.0 ? r1 : 1.0, l0, l1);
+      log_ratio[0] = active[0] ? (r0 > 0.0 ? l0 : -__builtin_inf()) : 0.0;
+      log_ratio[1] = active[1] ? (r1 > 0.0 ? l1 : -__builtin_inf()) : 0.0;
+    }
     HWY_WAVE_LDS_FENCE();  // previous readers of the snapshot / sbits are done
 #pragma unroll
     for (int h = 0; h < K; ++h) {
@@ -505,8 +565,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       int bits = 0;
       for (int L = 0; L < p.L; ++L)
         bits |= (inr && (fabs(me[h].y - L * p.lane_width) <= p.lane_width / 2 + 1.0)) ? (1 << L) : 0;
-      if (fr == 0) inv_v0[h] = B::idm_inv_v0(p, me[h].ts);  // (after the meta-action: the target speed is fixed for the step)
-      log_ratio[h] = active[h] ? B::idm_log_ratio_inv(me[h].v, inv_v0[h]) : 0.0;
+      if constexpr (K != 2) log_ratio[h] = active[h] ? B::idm_log_ratio_inv(me[h].v, inv_v0[h]) : 0.0;
       const int r = rank[h];
       sh.sbits[r] = bits;
       if (active[h]) {
@@ -553,7 +612,6 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       mv.timer = idm[h] ? (decide[h] ? 0.0 : timer) + p.dt : timer;
       left_ok[h] = mv.lane - 1 >= 0;
       right_ok[h] = mv.lane + 1 < p.L;
-      int ro, rt_;
       if (!has_tie) {
         u64 m_own[K], m_left[K], m_right[K], m_tgt[K];
 #pragma unroll
@@ -561,10 +619,10 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
           m_own[w] = sh.lane_mask[mv.lane + 1][w]; m_left[w] = sh.lane_mask[mv.lane][w];
           m_right[w] = sh.lane_mask[mv.lane + 2][w]; m_tgt[w] = sh.lane_mask[mv.tgt + 1][w];
         }
-        wide_mask_neighbours<K>(m_own, rank[h], &fo[h], &ro);
+        fo[h] = wide_mask_front<K>(m_own, rank[h]);
         wide_mask_neighbours<K>(m_left, rank[h], &fl[h], &rl[h]);
         wide_mask_neighbours<K>(m_right, rank[h], &frt[h], &rrt[h]);
-        wide_mask_neighbours<K>(m_tgt, rank[h], &ft[h], &rt_);
+        ft[h] = wide_mask_front<K>(m_tgt, rank[h]);  // (only read by a vehicle on its way to another lane)
       }
     }
     if (has_tie) {  // wave-uniform: literal scans (vehicle INDICES), converted to ranks below
@@ -593,6 +651,12 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       }
     }
     // Straight-line evaluation for every slot (hwy_wave.h): the K vehicles of a thread are independent chains
+    if constexpr (K == 2) {  // EnvBlock::idm_free_from_log for both vehicles at once (exp_bounded2: hwy_math.h)
+      double e0, e1;
+      exp_bounded2(me[0].delta * log_ratio[0], me[1].delta * log_ratio[1], e0, e1);
+      free_self[0] = HWY_COMFORT_ACC_MAX * (1 - e0);
+      free_self[1] = HWY_COMFORT_ACC_MAX * (1 - e1);
+    }
 #pragma unroll
     for (int h = 0; h < K; ++h) {
       const Veh &mv = me[h];
@@ -601,7 +665,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
       const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
       delta[h] = mv.delta;
-      free_self[h] = B::idm_free_from_log(log_ratio[h], delta[h]);
+      if constexpr (K != 2) free_self[h] = B::idm_free_from_log(log_ratio[h], delta[h]);
       gap_own[h] = fo[h] >= 0 ? B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
       // MOBIL (behavior.py:265-324), both candidates side by side
       const double self_a = free_self[h] - gap_own[h];
@@ -805,12 +869,19 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
     }
 
     // ---- E. Road.act: low-level control, F. Road.step: integrate ---------------------------------------------
-    double x_old[K];
+    double x_old[K], tb_[K];
+    if constexpr (K == 2) {  // the steering chain of both vehicles at once (steer_tan_beta2)
+      double iv0, iv1;
+      fast_rcp2(not_zero(me[0].v), not_zero(me[1].v), iv0, iv1);
+      steer_tan_beta2(p, me[0].y, me[0].h, iv0, me[0].tgt, me[1].y, me[1].h, iv1, me[1].tgt, tb_[0], tb_[1]);
+    } else {
+#pragma unroll
+      for (int h = 0; h < K; ++h) tb_[h] = B::steer_tan_beta(p, me[h].y, me[h].h, fast_rcp(not_zero(me[h].v)), me[h].tgt);
+    }
 #pragma unroll
     for (int h = 0; h < K; ++h) {
       Veh &mv = me[h];
-      const double inv_v = fast_rcp(not_zero(mv.v));
-      double tb = B::steer_tan_beta(p, mv.y, mv.h, inv_v, mv.tgt);
+      double tb = tb_[h];
       double accel = free_self[h] - gap_own[h];
       {
         // leader on the target lane: that lane's mask for an ongoing change, the left / right lane evaluated above otherwise
@@ -843,8 +914,9 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       mv.h += mv.v * sb * (1.0 / (HWY_VEH_LENGTH / 2)) * p.dt;
       mv.v += accel * p.dt;
       mv.lane = B::closest_lane(p, mv.x, mv.y, mv.h);
-      sincos_bounded(mv.h, &mv.sh, &mv.ch);
+      if constexpr (K != 2) sincos_bounded(mv.h, &mv.sh, &mv.ch);
     }
+    if constexpr (K == 2) sincos_bounded2(me[0].h, me[1].h, &me[0].sh, &me[0].ch, &me[1].sh, &me[1].ch);
 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) -----------------------------------
     if (all_check) {

@@ -23,6 +23,9 @@
 #define __launch_bounds__(...)
 #define __forceinline__ inline
 #define HWY_FMA_K(a, b, c) fma((a), (b), (c))
+// hwy_math.h, the paired forms (two evaluations sharing the coefficient): the same operations, one after the other
+#define HWY_FMA_K2(r0, r1, a0, b0, a1, b1, c) do { const double t0_ = fma((a0), (b0), (c)), t1_ = fma((a1), (b1), (c)); (r0) = t0_; (r1) = t1_; } while (0)
+#define HWY_LEAD2(r0, r1, t0, t1, kn, kn1) do { (r0) = ::hwy::lead_unfused((t0), (kn), (kn1)); (r1) = ::hwy::lead_unfused((t1), (kn), (kn1)); } while (0)
 #define HWY_RELOAD_PARAMS(q, p) const StepParams &q = p  // hwy_wave.h: re-read of the kernel-argument segment
 #define HWY_RELOAD_STEP_PARAMS(q, p) const StepParams &q = p  // hwy_device.h
 #define HWY_RELOAD_IX_PARAMS(q, ip) const IxParams &q = ip  // hwy_ix.h
@@ -138,6 +141,7 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
 }
 }  // namespace emu
 #define __builtin_amdgcn_readlane(v, lane) emu::readlane((v), (lane))
+#define __builtin_amdgcn_readfirstlane(v) (v)  // (only used on wave-uniform values: every fiber holds the same one)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt(x))

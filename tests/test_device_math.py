@@ -78,3 +78,21 @@ def test_atan_atan2(eng):
     for op, yy in ((10, 0.5), (11, -0.5)):
         got = eng.debug_math(op, y)
         assert np.abs(got - np.arctan2(yy, y)).max() < 9e-16                       # |result| <= pi: 2 ulp of pi
+
+
+def test_paired_routines_are_bit_identical_to_the_scalar_ones(eng):
+    """hwy_math.h's paired forms (log_pos2, exp_bounded2, sincos_bounded2, asin_bounded2, fast_rcp2, fast_rsqrt2: the two vehicles
+    of a thread in hwy_wave2.h share every coefficient's register pair, one asm statement per Horner step) run the same
+    operations on the same values as two scalar calls: compared bit for bit, in both positions of the pair."""
+    rng = np.random.default_rng(4)
+    pos = np.concatenate([rng.uniform(1e-3, 2.5, 50000), 10.0 ** rng.uniform(-30, 2, 10000), [1.0, 0.5, 2.0]])
+    ey = np.concatenate([rng.uniform(-5, 4, 50000), rng.uniform(-690, 40, 10000), [0.0, -701.0, -np.inf]])
+    ang = np.concatenate([rng.uniform(-1.6, 1.6, 50000), rng.uniform(-50, 50, 10000), [0.0, np.pi / 4]])
+    unit = np.concatenate([rng.uniform(-1, 1, 50000), [0.0, 0.5, -0.5, 1.0, -1.0, 0.7071067811865476]])
+    for first, second, scalar, x in ((20, 21, LOG, pos), (22, 23, EXP, ey), (28, 29, ASIN, unit), (30, 31, RCP, pos), (32, 33, RSQRT, pos)):
+        want = eng.debug_math(scalar, x)
+        np.testing.assert_array_equal(eng.debug_math(first, x), want, err_msg=f"op {first}")
+        np.testing.assert_array_equal(eng.debug_math(second, x), want, err_msg=f"op {second}")
+    s, c = eng.debug_math(SIN, ang), eng.debug_math(COS, ang)
+    for op, want in ((24, s), (25, c), (26, s), (27, c)):
+        np.testing.assert_array_equal(eng.debug_math(op, ang), want, err_msg=f"op {op}")
