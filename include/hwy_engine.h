@@ -428,7 +428,9 @@ int hwy_set_block_order(hwy_engine *eng, const int32_t *env_of_block);
  * log / exp / sincos / asin, Newton-refined v_rcp_f64 / v_rsq_f64, floor-mod angle wrap) on n doubles on
  * the device.  Host pointers.  op: 0 log_pos, 1 exp_bounded, 2 sin, 3 cos, 4 asin_bounded, 5 fast_rcp, 8 atan_fd,
  * 9 atan2_bounded(x, 0.75), 10 atan2_bounded(0.5, x), 11 atan2_bounded(-0.5, x),
- * 6 fast_rsqrt, 7 wrap_to_pi.  Lets the accuracy claims (<= 2 ulp on the stated domains) be checked on the GPU.
+ * 6 fast_rsqrt, 7 wrap_to_pi; 20 .. 33: the paired forms (log_pos2, exp_bounded2, sincos_bounded2, asin_bounded2, fast_rcp2,
+ * fast_rsqrt2: first / second result, see math_probe in csrc/hwy_device.h), which must equal the scalar ones bit for bit.
+ * Lets the accuracy claims (<= 2 ulp on the stated domains) be checked on the GPU.
  */
 int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n);
 
