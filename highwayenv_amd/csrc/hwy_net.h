@@ -41,7 +41,7 @@ struct NetShared {
   double lx0[HWY_MAX_LANES], ly0[HWY_MAX_LANES], llen[HWY_MAX_LANES], lwid[HWY_MAX_LANES], lamp[HWY_MAX_LANES],
       lpuls[HWY_MAX_LANES], lphase[HWY_MAX_LANES], llimit[HWY_MAX_LANES];
   int lroad[HWY_MAX_LANES], lid[HWY_MAX_LANES], lfirst[HWY_MAX_LANES], lcount[HWY_MAX_LANES], lnext[HWY_MAX_LANES],
-      lnextn[HWY_MAX_LANES], lforb[HWY_MAX_LANES], lconn[HWY_MAX_LANES];
+      lnextn[HWY_MAX_LANES], lforb[HWY_MAX_LANES], lconn[HWY_MAX_LANES], linv[HWY_MAX_LANES];  // linv[L] = {i : lconn[i] has L}
   // frame-start snapshot in RANK order
   double x[64], v[64], c[64], s[64], lr[64], ox[64];  // lr = log(v/v0) (IDM), ox = x0 of the vehicle's own lane
   int idx[64], kind[64];                              // kind: 1 = vehicle, 0 = obstacle
@@ -511,6 +511,11 @@ __device__ inline void net_load_table(const NetParams &np, NetShared &sh) {
     sh.lnext[i] = l.next_first; sh.lnextn[i] = l.next_lanes; sh.lforb[i] = l.forbidden;
     // lanes searched together with lane i by Road.neighbour_vehicles (road.py:508-529); just the lane itself by default
     sh.lconn[i] = (np.s.flags & HWY_C_CONNECTED_LANES) ? l.connected : (1 << i);
+    // the lanes whose search reads lane i's members (the inverse of lconn): a member of lane i sets its bit in all of them
+    int inv = 0;
+    for (int K2 = 0; K2 < np.n_lanes; ++K2)
+      inv |= ((((np.s.flags & HWY_C_CONNECTED_LANES) ? np.lane[K2].connected : (1 << K2)) >> i) & 1) ? (1 << K2) : 0;
+    sh.linv[i] = inv;
   }
   __syncthreads();
 }
@@ -710,16 +715,18 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
     // (counted in the first frame of a step, then carried from frame to frame and merely re-validated)
     if (fr == 0) net_rank(me.x, present, pm, rank, has_tie);
     else net_update_rank(me.x, present, pm, n_present, rank, has_tie);
-    const int sorted_bits = wave_send_i(bits, rank);
-    // thread i publishes the mask lane i is searched with: its own members and, with connected lanes, those of the
-    // connected segments too (a vehicle on two of them is one bit; all of these lanes measure s from x, so the order
-    // along x is the order of `s_v + offset` of road.py:536-545)
-    u64 m_pub = 0;
-    const int my_conn = i < np.n_lanes ? sh.lconn[i] : 0;
-    for (int L = 0; L < np.n_lanes; ++L) {
-      const u64 b = __ballot((sorted_bits >> L) & 1) & (n_present >= 64 ? ~(u64)0 : (((u64)1 << n_present) - 1));
-      m_pub |= ((my_conn >> L) & 1) ? b : 0;
-    }
+    // lane_mask[i] = the ranks lane i is searched with: its own members and, with connected lanes, those of the connected
+    // segments too (a vehicle on two of them is one bit; all of these lanes measure s from x, so the order along x is the
+    // order of `s_v + offset` of road.py:536-545).  Every vehicle ORs its rank bit into the masks of the lanes that read the
+    // lanes it is on (one or two, up to four at a segment joint: ds_or_b64) -- rounds 1-3 ran one ballot + select per LANE of
+    // the table, 15 of them per frame on the merge network.
+    HWY_WAVE_LDS_FENCE();  // (the previous frame's readers of the masks are done)
+    if (i < np.n_lanes) sh.lane_mask[i] = 0;
+    int pubs = 0;
+    for (int b_ = present ? bits : 0; b_; b_ &= b_ - 1) pubs |= sh.linv[__builtin_ctz(b_)];
+    HWY_WAVE_LDS_FENCE();
+    for (; pubs; pubs &= pubs - 1)
+      __hip_atomic_fetch_or(&sh.lane_mask[__builtin_ctz(pubs)], (u64)1 << rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const double log_ratio = veh ? net_log_ratio(me.v, me.ts, sh.llimit[me.lane]) : 0.0;
     HWY_WAVE_LDS_FENCE();
     if (present) {
@@ -728,7 +735,6 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
       sh.idx[rank] = i;
       sh.kind[rank] = veh ? 1 : 0;
     }
-    if (i < np.n_lanes) sh.lane_mask[i] = m_pub;
     HWY_WAVE_LDS_FENCE();
 
     wave_turn(turn);
