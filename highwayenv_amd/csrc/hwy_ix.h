@@ -598,21 +598,12 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     }
     // ---- B. membership masks + snapshot ---------------------------------------------------------------------------
     HWY_WAVE_LDS_FENCE();
-    if constexpr (SH::kNH > 1) {  // helper lanes carry their vehicle's bits: one ballot yields the masks of two lanes
-      const int HL = (ip.n_lanes + 1) >> 1, half = i / SH::kCap;
-      for (int L = 0; L < HL; ++L) {
-        const u64 b = __ballot((bits >> (L + half * HL)) & 1);
-        if (i == 0) {
-          sh.mask[L] = b & 0xffffffffull;
-          if (L + HL < ip.n_lanes) sh.mask[L + HL] = b >> 32;
-        }
-      }
-    } else {
-      for (int L = 0; L < ip.n_lanes; ++L) {
-        const u64 b = __ballot((bits >> L) & 1);
-        if (i == 0) sh.mask[L] = b;
-      }
-    }
+    // every vehicle ORs its slot bit into the masks of the lanes it is on (one to three: ds_or_b64); rounds 1-3 ran one ballot
+    // per lane (pair of lanes with helper lanes) of the 20-lane table
+    if (i < ip.n_lanes) sh.mask[i] = 0;
+    HWY_WAVE_LDS_FENCE();
+    for (int b_ = (i < SH::kCap) ? bits : 0; b_; b_ &= b_ - 1)
+      __hip_atomic_fetch_or(&sh.mask[__builtin_ctz(b_)], (u64)1 << i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const double ch = me.ch, shh = me.sh;
     sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = ch; sh.s[i] = shh;
     HWY_WAVE_LDS_FENCE();
