@@ -360,15 +360,15 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
     int bits = 0;
     for (int L = 0; L < p.L; ++L)
       bits |= (inr && (fabs(me.y - L * p.lane_width) <= p.lane_width / 2 + 1.0)) ? (1 << L) : 0;
-    const int sorted_bits = wave_send_i(bits, rank);
-    // one ballot per road lane; the masks go through a small LDS table (slot L+1 = lane L, zero slots on both
-    // sides for "no such lane") so that each vehicle fetches own / left / right / target lane with four LDS
-    // reads instead of four 64-bit select chains
-    u64 m_pub = 0;
-    for (int L = 0; L < p.L; ++L) {
-      const u64 b = __ballot((sorted_bits >> L) & 1);
-      m_pub = (i == L + 1) ? b : m_pub;
-    }
+    // the masks live in a small LDS table (slot L+1 = lane L, zero slots on both sides for "no such lane") so that each
+    // vehicle fetches own / left / right / target lane with four LDS reads instead of four 64-bit select chains; every vehicle
+    // ORs its rank bit into the masks of the lanes it is on (one or two: ds_or_b64) -- rounds 1-3: a ds_permute of the bits to
+    // the lane `rank` and one ballot + select per road lane
+    HWY_WAVE_LDS_FENCE();  // previous frame's mask reads are complete
+    if (i < p.L + 2) sh.lane_mask[i] = 0;
+    HWY_WAVE_LDS_FENCE();
+    for (int b_ = bits; b_; b_ &= b_ - 1)
+      __hip_atomic_fetch_or(&sh.lane_mask[__builtin_ctz(b_) + 1], (u64)1 << rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // frame-start snapshot, stored in rank order (with each vehicle's IDM log speed ratio)
     if (fr == 0) inv_v0 = B::idm_inv_v0(p, sh.ts[i]);  // (after the meta-action of frame 0: the target speed is fixed for the step)
     const double log_ratio = active ? B::idm_log_ratio_inv(me.v, inv_v0) : 0.0;  // egos and wrecks can be followers too
@@ -377,7 +377,6 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       sh.x[rank] = me.x; sh.v[rank] = me.v; sh.c[rank] = me.ch; sh.s[rank] = me.sh; sh.lr[rank] = log_ratio;
       sh.idx[rank] = i;
     }
-    if (i < p.L + 2) sh.lane_mask[i] = m_pub;
     HWY_WAVE_LDS_FENCE();
     const u64 m_own = sh.lane_mask[me.lane + 1], m_left = sh.lane_mask[me.lane], m_right = sh.lane_mask[me.lane + 2];
     const u64 m_tgt = sh.lane_mask[me.tgt + 1];
