@@ -558,7 +558,12 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       log_ratio[0] = active[0] ? (r0 > 0.0 ? l0 : -__builtin_inf()) : 0.0;
       log_ratio[1] = active[1] ? (r1 > 0.0 ? l1 : -__builtin_inf()) : 0.0;
     }
-    HWY_WAVE_LDS_FENCE();  // previous readers of the snapshot / sbits are done
+    HWY_WAVE_LDS_FENCE();  // previous readers of the snapshot / the masks are done
+    if (l < p.L + 2) {
+#pragma unroll
+      for (int w = 0; w < K; ++w) sh.lane_mask[l][w] = 0;
+    }
+    HWY_WAVE_LDS_FENCE();
 #pragma unroll
     for (int h = 0; h < K; ++h) {
       const bool inr = active[h] && (-5.0 <= me[h].x) && (me[h].x < p.road_length + 5.0);
@@ -567,30 +572,13 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
         bits |= (inr && (fabs(me[h].y - L * p.lane_width) <= p.lane_width / 2 + 1.0)) ? (1 << L) : 0;
       if constexpr (K != 2) log_ratio[h] = active[h] ? B::idm_log_ratio_inv(me[h].v, inv_v0[h]) : 0.0;
       const int r = rank[h];
-      sh.sbits[r] = bits;
+      // lane membership (AbstractLane.on_lane, margin 1) in rank space: every vehicle ORs its rank bit into the masks of the
+      // lanes it is on (one or two: ds_or_b64; row L+1 = lane L, rows 0 and L+1 stay 0 for "no such lane")
+      for (int b_ = bits; b_; b_ &= b_ - 1)
+        __hip_atomic_fetch_or(&sh.lane_mask[__builtin_ctz(b_) + 1][r >> 6], (u64)1 << (r & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (active[h]) {
         sh.x[r] = me[h].x; sh.v[r] = me[h].v; sh.c[r] = me[h].ch; sh.s[r] = me[h].sh; sh.lr[r] = log_ratio[h];
         sh.idx[r] = vi[h];
-      }
-    }
-    HWY_WAVE_LDS_FENCE();
-    {
-      int sorted_bits[K];
-#pragma unroll
-      for (int h = 0; h < K; ++h) sorted_bits[h] = sh.sbits[h * 64 + l];
-      u64 m_pub[K];
-#pragma unroll
-      for (int h = 0; h < K; ++h) m_pub[h] = 0;
-      for (int L = 0; L < p.L; ++L) {
-#pragma unroll
-        for (int h = 0; h < K; ++h) {
-          const u64 b = __ballot((sorted_bits[h] >> L) & 1);
-          m_pub[h] = (l == L + 1) ? b : m_pub[h];
-        }
-      }
-      if (l < p.L + 2) {
-#pragma unroll
-        for (int h = 0; h < K; ++h) sh.lane_mask[l][h] = m_pub[h];
       }
     }
     HWY_WAVE_LDS_FENCE();
