@@ -109,6 +109,17 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
             "source": d["_file"] + " (SQ counters of this kernel build and config)"}
 
 
+def wide_kernel_runs(n_vehicles: int, tune=None) -> bool:
+    """The engine's dispatch rule for the straight-road scenarios (csrc/hwy_kernels.hip: wide_kernel_applies; every bench workload
+    observes Kinematics there): 64 < N <= 128 runs one wavefront per environment with two vehicles per thread (hwy_wave2.h) unless
+    `--tune block_kernel=1` asks for the workgroup kernel."""
+    tune = TUNE_IN_EFFECT if tune is None else tune
+    return 64 < n_vehicles <= 128 and not int(tune.get("block_kernel", 0))
+
+
+TUNE_IN_EFFECT = {}  # (--tune KEY=VALUE of this run, set by main)
+
+
 def kernel_resources_view(scenario: str, fast: bool, n_vehicles: int):
     """Registers / spills / LDS the compiler allocated to the step-kernel family this workload launches, read from the code object
     inside the library being timed (highwayenv_amd.build.kernel_resources; the WPE variants of a family that allocate the same are
@@ -116,7 +127,8 @@ def kernel_resources_view(scenario: str, fast: bool, n_vehicles: int):
     try:
         from highwayenv_amd import build
         fam = ("hwy::hwy_ix_step_kernel<" if scenario == "intersection" else "hwy::hwy_net_step_kernel<" if scenario != "highway" else
-               "hwy::hwy_step_wave_kernel<" if n_vehicles <= 64 else f"hwy::hwy_step_kernel<{(n_vehicles + 63) // 64}, ")
+               "hwy::hwy_step_wave_kernel<" if n_vehicles <= 64 else
+               "hwy::hwy_step_wide_kernel<" if wide_kernel_runs(n_vehicles) else f"hwy::hwy_step_kernel<{(n_vehicles + 63) // 64}, ")
         tail = (", false>" if fast else ", true>") if fam.startswith("hwy::hwy_step_wave") else ""
         lib = os.environ.get("HWY_ENGINE_LIB") or build.LIB_PATH
         out, seen = {}, set()
@@ -441,6 +453,8 @@ def main(argv=None, platform=None, emit=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
         raise SystemExit(self_launch(sys.argv[1:] if argv is None else list(argv), args.gpus))
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
+    TUNE_IN_EFFECT.clear()
+    TUNE_IN_EFFECT.update(tuning)
     cfg_dict, fast, scenario = workload_config(args.workload)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner through C
     # stdio when a communicator is created), so everything else is sent to stderr: fd 1 is pointed at fd 2 for the whole
@@ -768,6 +782,7 @@ def main(argv=None, platform=None, emit=None):
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<WPE,{str(not fast).lower()}>  (one 64-wide wavefront per env; every WPE variant is the same "
                                     "102 / 128-VGPR code)" if N <= 64 else
+                                    "hwy_step_wide_kernel<2,2>  (one 64-wide wavefront per env, two vehicles per thread)" if wide_kernel_runs(N) else
                                     f"hwy_step_kernel<{(N + 63) // 64},WPE>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "avg_kernel_us_method": ("mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's own "
                                                   "timestamps (unclamped)" if event_kernel_s else "wall ms_per_step (no events)"),

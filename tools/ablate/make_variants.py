@@ -131,7 +131,7 @@ def net_ticks(text):
             "  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool present")(text)
     marks = ["    // ---- A. meta-actions of all agents",
              "    // ---- B. rank along x, lane membership masks",
-             "    const int sorted_bits = wave_send_i(bits, rank);",
+             "    // lane_mask[i] = the ranks lane i is searched with",
              "    // ---- C. Road.act ---",
              "    const double delta = me.delta;\n    const double free_self",
              "    // abort rule for ongoing lane changes on the same road",
@@ -142,14 +142,14 @@ def net_ticks(text):
              "  }  // frames\n\n  // ---- G. observe / reward / done"]
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
-    # collisions split: phase 1 (walk) -> acc[10], phase 2 (SAT trips) -> acc[12]; trip / walk-step counters
-    t = sub("      // Phase 2: the collected partners are filtered", "      TICK(10)\n      // Phase 2: the collected partners are filtered")(t)
+    # collisions split: walk steps -> acc[10], list passes (+ the verdict reads) -> acc[12]; walk-step / pass / SAT counters
+    t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64\n",
+            "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64\n        TICK(10)\n        n_trip += count > 0 ? 1.0f : 0.0f;\n")(t)
+    t = sub("        if (i < left) plist[i] = (unsigned short)carry;\n        n_list = left;", "        TICK(12)\n        if (i < left) plist[i] = (unsigned short)carry;\n        n_list = left;")(t)
     t = sub("  }  // frames\n\n  // ---- G. observe", "  TICK(12)\n  }  // frames\n\n  // ---- G. observe")(t)
     t = sub("    TICK(10)\n  TICK(12)\n  }  // frames", "  TICK(12)\n  }  // frames")(t)
-    t = sub("        if (__ballot(go_b) == 0) break;", "        if (__ballot(go_b) == 0) break;\n        n_walk += 1.0f;")(t)
-    t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count",
-            "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;\n        n_trip += 1.0f;\n        HWY_WAVE_LDS_FENCE();\n        const int pair = i < count")(t)
-    t = sub("          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "          n_sat += 1.0f;\n          r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
+    t = sub("          ++k;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;", "          ++k;\n          n_walk += 1.0f;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;")(t)
+    t = sub("            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "            n_sat += 1.0f;\n            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
     t = sub("  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};", "  float n_walk = 0, n_trip = 0, n_sat = 0; long long t_prev = clock64(); long long acc[13] = {0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
     t = sub("    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
             "    TICK(11)\n    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"

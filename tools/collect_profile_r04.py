@@ -26,11 +26,12 @@ def jl(path):
 
 
 KERNEL_OF = {"fast": "hwy_step_wave_kernel", "merge_ma4": "hwy_net_step_kernel", "intersection": "hwy_ix_step_kernel",
-             "v0": "hwy_step_wave_kernel", "cfg3": "hwy_step_kernel"}
+             "v0": "hwy_step_wave_kernel", "cfg3": "hwy_step_wide_kernel"}
 out_notes = {}
 # bench lines
 for name in ("fast", "merge_ma4", "intersection", "v0", "cfg3", "intersection_kin", "merge", "fast_1024", "fast_2048", "fast_8192",
-             "fast_16384", "fast_forcedist", "fast_split2", "intersection_split2", "cfg3_2048"):
+             "fast_16384", "fast_forcedist", "fast_split2", "intersection_split2", "cfg3_2048", "cfg3_block_kernel",
+             "cfg3_2048_block_kernel"):
     p = os.path.join(SRC, f"bench_{name}.json")
     if os.path.exists(p):
         d = jl(p)
@@ -89,7 +90,8 @@ for name, wl in (("fast", "fast"), ("merge_ma4", "merge_ma4"), ("intersection", 
 if sq_all:  # one file, keyed by bench.py's --workload (bench.py: valu_view)
     json.dump(sq_all, open(os.path.join(DST, "r04_pmc_sq.json"), "w"), indent=1)
 for src_name, dst_name in (("sections_fast.txt", "r04_section_clocks.txt"), ("sections_merge_ma4.txt", "r04_section_clocks_merge_ma4.txt"),
-                           ("sections_intersection.txt", "r04_section_clocks_intersection.txt")):
+                           ("sections_intersection.txt", "r04_section_clocks_intersection.txt"),
+                           ("sections_cfg3.txt", "r04_section_clocks_cfg3.txt")):
     sec = os.path.join(SRC, src_name)
     if os.path.exists(sec):
         open(os.path.join(DST, dst_name), "w").writelines(line for line in open(sec) if "amdgpu.ids" not in line)

@@ -36,13 +36,13 @@ for t in range(40):
         n += 1
 names = ["load", "A meta-action", "B rank", "B membership+snapshot", "C follow_road+neighbours", "C gaps + MOBIL",
          "C abort chain", "D control", "E integrate", "E closest lane", "F collisions: walk", "G observe",
-         "F collisions: SAT trips"]
+         "F collisions: list passes"]
 tot /= n
 print(which)
 for k, nm in enumerate(names):
     print(f"{nm:26s} {tot[k]:10.0f} cycles/step/wave  {100 * tot[k] / tot[:13].sum():5.1f}%")
 print(f"{'total':26s} {tot[:13].sum():10.0f}")
-print(f"walk steps per step {tot[13]:.1f}, SAT-phase trips per step {tot[14]:.1f}, waves that ran a SAT {tot[15]:.3f}")
+print(f"walk steps per step {tot[13]:.1f}, list passes with pairs per step {tot[14]:.1f}, waves that ran a SAT {tot[15]:.3f}")
 X = np.concatenate(per_wave)
 X = X[(X[:, :13] >= 0).all(1) & (X[:, :13].sum(1) > 1000)]  # (re-spawning waves hold observation floats there)
 T = X[:, :13].sum(1)

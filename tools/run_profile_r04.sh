@@ -2,14 +2,14 @@
 # GPU box: everything behind profiles/r04_* in ONE call (tests, bench lines, rocprofv3 kernel stats, PMC traffic and SQ
 # counters, wave timeline, secondary workloads).  Raw output under gpurun_out/r04prof/; tools/collect_profile_r04.py
 # (build container) turns it into the committed summaries.  Build the instrumented variants first:
-#   python tools/ablate/make_variants.py wtimeline wticks nticks ixticks
+#   python tools/ablate/make_variants.py wtimeline wticks nticks ixticks w2ticks
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/run_profile_r04.sh'
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r04prof; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
 timeout 600 python bench.py > $O/bench_fast.json 2> $O/bench_fast.err; echo "bench rc=$?"
 timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_fast_driver_shape.json 2>> $O/bench_misc.err
-HWY_FUZZ_CHUNKS=${HWY_FUZZ_CHUNKS:-500} timeout 1500 python -m pytest tests/test_fuzz_configs.py -m gpu -q -s -p no:cacheprovider > $O/gpu_fuzz.txt 2>&1; tail -2 $O/gpu_fuzz.txt
+HWY_FUZZ_CHUNKS=${HWY_FUZZ_CHUNKS:-500} HWY_FUZZ_FIRST=${HWY_FUZZ_FIRST:-0} timeout 1500 python -m pytest tests/test_fuzz_configs.py -m gpu -q -s -p no:cacheprovider > $O/gpu_fuzz.txt 2>&1; tail -2 $O/gpu_fuzz.txt
 prof() { # name workload envs [kernel-substr]
   local name=$1 w=$2 e=$3
   cd /tmp && export TMPDIR=/tmp
@@ -41,7 +41,7 @@ for spec in "merge_ma4 merge_ma4 4096" "intersection intersection 2048" "v0 v0 4
   prof $1 $2 $3
   pmc_bench $1 $2 $3 FETCH_SIZE
   pmc_bench $1 $2 $3 WRITE_SIZE
-  K=hwy_step_wave; [ $1 = merge_ma4 ] && K=hwy_net_step; [ $1 = intersection ] && K=hwy_ix_step; [ $1 = cfg3 ] && K=hwy_step_kernel
+  K=hwy_step_wave; [ $1 = merge_ma4 ] && K=hwy_net_step; [ $1 = intersection ] && K=hwy_ix_step; [ $1 = cfg3 ] && K=hwy_step_wide
   bash tools/pmc_sq.sh $2 $3 $K > $O/pmc_sq_$1.log 2>&1; cp gpurun_out/pmc_sq_$2.json $O/pmc_sq_$1.json 2>/dev/null
 done
 timeout 120 python bench.py --workload intersection_kin --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_intersection_kin.json 2>> $O/bench_misc.err
@@ -56,6 +56,10 @@ timeout 200 python bench.py --workload intersection --envs-per-gpu 2048 --no-cpu
 timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 > $O/bench_cfg3_2048.json 2>> $O/bench_misc.err
 HWY_ENGINE_LIB=tools/ablate/_build/libhwy_engine_nticks.so timeout 200 python tools/net_section_cycles.py merge_ma4 > $O/sections_merge_ma4.txt 2>&1
 HWY_ENGINE_LIB=tools/ablate/_build/libhwy_engine_ixticks.so timeout 200 python tools/ix_section_dist.py > $O/sections_intersection.txt 2>&1
+HWY_ENGINE_LIB=tools/ablate/_build/libhwy_engine_w2ticks.so timeout 120 python tools/wide_section_cycles.py 1024 > $O/sections_cfg3.txt 2>&1
+# config 3 on the workgroup kernel the wide kernel replaced there (same box, same run)
+timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 1024 --no-cpu-baseline --steps 300 --repeats 3 --tune block_kernel=1 > $O/bench_cfg3_block_kernel.json 2>> $O/bench_misc.err
+timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 --tune block_kernel=1 > $O/bench_cfg3_2048_block_kernel.json 2>> $O/bench_misc.err
 # keep the merged output small: only the stats / counter CSVs
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
