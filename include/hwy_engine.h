@@ -254,7 +254,9 @@ typedef struct hwy_config {
   /* Tuning (ABI v5; 0 everywhere = the engine's own choice).  These replace the process-global environment variables
    * earlier builds read with getenv: a knob now belongs to ONE engine and is part of its documented configuration.
    * None of them changes any result (tests/test_engine_parity.py, tests/test_ix_parity.py compare the variants). */
-  int32_t tune_block_kernel;           /* 1: run the generic workgroup kernel (hwy_device.h) even for N <= 64 */
+  int32_t tune_block_kernel;           /* 1: run the generic workgroup kernel (hwy_device.h) even for N <= 128, where the default is one
+                                          wavefront per environment (hwy_wave.h for N <= 64, hwy_wave2.h -- two vehicles per thread --
+                                          for 64 < N <= 128 with the Kinematics observation) */
   int32_t tune_waves_per_eu;           /* 1..4: register-allocation variant (resident wavefronts per SIMD) of the step kernel */
   int32_t tune_ix_no_helpers;          /* 1: HWY_SCENARIO_INTERSECTION with N <= 32 runs 32-thread workgroups (no helper lanes) */
   int32_t tune_ix_no_prewarm;          /* 1: HWY_SCENARIO_INTERSECTION auto-resets run their warm-up frames inline */
