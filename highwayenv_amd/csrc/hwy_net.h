@@ -412,7 +412,8 @@ __device__ inline void net_observe_grid(const NetParams &np, const NetShared &sh
 //      observation -- a compile-time switch, so that the Kinematics kernels (the measured configs) carry none of the grid
 //      code in their register / scalar allocation. ---------------------------------------------------------------------
 template <bool GRID>
-__device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, int eo, const Veh &me, bool write_reward) {
+__device__ inline void net_observe(const NetParams &np, const NetShared &sh, int e, int eo, const Veh &me, bool write_reward,
+                                   int rank = -1) {
   const StepParams &p = np.s;
   const int i = threadIdx.x;
   const bool present = i < p.N && !(me.flags & HWY_F_ABSENT);
@@ -439,10 +440,36 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
     const int n_elig = __popcll(__ballot(elig));
     const int m = n_elig < V - 1 ? n_elig : V - 1;
     int pos = 0;  // stable sort position; obstacles sit after every vehicle slot, so slot order == list order
-    for (u64 em = __ballot(elig); em; em &= em - 1) {
-      const int k = ctz64(em);
-      const double kk = wave_bcast(key, k);
-      pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+    bool by_rank = false;
+    if (!GRID && rank >= 0 && !(p.flags & (HWY_C_OBS_SEE_BEHIND | HWY_C_OBS_UNSORTED))) {  // wave-uniform
+      // `rank` = the exact rank along x on the CURRENT positions.  Everything eligible BEHIND the observer is closer than 2 LENGTH,
+      // so the eligible split into `near` (key < 2 LENGTH: a handful, ordered by explicit compares) and `far` (all in front,
+      // after every near one, and among themselves ordered like x, i.e. like their rank) -- hwy_wave.h's observe_wave.  "Like x"
+      // needs the key strictly monotone in x: d_lane = (x - ox) - (ex - ox) is, as long as both subtractions are EXACT for the
+      // far ones (TwoSum error terms, checked: else two cars a rounding apart could tie, and the reference breaks a tie by
+      // list order); one inexact far key sends this observer to the loop over all eligible below.
+      const bool nearv = elig && key < 2 * HWY_VEH_LENGTH, farv = elig && !nearv;
+      const double d1 = me.x - ox, c1 = ex - ox;
+      const double bb1 = d1 - me.x, err1 = (me.x - (d1 - bb1)) + (-ox - bb1);
+      const double bb2 = d_lane - d1, err2 = (d1 - (d_lane - bb2)) + (-c1 - bb2);
+      if (__ballot(farv && !(err1 == 0.0 && err2 == 0.0)) == 0) {
+        by_rank = true;
+        const u64 near_m = __ballot(nearv);
+        const u64 far_r = __ballot(wave_send_i(farv ? 1 : 0, rank) != 0);  // rank space
+        for (u64 em = near_m; em; em &= em - 1) {  // wave-uniform
+          const int k = ctz64(em);
+          const double kk = wave_bcast(key, k);
+          pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+        }
+        pos = farv ? __popcll(near_m) + __popcll(far_r & (((u64)1 << rank) - 1)) : pos;
+      }
+    }
+    if (!by_rank) {
+      for (u64 em = __ballot(elig); em; em &= em - 1) {
+        const int k = ctz64(em);
+        const double kk = wave_bcast(key, k);
+        pos += ((kk < key) || (kk == key && k < i)) ? 1 : 0;
+      }
     }
     if constexpr (GRID) {
       if (p.obs) net_observe_grid(np, sh, e, eo, a, me, veh, ex, ey, ev, ec, es);
@@ -461,9 +488,11 @@ __device__ inline void net_observe(const NetParams &np, const NetShared &sh, int
           }
           if (rel && (p.flags & HWY_C_OBS_NORMALIZE)) {
             const double r0 = fid == HWY_FEAT_X ? p.rx0 : fid == HWY_FEAT_Y ? p.ry0 : fid == HWY_FEAT_VX ? p.rvx0 : p.rvy0;
-            const double r1 = fid == HWY_FEAT_X ? p.rx1 : fid == HWY_FEAT_Y ? p.ry1 : fid == HWY_FEAT_VX ? p.rvx1 : p.rvy1;
+            // (the host-computed reciprocal of the feature range, like hwy_wave.h: an f64 ulp away from the quotient at most,
+            //  far below the rounding of the f32 observation)
+            const double ir = fid == HWY_FEAT_X ? p.inv_rx : fid == HWY_FEAT_Y ? p.inv_ry : fid == HWY_FEAT_VX ? p.inv_rvx : p.inv_rvy;
             if (r0 > -__builtin_inf()) {
-              val = lmap(val, r0, r1, -1.0, 1.0);
+              val = lmap_inv(val, r0, ir, -1.0, 1.0);
               if (p.flags & HWY_C_OBS_CLIP) val = clipd(val, -1.0, 1.0);
             }
           }
@@ -994,7 +1023,12 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
   }  // frames
 
   // ---- G. observe / reward / done ------------------------------------------------------------------------------
-  if (p.full_step) net_observe<GRID>(np, sh, e, eo, me, true);
+  if (p.full_step) {
+    // the positions moved in the last frame: the rank is re-validated once more, for the observation's sort (ties in x: the
+    // loop over all eligible)
+    if (!GRID && p.n_frames > 0) net_update_rank(me.x, present, pm, n_present, rank, has_tie);
+    net_observe<GRID>(np, sh, e, eo, me, true, (!GRID && p.n_frames > 0 && !has_tie) ? rank : -1);
+  }
   {
     // rank hint for the next step is not used by this kernel; keep the slot index
     me.rank = i & 0xff;
