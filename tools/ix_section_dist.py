@@ -44,3 +44,8 @@ for role, rn in ((0, "STEP"), (1, "RESPAWN")):
         print(f"{nm:32s} {c.mean():9.0f} {np.percentile(c, 50):9.0f} {np.percentile(c, 90):9.0f} {np.percentile(c, 99):9.0f} "
               f"{c.max():9.0f} {100 * c.mean() / tot.mean():5.1f}%")
     print(f"{'total':32s} {tot.mean():9.0f} {np.percentile(tot, 50):9.0f} {np.percentile(tot, 90):9.0f} {np.percentile(tot, 99):9.0f} {tot.max():9.0f}")
+    # the launch lasts as long as its slowest wavefront: where do the slowest ones spend their time?
+    top = np.argsort(tot)[-max(1, len(tot) // 100):]
+    print("slowest 1 % of these wavefronts, section means against the overall means:")
+    for k, nm in enumerate(names):
+        print(f"  {nm:32s} {S[top, k].mean():9.0f} {S[:, k].mean():9.0f}")
