@@ -76,6 +76,21 @@ def test_random_configurations_vs_oracle(chunk):
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
 
 
+@pytest.mark.parametrize("chunk", CHUNKS)  # 4 configurations each
+def test_random_wide_configurations_vs_oracle(chunk):
+    """The same family with 63 .. 127 other vehicles: the traffic sizes of the two-vehicles-per-thread kernel (csrc/hwy_wave2.h;
+    the OccupancyGrid draws of the family run the workgroup kernel there)."""
+    rng = np.random.default_rng(19000 + chunk)
+    for k in range(4):
+        cfg, fast = random_config(rng)
+        agents = cfg["controlled_vehicles"]
+        cfg["vehicles_count"] = int(rng.integers(64 - agents, 129 - agents))
+        try:
+            rollout(BACKEND, cfg, fast, E=4, steps=6, seed=chunk * 100 + k)
+        except AssertionError as ex:  # name the configuration in the failure
+            raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
+
+
 def random_merge_config(rng):
     from highwayenv_amd import merge
     cfg = merge.merge_generic_default_config()
