@@ -8,8 +8,8 @@
 // direction and a third of them are circular arcs, so there is no single sort key along "the road".  Instead every
 // vehicle projects itself on EVERY lane once per frame (one walk over the lane table after the integration: the
 // same projections give the new lane index -- get_closest_lane_index -- the membership bits of the next frame and
-// the longitudinal coordinate s on each lane, parked in LDS), one ballot per lane turns the bits into slot-space
-// masks, and a front / rear query on lane L is a walk over the few set bits of mask[L] reading s[L][j] from LDS.
+// the longitudinal coordinate s on each lane, parked in LDS), every vehicle ORs its slot bit into the masks of the
+// lanes it is on, and a front / rear query on lane L is a walk over the few set bits of mask[L] reading s[L][j] from LDS.
 //   * planned routes (controller.py:71-87; next_lane, road.py:73-133): every road has one lane, a route is a list of
 //     lane-table indices in one packed word;
 //   * RegulatedRoad (road/regulation.py): every int(1 / dt / 2) frames every vehicle predicts 11 constant-speed poses

@@ -1,6 +1,6 @@
 // hwy_kernels.hip -- gfx950 translation unit: instantiates the fused step / reset /
 // observe kernels of hwy_device.h and exposes plain launch functions to the C-ABI host
-// (hwy_engine.hip).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off.
+// (hwy_engine.hip).  Build: highwayenv_amd/build.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on ...).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 

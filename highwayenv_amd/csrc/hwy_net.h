@@ -3,7 +3,7 @@
 // arrays (vehicles in Road.vehicles order, HWY_F_ABSENT holes, then the Obstacle of Road.objects).
 //
 // Same wave formulation as hwy_wave.h -- rank of every vehicle along x, rank-space membership mask per lane
-// (one ballot per lane), front / rear neighbour == two bit scans + one LDS gather, ordered readlane chains for
+// (every vehicle ORs its rank bit into the masks that read its lanes), front / rear neighbour == two bit scans + one LDS gather, ordered readlane chains for
 // the sequential bits of the reference's Python loops -- generalised from "L parallel lanes of one road" to a
 // table of x-aligned lanes (hwy_config.net -> NetParams::lane -> LDS):
 //   * every lane has its own start / length (AbstractLane.on_lane, lane.py:80-102) and, for the SineLane of

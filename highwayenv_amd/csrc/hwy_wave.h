@@ -1,16 +1,17 @@
 // hwy_wave.h -- the fused policy-step kernel specialised for N <= 64 vehicles: ONE 64-wide
 // wavefront per environment (the headline highway-fast-v0 4096 x 51 case).
 //
-// Same semantics as the generic workgroup kernel in hwy_device.h (which remains the path for
-// N > 64), but built around what a single CDNA4 wavefront can do without touching LDS memory:
+// Same semantics as the generic workgroup kernel in hwy_device.h (the path for N > 128; hwy_wave2.h
+// runs 64 < N <= 128 on one wavefront with two vehicles per thread), but built around what a single
+// CDNA4 wavefront can do without barriers:
 //
 //   * cross-vehicle reads with a wave-uniform source index (rank counting, the lane-change abort
 //     chain, ego-vs-all collision checks, observation keys) use v_readlane -- the value lands in
 //     SGPRs and feeds the f64 compare directly, no LDS round trip and no barrier;
-//   * the sort by longitudinal position is a readlane counting pass; each vehicle then SENDS its
-//     lane-membership bits to the lane whose id equals its rank (ds_permute_b32: LDS crossbar, no
-//     LDS memory), and one v_cmp/ballot per road lane yields the rank-space membership mask, which
-//     every thread keeps in registers for its own / left / right / target lane;
+//   * the sort by longitudinal position is carried from frame to frame and merely verified (a
+//     ds_permute exchange of x; a readlane counting pass when the order changed); each vehicle ORs
+//     its rank bit into the masks of the one or two lanes it is on (ds_or_b64: rank-space
+//     membership masks), and fetches the masks of its own / left / right / target lane;
 //   * the only LDS-resident data is the frame snapshot stored IN RANK ORDER, so a neighbour found
 //     by bit-scan (rank) is fetched with one gather, not rank -> index -> data;
 //   * the two MOBIL candidates are evaluated side by side (independent chains) instead of one

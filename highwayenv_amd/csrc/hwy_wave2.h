@@ -60,7 +60,7 @@ struct WideShared {
   // frame snapshot in RANK order (slot r == r-th vehicle along the road)
   double x[NV], v[NV], c[NV], s[NV], lr[NV];
   int idx[NV];
-  int sbits[NV];                          // scratch in rank order: lane-membership bits / observation classes
+  int sbits[NV];                          // scratch in rank order: the abort chain's codes / the observation's classes
   u64 lane_mask[HWY_MAX_LANES + 2][K];    // rank-space membership mask of road lane L in row L+1; 0 in rows 0 and L+1
   // collision translations by vehicle index: written by the thread that evaluated the winning pair, read by the owner
   double impx[NV], impy[NV];
@@ -515,7 +515,9 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
   for (int h = 0; h < K; ++h) {
     i_check[h] = (me[h].flags & HWY_F_CHECK_COLLISIONS) != 0;
     chk[h] = __ballot(active[h] && i_check[h]);
-    rank[h] = active[h] ? me[h].rank : vi[h];  // idle slots keep their own so that the table stays a bijection
+    // idle slots keep their own so that the table stays a bijection (the hint is the engine's own: a permutation of 0 .. N - 1
+    // since the last spawn / hwy_set_state; masked to the table's size so that no state word can address outside it)
+    rank[h] = active[h] ? (me[h].rank & (64 * K - 1)) : vi[h];
   }
   const bool all_check = wide_popc<K>(chk) == N;
   bool has_tie = false;
