@@ -206,3 +206,24 @@ def test_abort_chain_on_the_emulator():
             soak(6, 14)
     finally:
         emu._lib = saved
+
+
+def test_abort_chain_window_bound_dominates_the_desired_gap():
+    """The wide kernel's abort chain stops walking the vehicles ahead of a changer at
+    bound = (10 + 1.5 v + v (v + 5) / (2 sqrt(ab))) (1 + 1e-6) + 1e-6, claimed to dominate IDMVehicle.desired_gap(changer, rival)
+    (behavior.py:192-217) for EVERY rival while no vehicle of the environment drives backwards (v cos h >= 0) or sideways faster
+    than 5 m/s (|v sin h| <= 5) and the changer itself has v >= 0, cos h >= 0 -- the kernel checks exactly these conditions and walks
+    without a bound otherwise (hwy_wave2.h section D).  Checked here on the formula the oracle evaluates, random and extreme cases."""
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    v = np.concatenate([rng.uniform(0, 60, n), [0.0, 40.0, 1e-9, 100.0]])
+    h = np.concatenate([rng.uniform(-np.pi / 2, np.pi / 2, n), [0.0, np.pi / 2, -np.pi / 2, 0.3]])
+    m = v.size
+    # rivals: forward component in [0, 80], lateral component in [-5, 5] (the `sane` condition), any mix of speed and heading
+    fx = np.concatenate([rng.uniform(0, 80, m - 3), [0.0, 0.0, 80.0]])
+    fy = np.concatenate([rng.uniform(-5, 5, m - 3), [5.0, -5.0, 5.0]])
+    ce, se = np.cos(h), np.sin(h)
+    dv = (v * ce - fx) * ce + (v * se - fy) * se
+    d_star = 10.0 + v * 1.5 + (v * dv) * 0.12909944487358055
+    bound = (10.0 + v * 1.5 + v * (v + 5.0) * 0.12909944487358055) * (1.0 + 1e-6) + 1e-6
+    assert (d_star <= bound).all(), float((d_star - bound).max())
