@@ -354,7 +354,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           return (lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi;
         },
         [&](int pair, bool more) {
-          const int v = pair & 255;
+          const int v = pair < 0 ? 0 : (pair & 255);
           unsigned long long key = 0;
           int L = 0;
           if (pair >= 0) {

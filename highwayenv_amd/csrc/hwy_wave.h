@@ -474,30 +474,68 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
     // side_lanes order is [left, right] and the loop does not break: right wins if both pass
     if (ok_l) me.tgt = me.lane - 1;
     if (ok_r) me.tgt = me.lane + 1;
-    // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
+    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain over Road.vehicles -- a changer c (on its
+    // way to lane T since an earlier frame) aborts if ANOTHER vehicle r heading for T from a third lane, with the target r shows
+    // when c acts (its current one for r before c in the list, the frame-start one after c), is ahead of c by less than the
+    // desired gap d*(c, r).  Evaluated per THREAD in rank space, without a loop over the changers (derivation and the bound's
+    // proof obligations: hwy_wave2.h section D; rounds 1-4 ran one link per changer here, ~25 instructions each and ~60 more
+    // with a rival -- 17 links per step on the SIMDs that end the headline launch):
+    //  * every mover ORs its rank bit into the mask row of ITS target lane (the membership masks are dead since the neighbour
+    //    scans; the next frame's snapshot zeroes them again) and leaves "decided in this frame | changer << 1" in its rank slot;
+    //  * a changer walks the members of its target lane's row AHEAD of it, nearest first, and stops at the first one beyond
+    //    bound >= d*(c, any sane rival) -- usually the very first;
+    //  * blocking rivals that are EARLIER changers only count while they do not abort themselves: ballots to the fixed point
+    //    (unique: a link depends on earlier links only).
     {
-      u64 cm = __ballot(changer);
-      // A rival is ANOTHER vehicle on its way to another lane (with the target it had at the start of the frame or the one it
-      // has now): most frames hold a single such vehicle -- the changer itself -- and then no link can block
-      if (cm && __popcll(__ballot(active && (me.lane != tgt_old || me.lane != me.tgt))) <= 1) cm = 0;
-      while (cm) {  // wave-uniform
-        const int ci = ctz64(cm);
-        cm &= cm - 1;
-        const int Tc = wave_bcast_i(tgt_old, ci);
-        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
-        // only ANOTHER vehicle moving into the same lane can block (behavior.py:233-237); usually there is none and the
-        // link costs three compares and a ballot instead of eight readlanes and a desired gap
-        const bool rival = active && i != ci && me.lane != Tc && my_tgt_seen == Tc;
-        if (__ballot(rival) == 0) continue;
-        const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
-        const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
-        bool blk = false;
-        if (rival) {
-          const double d = me.x - xc;
-          const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
-          blk = (0 < d) && (d < d_star);
+      const u64 cm = __ballot(changer);
+      // with a single vehicle on its way to another lane (the changer itself) no link can block
+      if (cm && __popcll(__ballot(active && (me.lane != tgt_old || me.lane != me.tgt))) > 1) {  // wave-uniform
+        int *const sbits = reinterpret_cast<int *>(sh.nx);  // (the post-integration bodies only live inside section G)
+        HWY_WAVE_LDS_FENCE();  // the masks' readers of this frame and section G of the previous one are done
+        if (i < p.L + 2) sh.lane_mask[i] = 0;
+        HWY_WAVE_LDS_FENCE();
+        sbits[rank] = ((me.tgt != tgt_old) ? 1 : 0) | (changer ? 2 : 0);
+        if (active && me.lane != me.tgt)
+          __hip_atomic_fetch_or(&sh.lane_mask[me.tgt + 1], (u64)1 << rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool sane = __ballot(active && !(me.v * me.ch >= 0.0 && fabs(me.v * me.sh) <= 5.0)) == 0;
+        HWY_WAVE_LDS_FENCE();
+        const u64 row = sh.lane_mask[tgt_old + 1];
+        u64 rem = changer ? (row & ~(((u64)2 << rank) - 1)) : 0;  // ranks above mine (2 << 63 wraps to 0)
+        u64 bc = 0;        // earlier changers (index space) that block me unless they abort
+        bool fixed = false;  // blocked for good
+        // d*(c, r) = 10 + 1.5 v + v dv / (2 sqrt(ab)), dv <= v + 5 for a sane rival when v >= 0 and cos h >= 0; 1e-6 relative +
+        // absolute on top, far above any rounding in d* (tests/test_wide_kernel.py::test_abort_chain_window_bound_...)
+        const double bound = (sane && me.v >= 0.0 && me.ch >= 0.0)
+                                 ? (HWY_DISTANCE_WANTED + me.v * HWY_TIME_WANTED + me.v * (me.v + 5.0) * 0.12909944487358055) * (1.0 + 1e-6) + 1e-6
+                                 : __builtin_inf();
+        while (__ballot(rem != 0) != 0) {  // wave-uniform
+          const bool go = rem != 0;
+          const int rr = go ? ctz64(rem) : 0;
+          rem &= rem - 1;
+          const double xr = sh.x[rr], vr = sh.v[rr], cr_ = sh.c[rr], sr = sh.s[rr];
+          const int ir = sh.idx[rr], fl_r = sbits[rr];
+          const double d = xr - me.x;
+          const bool inside = go && d < bound;
+          // a vehicle later in the list shows its frame-start target -- and one that decided in this very frame headed nowhere
+          const bool valid = inside && (ir < i || !(fl_r & 1));
+          const double d_star = B::desired_gap(me.v, me.ch, me.sh, vr, cr_, sr);
+          const bool blk = valid && (0 < d) && (d < d_star);
+          const bool cond = ir < i && (fl_r & 2) != 0;  // an earlier changer: it may abort
+          fixed = fixed || (blk && !cond);
+          bc |= (blk && cond) ? ((u64)1 << ir) : 0;
+          rem = ((go && !inside) || fixed) ? 0 : rem;
         }
-        if (__ballot(blk) != 0 && i == ci) me.tgt = me.lane;  // abort
+        if (__ballot(fixed || bc != 0) != 0) {  // wave-uniform
+          u64 ab = 0;
+          for (;;) {
+            const u64 nab = __ballot(fixed || (bc & ~ab) != 0);
+            if (nab == ab) break;
+            ab = nab;
+          }
+#ifndef HWY_WAVE_MUTANT_NO_ABORT  // (tests/test_wide_kernel.py: a build that never applies the verdict must fail the comparison)
+          if ((ab >> i) & 1) me.tgt = me.lane;  // abort
+#endif
+        }
       }
     }
 

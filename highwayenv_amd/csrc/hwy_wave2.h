@@ -738,34 +738,34 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       // with a single vehicle on its way to another lane (the changer itself) no link can block
       const bool chain = wide_any<K>(cm) && wide_popc<K>(mv_m) > 1;
       if (chain) {  // wave-uniform
-        // (1) into rank space: target lane | heads for it from another lane << 4 | decided in this frame << 5 | changer << 6
+        // (1) S_T (rank space) = the vehicles heading for lane T from another lane: every such vehicle ORs its rank bit into row T
+        // of the mask table (dead since the neighbour scans of this frame; zeroed again by the next frame's snapshot), and leaves
+        // "decided in this frame | changer << 1" in its rank slot for the walk; every changer then reads the row of ITS target lane
         bool insane = false;
-        HWY_WAVE_LDS_FENCE();  // (earlier readers of sbits are done)
+        HWY_WAVE_LDS_FENCE();  // (earlier readers of sbits and of the masks are done)
+        if (l < p.L) {
+#pragma unroll
+          for (int w = 0; w < K; ++w) sh.lane_mask[l][w] = 0;
+        }
+        HWY_WAVE_LDS_FENCE();
 #pragma unroll
         for (int h = 0; h < K; ++h) {
-          const int mover = (active[h] && me[h].lane != me[h].tgt) ? 1 : 0, decided = (me[h].tgt != tgt_old[h]) ? 1 : 0;
-          sh.sbits[rank[h]] = me[h].tgt | (mover << 4) | (decided << 5) | ((changer[h] ? 1 : 0) << 6);
+          const bool mover = active[h] && me[h].lane != me[h].tgt;
+          const int r = rank[h];
+          sh.sbits[r] = ((me[h].tgt != tgt_old[h]) ? 1 : 0) | ((changer[h] ? 1 : 0) << 1);
+          if (mover) __hip_atomic_fetch_or(&sh.lane_mask[me[h].tgt][r >> 6], (u64)1 << (r & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           insane = insane || (active[h] && !(me[h].v * me[h].ch >= 0.0 && fabs(me[h].v * me[h].sh) <= 5.0));
         }
         const bool sane = __ballot(insane) == 0;
         HWY_WAVE_LDS_FENCE();
-        u64 Dr[K], Cr[K], Rem[K][K], Bc[K][K];
-        int code[K];
+        u64 Rem[K][K], Bc[K][K];
 #pragma unroll
-        for (int w = 0; w < K; ++w) {
-          code[w] = sh.sbits[w * 64 + l];
-          Dr[w] = __ballot((code[w] >> 5) & 1);
-          Cr[w] = __ballot((code[w] >> 6) & 1);
-#pragma unroll
-          for (int h = 0; h < K; ++h) Rem[h][w] = Bc[h][w] = 0;
-        }
-        // S_T (rank space) = the vehicles heading for lane T from another lane; every changer keeps the members AHEAD of it
-        for (int T = 0; T < p.L; ++T) {  // wave-uniform
+        for (int h = 0; h < K; ++h) {
 #pragma unroll
           for (int w = 0; w < K; ++w) {
-            const u64 sT = __ballot(((code[w] >> 4) & 1) && (code[w] & 15) == T);
-#pragma unroll
-            for (int h = 0; h < K; ++h) Rem[h][w] = (changer[h] && tgt_old[h] == T) ? sT : Rem[h][w];
+            const u64 row = sh.lane_mask[tgt_old[h]][w];  // (every slot's target lane is a valid row)
+            Rem[h][w] = changer[h] ? row : 0;
+            Bc[h][w] = 0;
           }
         }
         bool fixed[K], any_left = false;
@@ -802,15 +802,15 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
               go = go || take;
             }
             const double xr = sh.x[rr], vr = sh.v[rr], cr = sh.c[rr], sr = sh.s[rr];
-            const int ir = sh.idx[rr];
+            const int ir = sh.idx[rr], fl_r = sh.sbits[rr];  // fl_r: the rival decided in this frame | is a changer << 1
             const double d = xr - me[h].x;
             const bool inside = go && d < bound[h];
             // the target r shows to c: its current one if it comes before c in the list, else the frame-start one -- and a vehicle
             // that decided in this very frame headed nowhere with that one
-            const bool valid = inside && (ir < vi[h] || !wide_test<K>(Dr, rr));
+            const bool valid = inside && (ir < vi[h] || !(fl_r & 1));
             const double d_star = B::desired_gap(me[h].v, me[h].ch, me[h].sh, vr, cr, sr);
             const bool blk = valid && (0 < d) && (d < d_star);
-            const bool cond = ir < vi[h] && wide_test<K>(Cr, rr);  // an earlier changer: it may abort
+            const bool cond = ir < vi[h] && (fl_r & 2) != 0;  // an earlier changer: it may abort
             fixed[h] = fixed[h] || (blk && !cond);
 #pragma unroll
             for (int w = 0; w < K; ++w) {
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
           if (count > 64 * h) {  // wave-uniform: the second slot only when the list holds more than 64 pairs
             const int t = h * 64 + l;
             const int pair = t < count ? (int)sh.plist[(head + t) & (RING - 1)] : -1;
-            const int u0 = pair & 255, u1 = (pair >> 8) & 255;
+            const int u0 = pair < 0 ? 0 : (pair & 255), u1 = pair < 0 ? 0 : ((pair >> 8) & 255);  // (no pair: slot 0, discarded)
             const int a = u0 < u1 ? u0 : u1, b = u0 < u1 ? u1 : u0;  // a < b: the reference's `self` and `other`
             pa[h] = a;
             pb[h] = b;

@@ -208,6 +208,49 @@ def test_abort_chain_on_the_emulator():
         emu._lib = saved
 
 
+def test_one_wavefront_abort_chain_on_the_emulator():
+    """The same per-thread rank-space chain in the N <= 64 kernel (hwy_wave.h section D: the headline path and highway-v0), against
+    the workgroup kernel's literal link-by-link chain, bit for bit, on dense three-lane traffic; and its own no-abort mutant."""
+    import ctypes as C
+    import tests.emu.emu as emu
+
+    def soak(E, T):
+        cfg_d = _abi.highway_default_config()
+        cfg_d.update({"vehicles_count": 60, "lanes_count": 3, "vehicles_density": 2.2, "duration": 12})
+        wave, block = _pair("emu", cfg_d, E, False)
+        cfg = _abi.make_config(cfg_d, E, fast=False)
+        st = spawn.spawn_reference_stream(cfg, np.arange(E) + 41, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+        for eng in (wave, block):
+            eng.set_state(_abi.copy_state(st))
+            eng.set_autoreset(True, base_seed=8, ego_spacing=cfg_d["ego_spacing"], vehicles_density=cfg_d["vehicles_density"])
+        rng = np.random.default_rng(4)
+        changing = 0
+        for t in range(T):
+            acts = rng.integers(0, 5, size=(E, 1)).astype(np.int32)
+            wave.step(acts)
+            block.step(acts)
+            a = wave.get_state()
+            _assert_same(a, block.get_state(), f"step {t}")
+            changing += int((a["lane"] != a["target_lane"]).sum())
+        wave.close()
+        block.close()
+        return changing
+
+    emu.build()
+    assert soak(12, 16) > 20
+    src = emu.os.path.join(emu._HERE, "emu_engine.cpp")
+    saved = emu._lib
+    try:
+        mutant = emu.os.path.join(emu._HERE, "_build", "libhwy_emu_wave_noabort.so")
+        emu.compile_emulator(src, mutant, ["-DHWY_WAVE_MUTANT_NO_ABORT=1"])
+        emu._lib = C.CDLL(mutant)
+        emu._lib.emu_config_size.restype = C.c_size_t
+        with pytest.raises(AssertionError):
+            soak(12, 16)
+    finally:
+        emu._lib = saved
+
+
 def test_abort_chain_window_bound_dominates_the_desired_gap():
     """The wide kernel's abort chain stops walking the vehicles ahead of a changer at
     bound = (10 + 1.5 v + v (v + 5) / (2 sqrt(ab))) (1 + 1e-6) + 1e-6, claimed to dominate IDMVehicle.desired_gap(changer, rival)
