@@ -846,64 +846,33 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
     }
     if (ok_l) me.tgt = L_left;
     if (ok_r) me.tgt = L_right;
-    // abort rule for ongoing lane changes on the same road (behavior.py:229-244): an ordered chain over Road.vehicles, evaluated
-    // per THREAD in rank space like in hwy_wave.h / hwy_wave2.h (derivation there).  What differs on a road network: a vehicle's
-    // target also moves by follow_road, so a rival r shows a changer c its CURRENT target if it comes before c in the list and
-    // its FRAME-START one otherwise -- either may be the lane c heads for: r ORs its rank bit into the rows of both (when they
-    // differ from its own lane) and leaves "current | frame-start << 8 | may abort << 16" in its rank slot; the lane distance is
-    // measured along c's own lane, (x_r - x0) - (x_c - x0), monotone in x like the rank order the walk follows.
+    // abort rule for ongoing lane changes on the same road: ordered chain over Road.vehicles (behavior.py:229-244)
+    // (The per-thread rank-space form of hwy_wave.h / hwy_wave2.h was built and measured here in round 5: 232.0 us against this
+    // literal chain's 230.5 on BASELINE config 5, interleaved on one box -- a merge frame holds one or two movers, a link without
+    // a rival costs three compares and a ballot, and the rank-space form pays its mask exchange in every frame with a chain.
+    // profiles/r05_history.md; the literal chain stays.)
     {
-      const bool may_abort = changer && same_road;
-      const u64 cm = __ballot(may_abort);
+      u64 cm = __ballot(changer && same_road);
       // a rival is ANOTHER vehicle on its way to another lane (old or new target): none, no link can block
-      if (cm && __popcll(__ballot(veh && (me.lane != tgt_old || me.lane != me.tgt))) > 1) {  // wave-uniform
-        int *const sbits = reinterpret_cast<int *>(sh.nx);  // (the post-integration bodies only live inside the collision section)
-        HWY_WAVE_LDS_FENCE();  // the masks' readers of this frame are done
-        if (i < np.n_lanes) sh.lane_mask[i] = 0;
-        HWY_WAVE_LDS_FENCE();
-        sbits[rank] = me.tgt | (tgt_old << 8) | (may_abort ? 1 << 16 : 0);
-        if (veh && me.lane != me.tgt)
-          __hip_atomic_fetch_or(&sh.lane_mask[me.tgt], (u64)1 << rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (veh && me.lane != tgt_old && tgt_old != me.tgt)
-          __hip_atomic_fetch_or(&sh.lane_mask[tgt_old], (u64)1 << rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool sane = __ballot(veh && !(me.v * me.ch >= 0.0 && fabs(me.v * me.sh) <= 5.0)) == 0;
-        HWY_WAVE_LDS_FENCE();
-        const u64 row = sh.lane_mask[tgt_f];
-        u64 rem = may_abort ? (row & ~(((u64)2 << rank) - 1)) : 0;  // ranks above mine (2 << 63 wraps to 0)
-        u64 bc = 0;          // earlier changers (slot space) that block me unless they abort
-        bool fixed = false;  // blocked for good
-        // d*(c, r) <= 10 + 1.5 v + v (v + 5) / (2 sqrt(ab)) for a sane rival when v >= 0, cos h >= 0 (hwy_wave2.h); + 1e-6
-        // relative and absolute, far above the rounding of d* and of the two subtractions of the lane distance
-        const double bound = (sane && me.v >= 0.0 && me.ch >= 0.0)
-                                 ? (HWY_DISTANCE_WANTED + me.v * HWY_TIME_WANTED + me.v * (me.v + 5.0) * 0.12909944487358055) * (1.0 + 1e-6) + 1e-6
-                                 : __builtin_inf();
-        const double xc_l = me.x - ox_me;
-        while (__ballot(rem != 0) != 0) {  // wave-uniform
-          const bool go = rem != 0;
-          const int rr = go ? ctz64(rem) : 0;
-          rem &= rem - 1;
-          const double xr = sh.x[rr], vr = sh.v[rr], cr_ = sh.c[rr], sr = sh.s[rr];
-          const int ir = sh.idx[rr], code = sbits[rr];
-          const double d = (xr - ox_me) - xc_l;
-          const bool inside = go && d < bound;
-          const int shown = ir < i ? (code & 255) : ((code >> 8) & 255);
-          const bool valid = inside && shown == tgt_f;
-          const double d_star = EnvBlock<1>::desired_gap(me.v, me.ch, me.sh, vr, cr_, sr);
-          const bool blk = valid && (0 < d) && (d < d_star);
-          const bool cond = ir < i && (code >> 16) != 0;  // an earlier changer: it may abort
-          fixed = fixed || (blk && !cond);
-          bc |= (blk && cond) ? ((u64)1 << ir) : 0;
-          rem = ((go && !inside) || fixed) ? 0 : rem;
+      if (cm && __popcll(__ballot(veh && (me.lane != tgt_old || me.lane != me.tgt))) <= 1) cm = 0;
+      while (cm) {  // wave-uniform
+        const int ci = ctz64(cm);
+        cm &= cm - 1;
+        const int Tc = wave_bcast_i(tgt_f, ci);
+        // usually nobody else heads for the changer's lane: the link then costs three compares and a ballot
+        if (__ballot(veh && i != ci && me.lane != Tc && ((i < ci) ? me.tgt : tgt_old) == Tc) == 0) continue;
+        const double xc = wave_bcast(me.x, ci), vc = wave_bcast(me.v, ci);
+        const double cc = wave_bcast(me.ch, ci), sc = wave_bcast(me.sh, ci);
+        const double oxc = wave_bcast(ox_me, ci);
+        const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+        bool blk = false;
+        if (veh && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+          const double d = (me.x - oxc) - (xc - oxc);
+          const double d_star = EnvBlock<1>::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
+          blk = (0 < d) && (d < d_star);
         }
-        if (__ballot(fixed || bc != 0) != 0) {  // wave-uniform
-          u64 ab = 0;
-          for (;;) {
-            const u64 nab = __ballot(fixed || (bc & ~ab) != 0);
-            if (nab == ab) break;
-            ab = nab;
-          }
-          if ((ab >> i) & 1) me.tgt = me.lane;  // abort
-        }
+        // `break` at the first hit does not change the outcome: the target is reset once
+        if (__ballot(blk) != 0 && i == ci) me.tgt = me.lane;
       }
     }
 
