@@ -246,20 +246,45 @@ __device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double 
 //      none; more = another pass follows).
 //      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
 //      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
+// HWY_IX_PAIR_TRIPS partner slots are asked per trip of the collecting loop (their cand() calls are independent: LDS reads, a
+// dozen f64 operations, no state); the list is appended to in trip order either way (a slot met while the list is full is put back
+// and asked again after the pass: same pairs, same order).  Measured on BASELINE config 4 (profiles/r05_history.md): 1 -> 255.7 us,
+// 2 -> 257.8, 4 -> 259.3, 8 -> 288.2 -- the loops are bound by the instructions a lone wavefront issues (one per 4 cycles, SALU
+// included), not by the latency of a trip: more chains in flight only add bookkeeping.  1 it stays.
+#ifndef HWY_IX_PAIR_TRIPS
+#define HWY_IX_PAIR_TRIPS 1
+#endif
 template <typename SH, typename Cand, typename Proc>
 __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
+  constexpr int U = HWY_IX_PAIR_TRIPS;
   const int i = threadIdx.x, width = (int)blockDim.x;  // pairs per pass: 64, or 32 in the 32-thread build
   const u64 below = ((u64)1 << i) - 1;
   int n_list = 0;  // wave-uniform
   while (trips || n_list) {
     while (trips && n_list < width) {
-      const int j = ctz64(trips) + half;
-      trips &= trips - 1;
-      const bool c = cand(j);
-      const u64 cm = __ballot(c);
-      if (cm) {
-        if (c) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | (j << 8));
-        n_list += __popcll(cm);
+      int jb[U];
+      bool c[U];
+      u64 t_ = trips;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // (wave-uniform slots; -1 = none left)
+        jb[u] = t_ ? ctz64(t_) : -1;
+        t_ &= t_ - 1;  // (0 stays 0)
+      }
+      trips = t_;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // (no slot left: slot 0 is asked and the answer dropped -- no branch between the chains)
+        const bool cu = cand((jb[u] < 0 ? 0 : jb[u]) + half);
+        c[u] = jb[u] >= 0 && cu;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (jb[u] < 0) continue;                                 // wave-uniform
+        if (n_list >= width) { trips |= (u64)1 << jb[u]; continue; }  // the list is full: asked again after the pass
+        const u64 cm = __ballot(c[u]);
+        if (cm) {
+          if (c[u]) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | ((jb[u] + half) << 8));
+          n_list += __popcll(cm);
+        }
       }
     }
     const int count = n_list < width ? n_list : width;
@@ -299,31 +324,40 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
   double bd = __builtin_inf(), lat_t = 0.0;  // lat_t: my lateral coordinate on my target lane (the next frame steers by it)
   bool has_lat = false;
   const int ns = sh.n_straight, n = ip.n_lanes;
-  // A lone wavefront is bound by the LATENCY of its dependent f64 chains here, not by issue slots: every trip projects
-  // the body on TWO lanes per half (rows k and k + NH) in one basic block, so that the two chains interleave.
-  for (int k = 0; k < ns; k += 2 * NH) {  // wave-uniform trip
-    const int k0 = k + half, k1 = k0 + NH;
-    const bool m0 = k0 < ns, m1 = k1 < ns;
-    const IxRow r0 = sh.row[m0 ? k0 : k], r1 = sh.row[m1 ? k1 : k];
-    const double dx0 = x - r0.a, dy0 = y - r0.b, dx1 = x - r1.a, dy1 = y - r1.b;
-    const double s0 = dx0 * r0.c + dy0 * r0.d, s1 = dx1 * r1.c + dy1 * r1.d;
-    const double lat0 = dx0 * -r0.d + dy0 * r0.c, lat1 = dx1 * -r1.d + dy1 * r1.c;
-    const bool on0 = fabs(lat0) <= r0.e && -5.0 <= s0 && s0 < r0.f + 5.0;
-    const bool on1 = fabs(lat1) <= r1.e && -5.0 <= s1 && s1 < r1.f + 5.0;
-    const double ang0 = fabs(wrap_to_pi(h - r0.g)), ang1 = fabs(wrap_to_pi(h - r1.g));
-    const double d0 = fabs(lat0) + fmax(s0 - r0.f, 0.0) + fmax(0 - s0, 0.0) + 1.0 * ang0;
-    const double d1 = fabs(lat1) + fmax(s1 - r1.f, 0.0) + fmax(0 - s1, 0.0) + 1.0 * ang1;
-    if (m0) {
-      bits |= on0 ? (1 << r0.L) : 0;
-      sh.sl[r0.L][vi] = s0;
-      if (d0 < bd || (d0 == bd && r0.L < best)) { bd = d0; best = r0.L; }
-      if (r0.L == tgt) { lat_t = lat0; has_lat = true; }
+  // Every trip projects the body on HWY_IX_WALK_ROWS lanes per half (rows k + half, + NH, + 2 NH ..) in one basic block, so that
+  // the chains interleave.  Two, three or all six rows of a half per trip: 259.3 / 259.3 / 259.4 us on BASELINE config 4
+  // (profiles/r05_history.md) -- two it stays.
+#ifndef HWY_IX_WALK_ROWS
+#define HWY_IX_WALK_ROWS 2
+#endif
+  constexpr int R = HWY_IX_WALK_ROWS;
+  for (int k = 0; k < ns; k += R * NH) {  // wave-uniform trip
+    bool m[R], on[R];
+    IxRow r[R];
+    double s_[R], lat[R], d[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int ku = k + half + u * NH;
+      m[u] = ku < ns;
+      r[u] = sh.row[m[u] ? ku : k];
     }
-    if (m1) {
-      bits |= on1 ? (1 << r1.L) : 0;
-      sh.sl[r1.L][vi] = s1;
-      if (d1 < bd || (d1 == bd && r1.L < best)) { bd = d1; best = r1.L; }
-      if (r1.L == tgt) { lat_t = lat1; has_lat = true; }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const double dx = x - r[u].a, dy = y - r[u].b;
+      s_[u] = dx * r[u].c + dy * r[u].d;
+      lat[u] = dx * -r[u].d + dy * r[u].c;
+      on[u] = fabs(lat[u]) <= r[u].e && -5.0 <= s_[u] && s_[u] < r[u].f + 5.0;
+      const double ang = fabs(wrap_to_pi(h - r[u].g));
+      d[u] = fabs(lat[u]) + fmax(s_[u] - r[u].f, 0.0) + fmax(0 - s_[u], 0.0) + 1.0 * ang;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (m[u]) {
+        bits |= on[u] ? (1 << r[u].L) : 0;
+        sh.sl[r[u].L][vi] = s_[u];
+        if (d[u] < bd || (d[u] == bd && r[u].L < best)) { bd = d[u]; best = r[u].L; }
+        if (r[u].L == tgt) { lat_t = lat[u]; has_lat = true; }
+      }
     }
   }
   {
@@ -344,14 +378,12 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
     const u64 rows = na >= 64 ? ~(u64)0 : (((u64)1 << na) - 1);
     ix_for_pairs(
         sh, NH > 1 ? ((rows | (rows >> 1)) & 0x5555555555555555ull) : rows, vi, half,
-        [&](int j) {
-          if (!(present && j < na)) return false;
-          const IxRow r = sh.row[ns + j];
-          if (r.L == tgt) return true;
+        [&](int j) {  // (straight-line code: ix_for_pairs keeps several of these in flight)
+          const IxRow r = sh.row[ns + (j < na ? j : 0)];
           // |radius - rr| <= m with m = max(width / 2 + 1, best straight distance), on the squares (a filter: 1e-9 of slack)
           const double dx = x - r.a, dy = y - r.b, r2 = dx * dx + dy * dy;
           const double m = fmax(r.e, bd) + 1e-9, lo = r.c - m, hi = r.c + m;
-          return (lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi;
+          return present && j < na && (r.L == tgt || ((lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi));
         },
         [&](int pair, bool more) {
           const int v = pair < 0 ? 0 : (pair & 255);
@@ -728,10 +760,9 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       ix_for_pairs(
           sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
           [&](int j) {
-            if (!(veh_v && vi < j && ((pm >> j) & 1))) return false;
             const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
             const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
-            return bdx * bdx + bdy * bdy <= reach * reach;
+            return veh_v && vi < j && ((pm >> j) & 1) && bdx * bdx + bdy * bdy <= reach * reach;
           },
           [&](int pair, bool) {
             if (pair < 0) return;
@@ -818,11 +849,11 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       ix_for_pairs(
           sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
           [&](int j) {
-            if (!(present_v && vi < j && ((pm >> j) & 1))) return false;
-            const Body other{sh.x[j], sh.y[j], sh.v[j], sh.c[j], sh.s[j]};
-            const double dx = other.x - mine.x, dy = other.y - mine.y;
-            const double lim = 5.5 + fmax(fabs(mine.v), fabs(other.v)) * p.dt;
-            return dx * dx + dy * dy <= lim * lim;  // objects.py:124-127 (the pre-check sphere: a dozen instructions per trip)
+            const double ox = sh.x[j], oy = sh.y[j], ov = sh.v[j];
+            const double dx = ox - mine.x, dy = oy - mine.y;
+            const double lim = 5.5 + fmax(fabs(mine.v), fabs(ov)) * p.dt;
+            // objects.py:124-127 (the pre-check sphere: a dozen instructions per trip)
+            return present_v && vi < j && ((pm >> j) & 1) && dx * dx + dy * dy <= lim * lim;
           },
           [&](int pair, bool) {
             // one PAIR per thread: the provable-separation test (hwy_device.h: provably (False, False) without the SAT) and, if

@@ -218,13 +218,14 @@ __device__ inline void net_rank(double x, bool present, u64 pm, int &rank, bool 
 // lanes `rank` and `rank - 1` (ds_permute); lane r then holds x of rank r and of rank r + 1 and checks the order.
 // Disjoint adjacent inversions (an overtake somewhere on the road) are repaired by swapping the two ranks;
 // anything else (overlapping inversions, equal x) goes back to the counting pass.
-__device__ inline void net_update_rank(double x, bool present, u64 pm, int n_present, int &rank, bool &has_tie) {
+// `trusted` = false (wave-uniform): `rank` is not known to be a permutation (a stale hint): count.
+__device__ inline void net_update_rank(double x, bool present, u64 pm, int n_present, int &rank, bool &has_tie, bool trusted = true) {
   const int i = threadIdx.x;
   const int lo = __double2loint(x), hi = __double2hiint(x);
   const double x_r = __hiloint2double(wave_send_i(hi, rank), wave_send_i(lo, rank));
   const double x_r1 = __hiloint2double(wave_send_i(hi, rank - 1), wave_send_i(lo, rank - 1));
-  bool recount = __ballot(i < n_present - 1 && !(x_r < x_r1)) != 0;
-  if (recount) {  // wave-uniform
+  bool recount = !trusted || __ballot(i < n_present - 1 && !(x_r < x_r1)) != 0;
+  if (recount && trusted) {  // wave-uniform
     const u64 inv = __ballot(i < n_present - 1 && x_r > x_r1);
     if (inv != 0 && (inv & (inv << 1)) == 0) {
       const bool up = present && ((inv >> rank) & 1);
@@ -660,6 +661,9 @@ __device__ inline void net_spawn_env(const NetParams &np, NetShared &sh, uint64_
   const NetParams &q = *(const NetParams *)kernarg_
 #endif
 
+#ifndef HWY_NET_WALK_STEPS
+#define HWY_NET_WALK_STEPS 2  // partners asked per trip of the collision walk
+#endif
 // One policy step of environment e by its wavefront (the lane table is in LDS); eo = row of the action / output planes.
 template <bool GRID>
 __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &sh, const int e, const int eo) {
@@ -742,8 +746,18 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
 
     // ---- B. rank along x, lane membership masks, frame-start snapshot ----------------------------------------
     // (counted in the first frame of a step, then carried from frame to frame and merely re-validated)
-    if (fr == 0) net_rank(me.x, present, pm, rank, has_tie);
-    else net_update_rank(me.x, present, pm, n_present, rank, has_tie);
+    {
+      // the order at the end of the previous step travels in the packed word (a HINT, like on the highway: hwy_set_state writes
+      // the slot index, a device spawn too): taken if it is a permutation that gives the present slots the ranks below
+      // n_present -- one ds_permute and two ballots --, then verified against the positions like in every later frame;
+      // anything else is counted (rounds 1-4 counted in the first frame of every step: 4.9 % of BASELINE config 5)
+      bool trusted = true;  // wave-uniform
+      if (fr == 0) {
+        rank = present ? me.rank : n_present + __popcll(~pm & (((u64)1 << i) - 1));
+        trusted = __ballot(present && rank >= n_present) == 0 && __ballot(wave_send_i(1, rank) != 0) == ~(u64)0;
+      }
+      net_update_rank(me.x, present, pm, n_present, rank, has_tie, trusted);
+    }
     // lane_mask[i] = the ranks lane i is searched with: its own members and, with connected lanes, those of the connected
     // segments too (a vehicle on two of them is one bit; all of these lanes measure s from x, so the order along x is the
     // order of `s_v + offset` of road.py:536-545).  Every vehicle ORs its rank bit into the masks of the lanes that read the
@@ -957,35 +971,49 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
       // (the snapshot arrays of this frame are dead here: they hold the per-slot results and the pair list)
       int *const jmax = reinterpret_cast<int *>(sh.lr), *const hit = reinterpret_cast<int *>(sh.ox);
       double *const ipx = sh.v, *const ipy = sh.c;
-      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.scratch);  // 128 entries
+      unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.scratch);  // 288 entries (at most 63 + 2 x 64 are ever listed)
       jmax[i] = -1;
       hit[i] = 0;
       const u64 below = ((u64)1 << i) - 1;
+      constexpr int WS = HWY_NET_WALK_STEPS;
       int n_list = 0, k = 1;  // wave-uniform
       bool go_b = present, walking = true;
       while (walking || n_list) {
         while (walking && n_list < 64) {
-          const int rb = rank + k;
-          const int r2 = rb < n_present ? rb : 0;
-          // (all four reads are issued before anything depends on one)
-          const double x0 = sh.x[r2], px = sh.nx[r2], py = sh.ny[r2], pv = sh.nv[r2];
-          const int q = sh.idx[r2];
-          go_b = go_b & (rb < n_present) & !(fabs(x0 - x_old) > reach);
-          ++k;
+          // two walk steps per trip (like the other two sorted kernels); the slots are clamped by the range alone so that every
+          // LDS read of the trip is issued before anything depends on one
+          bool near[WS];
+          int q[WS], r2[WS];
+          double x0[WS], px[WS], py[WS], pv[WS];
+#pragma unroll
+          for (int u = 0; u < WS; ++u) {
+            const int rb = rank + k + u;
+            r2[u] = rb < n_present ? rb : 0;
+            x0[u] = sh.x[r2[u]]; px[u] = sh.nx[r2[u]]; py[u] = sh.ny[r2[u]]; pv[u] = sh.nv[r2[u]];
+            q[u] = sh.idx[r2[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < WS; ++u) {
+            go_b = go_b & (rank + k + u < n_present) & !(fabs(x0[u] - x_old) > reach);
+            const double dx = px[u] - me.x, dy = py[u] - me.y;
+            const double lim = 5.5 + fmax(fabs(me.v), fabs(pv[u])) * p.dt;
+            near[u] = go_b & !(dx * dx + dy * dy > lim * lim);
+          }
+          k += WS;
           if (__ballot(go_b) == 0 || k >= n_present) walking = false;
-          const double dx = px - me.x, dy = py - me.y;
-          const double lim = 5.5 + fmax(fabs(me.v), fabs(pv)) * p.dt;
-          const bool near = go_b & !(dx * dx + dy * dy > lim * lim);
-          const u64 km = __ballot(near);
-          if (km) {
-            if (near) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q ? (rank | (r2 << 8)) : (r2 | (rank << 8)));
-            n_list += __popcll(km);
+#pragma unroll
+          for (int u = 0; u < WS; ++u) {
+            const u64 km = __ballot(near[u]);
+            if (km) {
+              if (near[u]) plist[n_list + __popcll(km & below)] = (unsigned short)(i < q[u] ? (rank | (r2[u] << 8)) : (r2[u] | (rank << 8)));
+              n_list += __popcll(km);
+            }
           }
         }
-        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64
+        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
         HWY_WAVE_LDS_FENCE();
         const int pair = i < count ? (int)plist[i] : -1;
-        const int carry = i < left ? (int)plist[count + i] : 0;
+        const int carry = i < left ? (int)plist[count + i] : 0, carry1 = 64 + i < left ? (int)plist[count + 64 + i] : 0;
         const int ra = pair < 0 ? 0 : (pair & 255), rb = pair < 0 ? 0 : (pair >> 8);
         const int a = sh.idx[ra], b = sh.idx[rb];  // a < b: the reference's `self` and `other`
         const bool a_veh = sh.kind[ra] != 0, b_veh = sh.kind[rb] != 0;
@@ -1013,6 +1041,7 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
           }
         }
         if (i < left) plist[i] = (unsigned short)carry;
+        if (64 + i < left) plist[64 + i] = (unsigned short)carry1;
         n_list = left;
         HWY_WAVE_LDS_FENCE();
       }
@@ -1034,8 +1063,7 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
     net_observe<GRID>(np, sh, e, eo, me, true, (!GRID && p.n_frames > 0 && !has_tie) ? rank : -1);
   }
   {
-    // rank hint for the next step is not used by this kernel; keep the slot index
-    me.rank = i & 0xff;
+    me.rank = rank & 0xff;  // the hint the next step verifies
     store_vehicle<1>(p, e, me, false);
   }
 }
