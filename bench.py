@@ -69,7 +69,7 @@ def _load_counters(name: str, workload: str):
     """A committed rocprofv3 PMC summary (profiles/<name>) -- returned ONLY if it was recorded for the kernel build
     being timed (its `kernel_source_sha16` equals this build's) and for this workload: counters of another build
     say nothing about this one, and PMC counters cannot be read from inside this process."""
-    for rnd in ("r04", "r03", "r02"):  # the newest round's file first
+    for rnd in ("r05", "r04", "r03", "r02"):  # the newest round's file first
         path = os.path.join(ROOT, "profiles", name.replace("RND", rnd))
         try:
             d = json.load(open(path))
@@ -93,14 +93,30 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     c = d["per_wave_per_step"]
     flop = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"]) * 64 * envs_per_gpu
     achieved = flop / avg_kernel_s / 1e12
-    # the ceiling that binds this kernel: every VALU instruction of a 64-wide wavefront holds its SIMD's issue port for 4 cycles
-    # (16 lanes per cycle, f64 and 32-bit alike), so a launch cannot end before (VALU instructions of all its wavefronts) x 4
-    # cycles / (1024 SIMDs x 2.4 GHz).  valu_issue = that floor / the measured launch duration.
+    # the ceiling that binds this kernel: what its VALU instructions occupy the SIMDs for.  MEASURED per class on this part
+    # (tools/microbench/issue_bench.hip -> profiles/r05_issue_costs.json): f64 arithmetic, VOP3 compares / selects with an SGPR
+    # operand, 64-bit shifts, conversions and cross-lane reads take 4 cycles; plain 32-bit VOP1/VOP2 take 2 in a run of their own
+    # but 4 when interleaved 1:1 with f64 instructions, which is how these kernels use them (4.0 cycles per instruction of the
+    # fma_f64 x and_b32 mix at every occupancy; SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.07 in the counters); f64 transcendental
+    # seeds (v_rcp_f64 / v_rsq_f64) take 16.  So a launch cannot end before
+    #   (4 x SQ_INSTS_VALU + 12 x SQ_INSTS_VALU_TRANS_F64) x environments / (1024 SIMDs x 2.4 GHz);
+    # valu_issue = that floor / the measured launch duration.  `valu_issue_if_32bit_at_2_cycles` prices the instructions that
+    # are neither f64 nor cross-lane at 2 cycles -- a bound the microbenchmark says these kernels cannot reach, kept for scale.
     # (the committed counters are sums over a launch / environments: per env-step, whatever the wavefronts per environment)
-    issue_floor_s = c["SQ_INSTS_VALU"] * 4.0 * envs_per_gpu / (SIMDS * CLOCK_HZ)
+    trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    cycles = 4.0 * c["SQ_INSTS_VALU"] + 12.0 * trans
+    issue_floor_s = cycles * envs_per_gpu / (SIMDS * CLOCK_HZ)
+    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + trans
+    narrow = max(0.0, c["SQ_INSTS_VALU"] - f64 - c.get("SQ_INSTS_VALU_INT64", 0.0) - c.get("SQ_INSTS_VALU_CVT", 0.0))
+    optimistic_s = (cycles - 2.0 * narrow) * envs_per_gpu / (SIMDS * CLOCK_HZ)
+    wait = c.get("SQ_WAIT_ANY")
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
             "valu_issue": issue_floor_s / avg_kernel_s, "valu_issue_floor_us": issue_floor_s * 1e6,
-            "valu_issue_method": f"SQ_INSTS_VALU per env-step x 4 cycles x {envs_per_gpu} envs / ({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz) / avg_kernel_us",
+            "valu_issue_method": (f"(4 x SQ_INSTS_VALU + 12 x SQ_INSTS_VALU_TRANS_F64) cycles per env-step x {envs_per_gpu} envs / "
+                                  f"({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz) / avg_kernel_us; per-class costs measured: "
+                                  "profiles/r05_issue_costs.json"),
+            "valu_issue_if_32bit_at_2_cycles": optimistic_s / avg_kernel_s,
+            "wait_fraction_of_a_wavefront": (wait / c["SQ_WAVE_CYCLES"]) if wait else None,
             "valu_instructions_per_env_step": c["SQ_INSTS_VALU"], "salu_instructions_per_env_step": c["SQ_INSTS_SALU"],
             # (one wavefront per environment and the whole grid resident: the headline workload only)
             "valu_issue_utilisation_while_resident": (c["SQ_ACTIVE_INST_VALU"] * d.get("waves_per_simd", 4) / c["SQ_WAVE_CYCLES"]
@@ -164,6 +180,7 @@ def cpu_baseline(workload: str, cfg_dict, fast: bool, scenario: str, have_gpu: b
     if ref_bench.available():
         out = ref_bench.measure(workload, budget_s=30.0, all_cores_budget_s=30.0)
         out["reference"] = dict({k: v for k, v in out.items() if k != "all_cores"}, same_box=True, all_cores=out.get("all_cores"))
+        out["same_box"] = True
         if port is not None:
             out["port"] = port
         return out
@@ -345,22 +362,34 @@ SECONDARY = [("config 3 shard: highway-v0, 1024 envs x 101 vehicles", ["--worklo
              ("highway-v0 defaults, 4096 envs x 51 vehicles", ["--workload", "v0"])]
 
 
-def secondary_workloads(steps: int = 200, repeats: int = 3) -> dict:
+def secondary_workloads(steps: int = 200, repeats: int = 3, budget_s: float = 100.0) -> dict:
     """BASELINE's other single-GPU configurations, one short run of this same script each (its own process, after the headline's
-    timed regions; same box, same build), so that the driver's record carries their numbers too.  Never part of `value`."""
+    timed regions; same box, same build), so that the driver's record carries their numbers too.  Never part of `value`.
+    `budget_s` bounds ALL legs together (a leg takes ~8 s; one that hangs gets what is left of the budget, the legs after it are
+    reported as skipped): the headline's one JSON line is never held back by more than that."""
     import subprocess
     out = {}
+    t_end = time.perf_counter() + budget_s
     for name, argv in SECONDARY:
+        left = t_end - time.perf_counter()
+        if left < 5.0:
+            out[argv[1]] = {"workload": name, "error": f"skipped: the {budget_s:.0f} s budget of the secondary legs was spent"}
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), *argv, "--steps", str(steps), "--repeats", str(repeats), "--warmup", "20",
                "--settle-ms", "100", "--no-cpu-baseline", "--no-secondary", "--rollout-k", "0"]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             rf = d["roofline"]
+            v = rf.get("valu") or {}
             out[argv[1]] = {"workload": name, "ms_per_step": d["ms_per_step"], "ms_per_step_device": d["ms_per_step_device"],
                             "value": d["value"], "unit": d["unit"], "vehicle_steps_per_s": d["vehicle_steps_per_s"],
                             "steps": steps, "repeats": repeats, "avg_kernel_us": rf["avg_kernel_us"], "kernel": rf["kernel"],
-                            "roofline_frac_hbm": rf["frac"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"]}
+                            "roofline_frac_hbm": rf["frac"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                            # the ceiling that binds these kernels (None unless profiles/ holds SQ counters of THIS build)
+                            "valu_issue": v.get("valu_issue"), "valu_issue_floor_us": v.get("valu_issue_floor_us"),
+                            "wait_fraction_of_a_wavefront": v.get("wait_fraction_of_a_wavefront"),
+                            "valu_active_fraction_of_a_wavefront": v.get("valu_active_fraction_of_a_wavefront")}
         except Exception as ex:  # a report next to the headline, never a reason to lose the headline
             out[argv[1]] = {"workload": name, "error": repr(ex)[:300]}
     return out

@@ -31,8 +31,12 @@ HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"
 # launch stays bit-identical to K one-step launches (tests/test_rollout.py).  "fast" (fuse whatever the optimiser finds after
 # inlining) fuses 4 % more sites and measured 1 ulp apart between hwy_step_kernel and hwy_rollout_kernel on the reward
 # (profiles/r04_history.md).  "off" (rounds 1-3) rounded every a*b+c twice like the reference's numpy scalars: +6.6 % on the
-# headline launch.  No parity test depended on the double rounding: every comparison with the reference is at 1e-9 or looser
-# (DESIGN.md section 4).  tests/emu builds the CPU emulator with the same front end and the same setting.
+# headline launch.  The per-frame comparisons with the reference are at 1e-9 and unaffected; ONE bound moved with this setting:
+# the lateral offset of intersection cars between 1 and 2 m/s after 15 free-running frames (steering_control divides by
+# not_zero(speed) twice and amplifies the fused roundings: 4.8e-8 measured) is held at 1e-6 where the unfused build held 1e-8
+# (tests/test_ix_parity.py, tests/golden_util.py: slow_atol) -- and the exact comparisons (lane indices, flags) now rest on the
+# decisions being well conditioned, not on identical arithmetic: DESIGN.md section 4 states both as part of the parity contract.
+# tests/emu builds the CPU emulator with the same front end and the same setting.
 FP_CONTRACT = "on"
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", f"-ffp-contract={FP_CONTRACT}", "-fPIC", "-mllvm", "-disable-machine-licm",
                "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
@@ -106,7 +110,9 @@ def build_engine_asan(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(ASAN_LIB_PATH) and os.path.getmtime(ASAN_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs):
         return ASAN_LIB_PATH
     hipcc = _hipcc()
-    build_engine()  # (the kernels' object file is the product's own: hwy_kernels.o)
+    # the kernels' object file is the product's own (hwy_kernels.o): rebuilt if the library is stale OR the object did not travel
+    # with it (*.o is git-ignored; a fresh .so without its objects would leave the link below without an input)
+    build_engine(force=not os.path.exists(os.path.join(CSRC, "hwy_kernels.o")))
     objs = []
     for src in SOURCES:
         if src == "hwy_kernels.hip":

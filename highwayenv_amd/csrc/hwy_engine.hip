@@ -293,10 +293,8 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     const int simds = (hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256) * 4;
     const long long waves = (long long)cfg->num_envs * ((cfg->num_vehicles + 63) / 64);
     eng->waves_per_eu = waves > 3LL * simds ? 4 : 3;
-    // 64 < N <= 128 with the Kinematics observation: ONE wavefront per environment, two vehicles per thread (hwy_wave2.h);
-    // its register-allocation variants are 1 .. 3 resident wavefronts per SIMD
-    if (cfg->num_vehicles > 64 && cfg->num_vehicles <= 128 && cfg->obs_type == HWY_OBS_KINEMATICS && !eng->force_block_kernel)
-      eng->waves_per_eu = cfg->num_envs > 2LL * simds ? 3 : 2;
+    // (64 < N <= 128 with the Kinematics observation runs the wide kernel, hwy_wave2.h: ONE build, <2, 2> -- 245 VGPRs, two
+    //  resident wavefronts per SIMD --, which this variable and hwy_config.tune_waves_per_eu do not select among)
   }
   if (cfg->tune_waves_per_eu >= 1 && cfg->tune_waves_per_eu <= 4) eng->waves_per_eu = cfg->tune_waves_per_eu;
   eng->rollout_waves_per_eu = eng->waves_per_eu;

@@ -257,7 +257,8 @@ typedef struct hwy_config {
   int32_t tune_block_kernel;           /* 1: run the generic workgroup kernel (hwy_device.h) even for N <= 128, where the default is one
                                           wavefront per environment (hwy_wave.h for N <= 64, hwy_wave2.h -- two vehicles per thread --
                                           for 64 < N <= 128 with the Kinematics observation) */
-  int32_t tune_waves_per_eu;           /* 1..4: register-allocation variant (resident wavefronts per SIMD) of the step kernel */
+  int32_t tune_waves_per_eu;           /* 1..4: register-allocation variant (resident wavefronts per SIMD) of the step kernel;
+                                          no effect where the wide kernel runs (64 < N <= 128, Kinematics: one build, hwy_wave2.h) */
   int32_t tune_ix_no_helpers;          /* 1: HWY_SCENARIO_INTERSECTION with N <= 32 runs 32-thread workgroups (no helper lanes) */
   int32_t tune_ix_no_prewarm;          /* 1: HWY_SCENARIO_INTERSECTION auto-resets run their warm-up frames inline */
   int32_t tune_extra_lds;              /* bytes of dynamic LDS per workgroup of the one-wavefront step kernel (<= 65536):

@@ -329,7 +329,7 @@ static double interval_distance(double min_a, double max_a, double min_b, double
  * orc_set_margin_buffer (hwy_oracle.c) hands out the per-slot minimum over the impacts assigned during a call. */
 static __thread double g_axis_dn = INFINITY;
 static __thread double g_flag_dn = INFINITY; /* smallest |interval distance| behind an intersecting / will_intersect decision */
-extern double *orc_margin_buf, *orc_flag_margin_buf;
+extern __thread double *orc_margin_buf, *orc_flag_margin_buf;
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {

@@ -368,3 +368,39 @@ def ix_oracle_state(h: dict, cfg) -> dict:
 def ix_oracle_config(cfg_dict: dict, cfg, num_envs: int):
     from oracle import oracle_ix
     return oracle_ix.config_from_engine(cfg_dict, cfg, num_envs)
+
+
+class OraclePool:
+    """The C oracle over ALL environments of a full-size batch: disjoint blocks of environments, one block per thread of a pool
+    (ctypes releases the GIL inside the C call; the oracle's diagnostic buffers are thread-local), so that the full-size parity
+    tests compare every environment of BASELINE configs 3 / 4 / 5 instead of a sample -- like bench.py's cpu_baseline leg steps the
+    same oracle on every host core.  ``make_cfg(n)`` builds the oracle's config for a block of n environments."""
+
+    def __init__(self, num_envs: int, make_cfg, threads: int | None = None):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        n = max(1, min(threads or (os.cpu_count() or 1), 64, num_envs))
+        edges = np.linspace(0, num_envs, n + 1).astype(int)
+        self.blocks = [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        self.cfgs = [make_cfg(b - a) for a, b in self.blocks]
+        self.pool = ThreadPoolExecutor(len(self.blocks))
+        self.num_envs = num_envs
+
+    def split(self, arrays: dict) -> list:
+        """[E, ...] arrays -> one contiguous copy per block (the oracle steps its block in place)."""
+        return [{k: np.ascontiguousarray(v[a:b]).copy() for k, v in arrays.items()} for a, b in self.blocks]
+
+    def run(self, fn, *per_block):
+        """fn(cfg_k, margins_k, *[x[k] for x in per_block]) on every block in parallel; the list of results in block order."""
+        from oracle import oracle
+
+        def one(k):
+            with oracle.impact_margins(self.cfgs[k]) as mg:
+                return fn(self.cfgs[k], mg, *[x[k] for x in per_block]), mg.margin.min(1), mg.flag_margin.min(1)
+        return list(self.pool.map(one, range(len(self.blocks))))
+
+    def rows(self, x):
+        return [x[a:b] for a, b in self.blocks]
+
+    def close(self):
+        self.pool.shutdown()

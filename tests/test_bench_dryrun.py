@@ -137,3 +137,27 @@ def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_eve
         assert terms == [1, 2]
     for rewards in r0["gathered_rewards"]:
         assert rewards[0] < 1000.0 <= rewards[1] < 2000.0
+
+
+@pytest.mark.parametrize("scaling,envs", [("weak", 1024), ("strong", 8192)])
+def test_eight_rank_bench_of_baseline_config_3_on_gloo(tmp_path, scaling, envs):
+    """The command DESIGN.md section 6 names for BASELINE config 3 (highway-v0, 8192 envs x 101 vehicles over 8 GPUs), at the
+    rank count it will meet: `--gpus 8 --workload v0_n100 --envs-per-gpu 1024` (weak: 1024 per rank) and `--scaling strong
+    --envs-per-gpu 8192` (the same 8 x 1024 as a remainder-free split of a fixed total), eight ranks on gloo with the stand-in
+    engine -- shard sizes, the packed gather of eight ranks' blocks into rank 0's buffer, the one JSON line (round-4 verdict item 7)."""
+    steps, warmup, repeats, world = 5, 2, 2, 8
+    argv = ["--gpus", str(world), "--workload", "v0_n100", "--steps", str(steps), "--warmup", str(warmup), "--repeats", str(repeats),
+            "--envs-per-gpu", str(envs), "--scaling", scaling, "--gather-every", "4", "--settle-ms", "0", "--no-cpu-baseline"]
+    res = _run(tmp_path, argv, world=world)
+    assert all(r["lines"] == [] for r in res[1:]) and len(res[0]["lines"]) == 1
+    line = res[0]["lines"][0]
+    assert [r["envs"] for r in res] == [1024] * world                       # every rank steps its 1024-environment shard
+    assert line["n_gpus"] == world and line["scaling"] == scaling and line["config"]["world_size_reported_by_the_process_group"] == world
+    assert line["config"]["envs_per_gpu"] == 1024 and line["config"]["vehicles_per_env"] == 101
+    assert line["value"] == pytest.approx(steps * 1024 * world / (line["ms_per_step"] * 1e-3 * steps), rel=1e-9)
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 1024 * (72 * 101 + 110)   # SURVEY 8d: 7,382 B per env-step
+    assert len({r["steps"] for r in res}) == 1                              # the ranks agree on the number of steps (collectives)
+    for terms in res[0]["gathered_term"]:
+        assert terms == list(range(1, world + 1))                           # rank r's block landed in slot r of the root's buffer
+    for rewards in res[0]["gathered_rewards"]:
+        assert all(1000.0 * r <= rewards[r] < 1000.0 * (r + 1) for r in range(world))

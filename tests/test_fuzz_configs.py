@@ -26,6 +26,8 @@ INTERSECTION_WHOLE_STEP_FLOOR = 0.33
 # consecutive frames; last-bit lane indices in a frame 0; lane flips in a whole step 0; queue-order cuts 3 in all, at most 2 in
 # a chunk.  The ceilings are those maxima plus a small margin (a resting pair may last a whole 15-frame step):
 EDGE_MAX, TOUCH_MAX, LANE_FRAMES_MAX, FLIP_MAX, CUT_MAX = 1, 15, 2, 2, 4
+# queue-order cuts among the end-of-step products of EVERY live env-step (queues included: that is where the cuts are)
+CUT_P_MAX = 2  # (0 in 144 chunks on the emulator)
 
 
 def random_config(rng):
@@ -184,13 +186,18 @@ def test_random_intersection_configurations_vs_oracle(chunk):
       are comparable between two arithmetics: no vehicle below 1 m/s (steering_control divides by not_zero(speed) twice, so
       last-bit differences grow 1e2..1e4 x per frame there -- at an intersection cars yield and queue, so this is the bulk of
       the exclusions), no lane-index knife edge, and -- steps WITH a collision are compared like any other -- no push on the
-      knife edge.  What this leaves out is covered by the first comparison, frame by frame."""
+      knife edge.  What this leaves out is covered by the first comparison, frame by frame;
+    * the END-OF-STEP PRODUCTS (observation, reward, terminated, truncated: observation.py:234-276 / :354-413, intersection_env.py:
+      70-134) of EVERY live env-step, slow and queueing ones included: the LAST frame of the teacher-forced sequence is run as one
+      policy step of a second engine / oracle pair configured with policy_frequency = simulation_frequency (one frame per step,
+      IDLE meta-action == no meta-action: controller.py:295-315) from the engine's state after the frame before it -- both sides
+      observe, reward and terminate on states that differ by one frame's rounding (1e-9), not by fifteen."""
     from oracle import oracle, oracle_ix
     from tests.backends import make_engine
     from tests.golden_util import KNIFE, assert_obs_close, ix_oracle_config, ix_oracle_state
     rng = np.random.default_rng(5000 + chunk)
     tot_steps = tot_checked = tot_frames = tot_col = tot_col_full = tot_img_cells = tot_edge = tot_touch = 0
-    tot_all_frames = tot_live_frames = tot_lane_frames = tot_flip = tot_cut = 0
+    tot_all_frames = tot_live_frames = tot_lane_frames = tot_flip = tot_cut = tot_prod = tot_cut_p = 0
     for k in range(4):
         cfg = random_intersection_config(rng)
         E = 12
@@ -200,6 +207,12 @@ def test_random_intersection_configurations_vs_oracle(chunk):
             dev, host = make_engine(BACKEND, c), make_engine(BACKEND, ch)
             oc = ix_oracle_config(dict(cfg, host_traffic=True), ch, E)
             T_frames = int(c.frames_per_step)
+            # one frame per policy step: the last frame of a step + its products from one state (docstring, third comparison)
+            cfg1 = dict(cfg, host_traffic=True, policy_frequency=cfg["simulation_frequency"])
+            c1 = _abi.make_config(cfg1, E, scenario="intersection")
+            assert int(c1.frames_per_step) == 1
+            host1, oc1 = make_engine(BACKEND, c1), ix_oracle_config(cfg1, c1, E)
+            idle = np.ones((E, c.num_agents), np.int32)
             dev.reset(base_seed=chunk * 1000 + k)
             dev.set_autoreset(True, base_seed=chunk * 1000 + k)
             checked = n_flip = n_cut = n_live = n_edge = 0
@@ -223,6 +236,43 @@ def test_random_intersection_configurations_vs_oracle(chunk):
                         oracle_ix.frames(oc, ost1, acts if fr == 0 else None, 1)
                     g1 = host.get_state()
                     fine = ~done_prev & (m1.margin.min(1) >= 1e-9)
+                    if fr == T_frames - 1:
+                        # -- end-of-step products of EVERY live env-step: this last frame as a one-frame policy step ------------
+                        host1.set_state(st_k)
+                        p_obs, p_rew, p_term, p_trunc, _ = host1.step(idle)
+                        ost_p = ix_oracle_state(st_k, c1)
+                        q_obs, _, q_term, q_trunc, q_info = oracle_ix.step(oc1, ost_p, idle)
+                        g_p = host1.get_state()
+                        # (a last-bit lane index changes the ego's lane coordinate the observation is ordered by, a knife-edge push
+                        #  the pose itself: the frame comparison below counts / excludes those, and so does this one)
+                        pres_p = (g_p["flags"] & _abi.F_ABSENT) == 0
+                        ok_p = fine & ~(pres_p & (g_p["lane"] != ost_p["lane"])).any(1)
+                        np.testing.assert_array_equal(p_term[ok_p], q_term[ok_p], err_msg=f"step {t}: terminated (products of every step)")
+                        np.testing.assert_array_equal(p_trunc[ok_p], q_trunc[ok_p], err_msg=f"step {t}: truncated (products of every step)")
+                        np.testing.assert_allclose(p_rew[ok_p], q_info["agents_rewards"][ok_p], rtol=0, atol=1e-9,
+                                                   err_msg=f"step {t}: reward (products of every step)")
+                        rows_p = lambda o: o.reshape(-1, *o.shape[-2:])  # noqa: E731
+                        if c.obs_type == _abi.OBS_KINEMATICS:
+                            ix_x, ix_y = feats.index("x"), feats.index("y")
+                            for hq, oq in zip(rows_p(p_obs[ok_p]).astype(np.float64), rows_p(q_obs[ok_p]).astype(np.float64)):
+                                if np.abs(hq - oq).max() <= 1e-6 or _unmatched_rows(hq, oq) == 0:
+                                    continue
+                                # (the queue-order knife edge of the whole-step comparison below, same rule, its own counter)
+                                seen = oq[oq[:, 0] > 0]
+                                queued = any((np.abs(seen[:, col][:, None] - seen[:, col][None, :]) < 1e-4).sum() > len(seen)
+                                             for col in (ix_x, ix_y))
+                                if not queued:
+                                    only_h, only_o = _unmatched_rows(hq, oq, rows=True)
+                                    queued = len(only_h) == len(only_o) and all(
+                                        any(min(abs(a[ix_x] - b[ix_x]), abs(a[ix_y] - b[ix_y])) < 1e-6 for b in only_o) for a in only_h)
+                                assert queued, f"step {t} (products of every step): {hq} != {oq}"
+                                tot_cut_p += 1
+                            np.testing.assert_allclose(rows_p(p_obs[ok_p])[:, 0], rows_p(q_obs[ok_p])[:, 0], rtol=0, atol=1e-6,
+                                                       err_msg=f"step {t}: ego row (products of every step)")
+                        else:
+                            image = bool(c.flags & _abi.C_GRID_IMAGE)
+                            assert_obs_close(p_obs[ok_p].reshape(q_obs[ok_p].shape), q_obs[ok_p], image, f"step {t} (products of every step)")
+                        tot_prod += int(ok_p.sum())
                     for f in ("x", "y", "heading", "speed"):
                         np.testing.assert_allclose(g1[f][fine], ost1[f][fine], rtol=0, atol=1e-9, err_msg=f"step {t} frame {fr}: {f}")
                     # two wrecks resting EXACTLY touching (flag_margin < KNIFE: the `will_intersect` of that pair hinges on a distance
@@ -354,13 +404,15 @@ def test_random_intersection_configurations_vs_oracle(chunk):
             tot_col_full -= n_edge
             tot_steps += n_live
             tot_checked += checked
-            for e_ in (dev, host):
+            for e_ in (dev, host, host1):
                 e_.close()
         except AssertionError as ex:
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
     frac = tot_checked / max(tot_steps, 1)
     print(f"\nintersection fuzz chunk {chunk}: {tot_steps} live env-steps = {tot_live_frames} frames; teacher-forced frames compared at "
-          f"1e-9: {tot_all_frames} ({100.0 * tot_all_frames / max(tot_live_frames, 1):.2f} %; first frames {tot_frames}); whole step on "
+          f"1e-9: {tot_all_frames} ({100.0 * tot_all_frames / max(tot_live_frames, 1):.2f} %; first frames {tot_frames}); end-of-step "
+          f"products (obs, reward, flags) on {tot_prod} env-steps ({100.0 * tot_prod / max(tot_steps, 1):.2f} %, {tot_cut_p} queue-order "
+          f"cuts); whole step on "
           f"{tot_checked} ({100.0 * frac:.1f} %); {tot_col} fast-enough steps with a wreck, {tot_col_full} of them in full; "
           f"as_image cells off by one: {tot_img_cells}; tolerated and counted: {tot_edge} env-steps diverged on a touching pair's knife "
           f"edge, {tot_touch} pending-impact bits of exactly touching wrecks, {tot_lane_frames} frames with a last-bit lane index, "
@@ -371,5 +423,8 @@ def test_random_intersection_configurations_vs_oracle(chunk):
         assert tot_edge <= EDGE_MAX and tot_touch <= TOUCH_MAX and tot_lane_frames <= LANE_FRAMES_MAX, (tot_edge, tot_touch, tot_lane_frames)
         assert tot_flip <= FLIP_MAX and tot_cut <= CUT_MAX, (tot_flip, tot_cut)
     assert tot_all_frames >= 0.985 * tot_live_frames, "the teacher-forced comparison must cover (nearly) every live frame"
+    assert tot_prod >= 0.97 * tot_steps, "the end-of-step products must be compared on (nearly) every live env-step"
+    if os.environ.get("HWY_FUZZ_CALIBRATE") != "1":
+        assert tot_cut_p <= CUT_P_MAX, tot_cut_p
     assert frac >= INTERSECTION_WHOLE_STEP_FLOOR, f"only {100 * frac:.1f} % of the env-steps were compared as whole steps"
     assert tot_col_full >= 0.9 * tot_col - 1
