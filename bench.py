@@ -130,7 +130,7 @@ def wide_kernel_runs(n_vehicles: int, tune=None) -> bool:
     observes Kinematics there): 64 < N <= 128 runs one wavefront per environment with two vehicles per thread (hwy_wave2.h) unless
     `--tune block_kernel=1` asks for the workgroup kernel."""
     tune = TUNE_IN_EFFECT if tune is None else tune
-    return 64 < n_vehicles <= 128 and not int(tune.get("block_kernel", 0))
+    return 64 < n_vehicles <= 256 and not int(tune.get("block_kernel", 0))
 
 
 TUNE_IN_EFFECT = {}  # (--tune KEY=VALUE of this run, set by main)
@@ -325,6 +325,8 @@ def workload_config(workload: str):
         cfg_dict = _abi.highway_default_config()
         if workload == "v0_n100":
             cfg_dict.update({"vehicles_count": 100})
+        elif workload == "v0_n200":  # beyond BASELINE's configurations: the N > 128 path (four vehicles per thread, round 5)
+            cfg_dict.update({"vehicles_count": 200})
     return cfg_dict, fast, scenario
 
 
@@ -457,7 +459,7 @@ def main(argv=None, platform=None, emit=None):
     ap.add_argument("--gather-every", type=int, default=16,
                     help="N > 1: the (obs, reward, done) blocks of this many consecutive steps travel to rank 0 in one RCCL "
                          "gather (every step's outputs still reach rank 0 inside the timed region); 1 = one gather per step")
-    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "merge_ma4", "merge", "intersection", "intersection_kin"], default="fast",
+    ap.add_argument("--workload", choices=["fast", "v0", "v0_n100", "v0_n200", "merge_ma4", "merge", "intersection", "intersection_kin"], default="fast",
                     help="fast = BASELINE config 2 (the headline metric); v0_n100 = the per-GPU shard of config 3 "
                          "(highway-v0, 101 vehicles, 15 frames/step, full pairwise collisions; use --envs-per-gpu 1024); "
                          "merge_ma4 = BASELINE config 5 (merge-generic, 4 lanes, 40 traffic vehicles, 4 controlled agents "
@@ -811,7 +813,7 @@ def main(argv=None, platform=None, emit=None):
                                     "hwy_net_step_kernel  (one 64-wide wavefront per env)" if scenario != "highway" else
                                     f"hwy_step_wave_kernel<WPE,{str(not fast).lower()}>  (one 64-wide wavefront per env; every WPE variant is the same "
                                     "102 / 128-VGPR code)" if N <= 64 else
-                                    "hwy_step_wide_kernel<2,2>  (one 64-wide wavefront per env, two vehicles per thread)" if wide_kernel_runs(N) else
+                                    f"hwy_step_wide_kernel<{(N + 63) // 64},{2 if N <= 128 else 1}>  (one 64-wide wavefront per env, {(N + 63) // 64} vehicles per thread)" if wide_kernel_runs(N) else
                                     f"hwy_step_kernel<{(N + 63) // 64},WPE>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
                          "avg_kernel_us_method": ("mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's own "
                                                   "timestamps (unclamped)" if event_kernel_s else "wall ms_per_step (no events)"),

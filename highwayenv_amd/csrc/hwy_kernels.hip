@@ -75,19 +75,30 @@ static hipError_t launch_rollout_wpe(const StepParams &p, int num_envs, hipStrea
     HWY_LAUNCH((hwy_rollout_wave_kernel<WPE, true>), dim3(num_envs), dim3(64), lds, stream, p);
   return hipGetLastError();
 }
-// 64 < N <= 128 with the Kinematics observation: ONE wavefront per environment, two vehicles per thread (hwy_wave2.h)
+// 64 < N <= 256 with the Kinematics observation: ONE wavefront per environment, ceil(N / 64) vehicles per thread (hwy_wave2.h).
+// Two per thread (BASELINE config 3's N = 101): 245 VGPRs, 15.7 KB of LDS, two resident wavefronts per SIMD.  Three / four per thread
+// (N <= 192 / 256; round 5): 338 / 436 VGPRs without a spill, 23 / 30 KB of LDS, ONE wavefront per SIMD -- the same source, bit-identical
+// to the workgroup kernel (tests/test_wide_kernel.py); the workgroup kernel (hwy_device.h) remains for the OccupancyGrid observation
+// with N > 64 and behind hwy_config.tune_block_kernel.
 bool wide_kernel_applies(const StepParams &p, bool force_block_kernel) {
-  return p.N > 64 && p.N <= 128 && p.obs_type == HWY_OBS_KINEMATICS && !force_block_kernel;
+  return p.N > 64 && p.N <= 256 && p.obs_type == HWY_OBS_KINEMATICS && !force_block_kernel;
 }
-// (one register-allocation variant: 177 VGPRs whatever the bound, and 18.7 KB of LDS per one-wavefront workgroup allow two per SIMD)
 static hipError_t launch_wide(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
-  (void)waves_per_eu;
-  HWY_LAUNCH((hwy_step_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p);
+  (void)waves_per_eu;  // (one register-allocation variant per K)
+  switch (waves_for(p.N)) {
+    case 2: HWY_LAUNCH((hwy_step_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 3: HWY_LAUNCH((hwy_step_wide_kernel<3, 1>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    default: HWY_LAUNCH((hwy_step_wide_kernel<4, 1>), dim3(num_envs), dim3(64), 0, stream, p); break;
+  }
   return hipGetLastError();
 }
 static hipError_t launch_wide_rollout(const StepParams &p, int num_envs, hipStream_t stream, int waves_per_eu) {
   (void)waves_per_eu;
-  HWY_LAUNCH((hwy_rollout_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p);
+  switch (waves_for(p.N)) {
+    case 2: HWY_LAUNCH((hwy_rollout_wide_kernel<2, 2>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    case 3: HWY_LAUNCH((hwy_rollout_wide_kernel<3, 1>), dim3(num_envs), dim3(64), 0, stream, p); break;
+    default: HWY_LAUNCH((hwy_rollout_wide_kernel<4, 1>), dim3(num_envs), dim3(64), 0, stream, p); break;
+  }
   return hipGetLastError();
 }
 // hwy_rollout_device on the straight-road kernels: p.k_steps policy steps in one launch -- the one-wavefront kernel for N <= 64,

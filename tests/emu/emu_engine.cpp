@@ -158,16 +158,19 @@ void dispatch(Which which, const StepParams &p, int E) {
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
     return;
   }
-  if (which == STEP && nw == 2 && p.obs_type == HWY_OBS_KINEMATICS && !g_force_block && !g_cfg->tune_block_kernel) {
-    // same dispatch rule as hwy_kernels.hip (wide_kernel_applies): one wavefront per environment, two vehicles per thread
-    if (g_k_steps > 0) {
-      StepParams pk = p;
-      pk.k_steps = g_k_steps;
-      pk.num_envs = E;
-      emu::launch([](const StepParams &q) { hwy::hwy_rollout_wide_kernel<2, 1>(q); }, E, 64, pk);
-      return;
+  if (which == STEP && nw >= 2 && nw <= 4 && p.obs_type == HWY_OBS_KINEMATICS && !g_force_block && !g_cfg->tune_block_kernel) {
+    // same dispatch rule as hwy_kernels.hip (wide_kernel_applies): one wavefront per environment, nw vehicles per thread
+#define RUN_WIDE(KV)                                                                                           \
+    if (g_k_steps > 0) {                                                                                       \
+      StepParams pk = p;                                                                                       \
+      pk.k_steps = g_k_steps;                                                                                  \
+      pk.num_envs = E;                                                                                         \
+      emu::launch([](const StepParams &q) { hwy::hwy_rollout_wide_kernel<KV, 1>(q); }, E, 64, pk);             \
+    } else {                                                                                                   \
+      emu::launch([](const StepParams &q) { hwy::hwy_step_wide_kernel<KV, 1>(q); }, E, 64, p);                 \
     }
-    emu::launch([](const StepParams &q) { hwy::hwy_step_wide_kernel<2, 1>(q); }, E, 64, p);
+    if (nw == 2) { RUN_WIDE(2) } else if (nw == 3) { RUN_WIDE(3) } else { RUN_WIDE(4) }
+#undef RUN_WIDE
     return;
   }
 #define RUN(NW)                                                                                         \

@@ -80,15 +80,18 @@ def test_random_configurations_vs_oracle(chunk):
 
 @pytest.mark.parametrize("chunk", CHUNKS)  # 4 configurations each
 def test_random_wide_configurations_vs_oracle(chunk):
-    """The same family with 63 .. 127 other vehicles: the traffic sizes of the two-vehicles-per-thread kernel (csrc/hwy_wave2.h;
-    the OccupancyGrid draws of the family run the workgroup kernel there)."""
+    """The same family with 63 .. 127 other vehicles -- the traffic sizes of the two-vehicles-per-thread kernel (csrc/hwy_wave2.h; the
+    OccupancyGrid draws of the family run the workgroup kernel there) -- and, fourth configuration of every chunk, 128 .. 255: three
+    and four vehicles per thread, the N > 128 path since round 5."""
     rng = np.random.default_rng(19000 + chunk)
     for k in range(4):
         cfg, fast = random_config(rng)
         agents = cfg["controlled_vehicles"]
         cfg["vehicles_count"] = int(rng.integers(64 - agents, 129 - agents))
+        if k == 3:
+            cfg["vehicles_count"] = int(np.random.default_rng(23000 + chunk).integers(129 - agents, 257 - agents))
         try:
-            rollout(BACKEND, cfg, fast, E=4, steps=6, seed=chunk * 100 + k)
+            rollout(BACKEND, cfg, fast, E=4 if k < 3 else 2, steps=6 if k < 3 else 4, seed=chunk * 100 + k)
         except AssertionError as ex:  # name the configuration in the failure
             raise AssertionError(f"chunk {chunk} config {k}: {cfg}\n{ex}") from ex
 

@@ -91,3 +91,9 @@ def test_wide_kernel_allocation(res):
         assert waves_per_simd(r["vgpr"]) >= 2, r
         assert 8 * r["lds"] <= LDS_PER_CU, r
         assert r["workgroup"] == 64
+        # three / four vehicles per thread (128 < N <= 192 / 256, round 5): the N > 128 path holds NO spilled VGPR either (the
+        # workgroup kernel it replaced there carried 16-32 in its 4-wave builds), one wavefront per SIMD, LDS for four per CU
+        for k in (3, 4):
+            r = res[f"hwy::{fam}<{k}, 1>"]
+            assert r["vgpr_spill"] == 0 and r["vgpr"] <= 512 and r["workgroup"] == 64, r
+            assert 4 * r["lds"] <= LDS_PER_CU, r

@@ -1,5 +1,6 @@
-"""The two-vehicles-per-thread one-wavefront kernel (highwayenv_amd/csrc/hwy_wave2.h: 64 < N <= 128, BASELINE config 3's
-N = 101) against the workgroup kernel it replaces there (hwy_device.h, `tuning.block_kernel`) and against the C oracle.
+"""The K-vehicles-per-thread one-wavefront kernel (highwayenv_amd/csrc/hwy_wave2.h: K = 2 for 64 < N <= 128, BASELINE config 3's
+N = 101; K = 3 / 4 for N <= 192 / 256 since round 5) against the workgroup kernel it replaces there (hwy_device.h,
+`tuning.block_kernel`) and against the C oracle.
 
 Both kernels call the same per-vehicle device functions on the same source expressions, so the comparison between them is
 BIT FOR BIT (state planes, rewards, flags; observations to an f64 ulp before their rounding to f32) -- across free-running episodes with device auto-resets, the
@@ -38,6 +39,12 @@ CASES = [
     pytest.param({"vehicles_count": 127, "lanes_count": 5, "vehicles_density": 2.0}, False, (1, 32), (2, 12), id="v0_n128_dense"),
     pytest.param({"vehicles_count": 64, "lanes_count": 2, "vehicles_density": 2.5, "duration": 5}, True, (2, 64), (6, 30),
                  id="fast_n65_two_lanes"),
+    # three / four vehicles per thread: the N > 128 path (round 5)
+    pytest.param({"vehicles_count": 150, "lanes_count": 4}, False, (2, 48), (3, 20), id="v0_n151_three_per_thread"),
+    pytest.param({"vehicles_count": 200, "lanes_count": 5, "vehicles_density": 1.5, "duration": 8}, False, (1, 32), (3, 16), id="v0_n201_four_per_thread"),
+    pytest.param({"vehicles_count": 253, "controlled_vehicles": 3, "lanes_count": 6, "vehicles_density": 2.0, "duration": 6}, False, (1, 24), (2, 12),
+                 id="v0_n256_three_agents"),
+    pytest.param({"vehicles_count": 140, "lanes_count": 3, "duration": 5}, True, (2, 48), (7, 30), id="fast_n141_ego_only"),
 ]
 
 
