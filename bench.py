@@ -128,9 +128,11 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
 def wide_kernel_runs(n_vehicles: int, tune=None) -> bool:
     """The engine's dispatch rule for the straight-road scenarios (csrc/hwy_kernels.hip: wide_kernel_applies; every bench workload
     observes Kinematics there): 64 < N <= 128 runs one wavefront per environment with two vehicles per thread (hwy_wave2.h) unless
-    `--tune block_kernel=1` asks for the workgroup kernel."""
+    `--tune block_kernel=1` asks for the workgroup kernel; 128 < N <= 256 runs the workgroup kernel unless `--tune block_kernel=2` asks
+    for three / four vehicles per thread."""
     tune = TUNE_IN_EFFECT if tune is None else tune
-    return 64 < n_vehicles <= 256 and not int(tune.get("block_kernel", 0))
+    bk = int(tune.get("block_kernel", 0))
+    return (64 < n_vehicles <= 128 and bk != 1) or (128 < n_vehicles <= 256 and bk == 2)
 
 
 TUNE_IN_EFFECT = {}  # (--tune KEY=VALUE of this run, set by main)

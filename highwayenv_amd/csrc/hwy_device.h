@@ -841,24 +841,42 @@ __device__ inline void load_vehicle(const StepParams &p, int e, Veh &o) { load_v
 // written back (HWY_CTR_NONFINITE_STORES, hwy_get_counters) -- the simulation has no operation that recovers from a NaN (it spreads
 // through the neighbour gaps to the whole lane), so a nonzero count says the state handed to hwy_set_state, or a kernel, is broken.
 // x - x is 0 for every finite x and NaN for +-inf and NaN: one compare per thread, one ballot, an atomic only on the broken path.
+#ifndef HWY_PIN_POINTERS
+#define HWY_PIN_POINTERS(a, b) asm volatile("" : "+s"(a), "+s"(b))   // both are in SGPRs here (the emulator defines it away)
+#define HWY_GLOBAL_F64 __attribute__((address_space(1))) double        // (a pointer into global memory stays one through the asm: no flat_store)
+#endif
 __device__ inline void count_nonfinite(unsigned long long *counters, bool bad) {
   const unsigned long long m = __ballot(bad);
   if (m && counters && (threadIdx.x & 63) == 0) atomicAdd(&counters[HWY_CTR_NONFINITE_STORES], (unsigned long long)__popcll(m));
 }
 __device__ inline void store_vehicle_at(const StepParams &p, int e, int i, const Veh &o, bool full = true) {
+  // The stores below are the last thing a wavefront does, and a wavefront waits for its outstanding stores (s_waitcnt vmcnt) before
+  // it may overwrite a register one of them still reads: everything that computes -- the NaN guard's predicate, the packed word,
+  // the plane pointers -- comes FIRST, so that nothing but the stores and scalar bookkeeping is left between the first store and
+  // s_endpgm (the round-4 order -- stores, then the guard's four subtractions in the registers the stores had just been fed from --
+  // parked every wavefront for a memory round trip at its very end).
+  const bool bad = i < p.N && !((o.x - o.x) + (o.y - o.y) + (o.h - o.h) + (o.v - o.v) == 0.0);
+  const unsigned long long bad_m = __ballot(bad);
   if (i < p.N) {
     const size_t k = (size_t)e * p.pitch + i;
+    const int32_t word = pack_word(o.lane, o.tgt, o.sidx, o.flags, o.rank);
+    // (the two plane pointers as VALUES before the predicated stores: the optimiser merges the two stores into one with a per-lane
+    //  choice of the destination, and -- when `p` is the re-read view of the kernel arguments, HWY_RELOAD_PARAMS -- made that choice
+    //  by LOADING the pointer from the argument segment with a per-lane address: one more round trip before the wavefront retires)
+    HWY_GLOBAL_F64 *timer_plane = (HWY_GLOBAL_F64 *)p.st.timer, *ts_plane = (HWY_GLOBAL_F64 *)p.st.target_speed;
+    HWY_PIN_POINTERS(timer_plane, ts_plane);
     p.st.x[k] = o.x; p.st.y[k] = o.y; p.st.heading[k] = o.h; p.st.speed[k] = o.v;
-    p.st.packed[k] = pack_word(o.lane, o.tgt, o.sidx, o.flags, o.rank);
-    if (full || !(o.flags & HWY_F_CONTROLLED)) p.st.timer[k] = o.timer;
-    if (full || (o.flags & HWY_F_CONTROLLED)) p.st.target_speed[k] = o.ts;
+    p.st.packed[k] = word;
+    if (full || !(o.flags & HWY_F_CONTROLLED)) timer_plane[k] = o.timer;
+    if (full || (o.flags & HWY_F_CONTROLLED)) ts_plane[k] = o.ts;
     if (full) p.st.delta[k] = o.delta;
     if (full || (o.flags & HWY_F_HAS_IMPACT)) {
       p.st.impact_x[k] = o.impx;
       p.st.impact_y[k] = o.impy;
     }
   }
-  count_nonfinite(p.counters, i < p.N && !((o.x - o.x) + (o.y - o.y) + (o.h - o.h) + (o.v - o.v) == 0.0));
+  if (bad_m && p.counters && (threadIdx.x & 63) == 0)
+    atomicAdd(&p.counters[HWY_CTR_NONFINITE_STORES], (unsigned long long)__popcll(bad_m));
 }
 template <int NW>
 __device__ inline void store_vehicle(const StepParams &p, int e, const Veh &o, bool full = true) {

@@ -130,6 +130,7 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->tune_extra_lds < 0 || c->tune_extra_lds > 65536) BAD("tune_extra_lds must be in [0,65536]");
   if (c->tune_ix_prewarm_frames < 0) BAD("tune_ix_prewarm_frames must be >= 0");
   if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
+  if (c->tune_block_kernel < 0 || c->tune_block_kernel > 2) BAD("tune_block_kernel must be 0 (engine's choice), 1 (workgroup kernel) or 2 (one-wavefront kernels)");
   if (c->tune_prio_shift < -1 || c->tune_prio_shift > 30) BAD("tune_prio_shift must be in [-1,30] (a shift of the 64-bit clock)");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
   if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");
@@ -275,7 +276,10 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
   eng->cfg = *cfg;
   eng->device = device;
   eng->pitch = (cfg->num_vehicles + 7) & ~7;  // 64-byte aligned rows of f64
-  eng->force_block_kernel = cfg->tune_block_kernel != 0;
+  // 0 = the engine's choice: the wide kernel (hwy_wave2.h) for 64 < N <= 128, the workgroup kernel beyond -- three / four vehicles
+  // per thread are one 338 / 442-VGPR wavefront per SIMD and measured slower there (1024 x 201: 312 us against 240,
+  // profiles/r05_history.md); 1 = the workgroup kernel wherever it exists; 2 = the wide kernel wherever it exists (N <= 256)
+  eng->force_block_kernel = cfg->tune_block_kernel == 1 || (cfg->tune_block_kernel == 0 && cfg->num_vehicles > 128);
   // road-network kernel: 128 VGPRs, 4 waves/SIMD, no spills.
   // intersection kernel with helper lanes (N <= 32, hwy_ix.h): 150 VGPRs, but 20.2 KB of LDS per one-wavefront workgroup keep it
   // at 2 per SIMD.  Without them (N > 32, or tune_ix_no_helpers): 128 VGPRs / 16.7 KB (2048 x 30: 371.9 us against 285.1)

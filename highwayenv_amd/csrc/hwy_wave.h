@@ -43,6 +43,33 @@ __device__ inline int wave_send_i(int v, int dst) { return __builtin_amdgcn_ds_p
   const StepParams &q = *(const StepParams *)kernarg_
 #endif
 
+// The five values are in registers here: every load that produces one of them has been ISSUED above this point (and is waited for
+// here, together), whatever branches follow -- the compiler may neither sink such a load into the block that uses it nor hoist the
+// branch's own load above them.
+#ifndef HWY_ISSUED_TOGETHER
+#define HWY_ISSUED_TOGETHER(a, b, c, d, e_) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e_))
+#endif
+
+// The kernel-argument segment (StepParams: ~760 bytes, a dozen cache lines, freshly written by the host for every dispatch) is read
+// on demand by scalar loads scattered over the prologue, each followed by its own wait: a chain of four or five cache misses in a
+// row before the first vehicle plane is even requested -- and every wavefront of the launch walks it at the same moment.  One dword
+// of every line, requested back to back and waited for once, turns the chain into a single miss; the loads that follow hit the
+// scalar cache.  Measured (profiles/r05_history.md): headline 41.3 -> 40.7 us with it; NOT for the road-network / intersection
+// kernels, whose argument structs are 2-3 x larger (lane table, route table): touching them whole cost +2 us, their first 760 bytes
+// nothing either way.
+#if defined(HWY_NO_KERNARG_TOUCH) && !defined(HWY_KERNARG_TOUCH)
+#define HWY_KERNARG_TOUCH(T) ((void)0)
+#endif
+#ifndef HWY_KERNARG_TOUCH
+#define HWY_KERNARG_TOUCH(T)                                                                              \
+  do {                                                                                                    \
+    const unsigned *ka_ = (const unsigned *)__builtin_amdgcn_kernarg_segment_ptr();                       \
+    unsigned acc_ = 0;                                                                                    \
+    _Pragma("unroll") for (unsigned o_ = 0; o_ < sizeof(T); o_ += 64) acc_ ^= ka_[o_ / 4];               \
+    asm volatile("" : : "s"(acc_));                                                                       \
+  } while (0)
+#endif
+
 // One wavefront == one workgroup: LDS instructions of a wavefront execute in order, so a ds_read issued after a ds_write
 // of the same wavefront sees it without any wait or s_barrier.  Only the COMPILER must keep the order (and the CPU
 // emulation of tests/emu, whose 64 threads are separate fibers, needs a real rendezvous).
@@ -154,8 +181,11 @@ __device__ inline void wave_update_rank(double x, bool active, int N, int &rank,
 // BY_RANK: `rank` is the exact rank along the road of every vehicle (wave_update_rank on the CURRENT positions).
 // eo: the row of the output planes (obs, reward, flags, info) this environment writes -- e, or k * num_envs + e for step k of a
 // multi-step launch (hwy_rollout_device).
+// env_time: the environment's clock at the start of the step (requested with the state by the caller: a load here, at the end of
+// the wavefront's life, is a round trip nothing hides); only read when write_reward is set
 template <bool BY_RANK>
-__device__ inline void observe_wave(const StepParams &p, int e, int eo, const Veh &me, bool write_reward, int rank = 0) {
+__device__ inline void observe_wave(const StepParams &p, int e, int eo, const Veh &me, bool write_reward, int rank = 0,
+                                    double env_time = 0.0) {
   typedef EnvBlock<1> B;
   const int i = threadIdx.x;
   const bool active = i < p.N;
@@ -265,7 +295,7 @@ __device__ inline void observe_wave(const StepParams &p, int e, int eo, const Ve
       if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = crashed ? 1 : 0;
       if (a == 0) {
         const bool term = crashed || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
-        const double t = p.st.time[e] + p.policy_dt;
+        const double t = env_time + p.policy_dt;
         const bool trunc = t >= p.duration;
         p.st.time[e] = t;
         p.terminated[eo] = term ? 1 : 0;
@@ -288,9 +318,20 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
   const int N = p.N;
   const bool active = i < N;
 
+  // Everything the step needs from HBM is requested BEFORE anything is waited for: the environment's done flag and clock, the
+  // meta-actions (lane a fetches agent a's) and the vehicle's planes -- one round trip instead of three (flag -> state; the clock
+  // at the end of the step, where the wavefront could not retire before it came back).  All wavefronts of a launch start together,
+  // so nothing else hides these latencies.  An environment that is re-spawned instead (7 % of the steady state) has fetched its
+  // old state for nothing.
+  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;
+  double env_time = p.st.time[e];
+  int act_lane = (p.actions && i < p.A) ? p.actions[(size_t)eo * p.A + i] : HWY_IDLE;
+  Veh me;
+  load_vehicle<1>(p, e, me);
+  HWY_ISSUED_TOGETHER(done_flag, env_time, act_lane, me.x, me.timer);  // (keeps the requests above the branch)
   // ---- auto-reset: re-spawn instead of stepping (rare; shares the generic helpers) -------------
-  if (p.autoreset && p.st.done[e]) {
-    Veh me = Veh{};
+  if (done_flag) {
+    me = Veh{};
     const uint32_t episode = p.st.episode[e] + 1u;
     spawn_env<1>(p, sh.x, sh.v, e, p.rp.base_seed + (uint64_t)e, episode, me);
     observe_wave<false>(p, e, eo, me, false);
@@ -315,10 +356,6 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
 
   WaveTurn turn;
   wave_turn_init(turn, p.prio_shift);
-  // the meta-actions are requested BEFORE the state (lane a fetches agent a's): one HBM round trip instead of two
-  const int act_lane = (p.actions && i < p.A) ? p.actions[(size_t)eo * p.A + i] : HWY_IDLE;
-  Veh me;
-  load_vehicle<1>(p, e, me);
   const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
   const bool idm = active && !controlled;
   int agent = 0, act0 = HWY_IDLE;
@@ -724,10 +761,9 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
   // again from the kernel-argument segment, through a pointer the compiler cannot see through, instead of
   // keeping them live -- i.e. spilled to VGPR lanes and re-read with v_readlane -- across the frame loop.
   HWY_RELOAD_PARAMS(q, p);
-  if (q.full_step) {
-    wave_update_rank(me.x, active, N, rank, has_tie);  // positions moved in the last frame
-    observe_wave<true>(q, e, eo, me, true, rank);
-  }
+  if (q.full_step) wave_update_rank(me.x, active, N, rank, has_tie);  // positions moved in the last frame
+  // (state stores before or after the observation: 40.8 / 40.6 us, within the noise -- profiles/r05_history.md)
+  if (q.full_step) observe_wave<true>(q, e, eo, me, true, rank, env_time);
   me.rank = rank;
   me.timer = sh.timer[i]; me.ts = sh.ts[i]; me.delta = sh.delta[i]; me.impx = sh.impx[i]; me.impy = sh.impy[i];
   store_vehicle<1>(q, e, me, false);
@@ -738,6 +774,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
   __shared__ WaveShared sh;
   // which environment a workgroup steps is free (environments are independent): the dispatcher places workgroup b on the same
   // SIMD launch after launch, so a table b -> environment is a PLACEMENT of the environments on the SIMDs (hwy_set_block_order)
+  HWY_KERNARG_TOUCH(StepParams);
   const int e = p.block_env ? (int)p.block_env[blockIdx.x] : (int)blockIdx.x;
   wave_policy_step<FULL_SCAN>(p, sh, e, e);
 }
@@ -751,6 +788,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wave_kernel(const StepParams
 template <int WPE, bool FULL_SCAN>
 __global__ void __launch_bounds__(64, WPE) hwy_rollout_wave_kernel(const StepParams p) {
   __shared__ WaveShared sh;
+  HWY_KERNARG_TOUCH(StepParams);
   const int e = blockIdx.x;
   for (int k = 0; k < p.k_steps; ++k) {  // wave-uniform
     // a fresh, opaque view of the kernel arguments per step: nothing of a step's parameter set (or what was derived from it)

@@ -289,7 +289,7 @@ __device__ inline void wide_update_rank(WideShared<K> &sh, const Veh (&me)[K], i
 // the OccupancyGrid observation of N > 64 stays on the workgroup kernel).
 template <int K, bool BY_RANK>
 __device__ inline void observe_wide(const StepParams &p, WideShared<K> &sh, int e, int eo, const Veh (&me)[K], bool write_reward,
-                                    const int (&rank)[K]) {
+                                    const int (&rank)[K], double env_time = 0.0) {  // env_time: the clock at the start of the step
   const int l = threadIdx.x;
   const int V = p.V, F = p.F, N = p.N;
   for (int a = 0; a < p.A; ++a) {
@@ -420,7 +420,7 @@ __device__ inline void observe_wide(const StepParams &p, WideShared<K> &sh, int 
         if (p.info_crashed) p.info_crashed[(size_t)eo * p.A + a] = crashed ? 1 : 0;
         if (a == 0) {
           const bool term = crashed || ((p.flags & HWY_C_OFFROAD_TERMINAL) && !on_road);
-          const double t = p.st.time[e] + p.policy_dt;
+          const double t = env_time + p.policy_dt;  // (the clock was requested with the state: hwy_wave.h)
           const bool trunc = t >= p.duration;
           p.st.time[e] = t;
           p.terminated[eo] = term ? 1 : 0;
@@ -444,15 +444,22 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
 #pragma unroll
   for (int h = 0; h < K; ++h) { vi[h] = h * 64 + l; active[h] = vi[h] < N; }
 
+  // everything the step needs from HBM is requested before anything is waited for (hwy_wave.h: one round trip instead of three)
+  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;
+  double env_time = p.st.time[e];
+  int act_lane = (p.actions && l < p.A) ? p.actions[(size_t)eo * p.A + l] : HWY_IDLE;
+  Veh me[K];
+#pragma unroll
+  for (int h = 0; h < K; ++h) load_vehicle_at(p, e, vi[h], me[h]);
+  HWY_ISSUED_TOGETHER(done_flag, env_time, act_lane, me[0].x, me[K - 1].timer);
   // ---- auto-reset: re-spawn instead of stepping ---------------------------------------------------------------
-  if (p.autoreset && p.st.done[e]) {
-    Veh me[K];
+  if (done_flag) {
     const uint32_t episode = p.st.episode[e] + 1u;
     const uint64_t seed = p.rp.base_seed + (uint64_t)e;
     SpawnDraw d[K];
 #pragma unroll
     for (int h = 0; h < K; ++h) {
-      me[h] = Veh{};
+      me[h] = Veh{};  // (the old state was fetched for nothing)
       d[h] = spawn_draw(p, vi[h], seed, episode);
       if (active[h]) sh.x[vi[h]] = d[h].step;
       if (active[h] && vi[h] == 0) sh.scratch_base[0] = 3 * d[h].offset;  // first vehicle starts from 3*offset
@@ -492,15 +499,11 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
     return;
   }
 
-  // the meta-actions are requested BEFORE the state (lane a fetches agent a's)
-  const int act_lane = (p.actions && l < p.A) ? p.actions[(size_t)eo * p.A + l] : HWY_IDLE;
-  Veh me[K];
   bool controlled[K], idm[K], i_check[K];
   int act0[K], rank[K];
   u64 chk[K];
 #pragma unroll
   for (int h = 0; h < K; ++h) {
-    load_vehicle_at(p, e, vi[h], me[h]);
     controlled[h] = active[h] && (me[h].flags & HWY_F_CONTROLLED);
     idm[h] = active[h] && !controlled[h];
     act0[h] = HWY_IDLE;
@@ -1115,7 +1118,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
   HWY_RELOAD_PARAMS(q, p);
   if (q.full_step) {
     wide_update_rank<K>(sh, me, N, rank, has_tie);  // positions moved in the last frame
-    observe_wide<K, true>(q, sh, e, eo, me, true, rank);
+    observe_wide<K, true>(q, sh, e, eo, me, true, rank, env_time);
   }
 #pragma unroll
   for (int h = 0; h < K; ++h) {
@@ -1128,6 +1131,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
 template <int K, int WPE>
 __global__ void __launch_bounds__(64, WPE) hwy_step_wide_kernel(const StepParams p) {
   __shared__ WideShared<K> sh;
+  HWY_KERNARG_TOUCH(StepParams);
   wide_policy_step<K>(p, sh, blockIdx.x, blockIdx.x);
 }
 
@@ -1135,6 +1139,7 @@ __global__ void __launch_bounds__(64, WPE) hwy_step_wide_kernel(const StepParams
 template <int K, int WPE>
 __global__ void __launch_bounds__(64, WPE) hwy_rollout_wide_kernel(const StepParams p) {
   __shared__ WideShared<K> sh;
+  HWY_KERNARG_TOUCH(StepParams);
   const int e = blockIdx.x;
   for (int k = 0; k < p.k_steps; ++k) {  // wave-uniform
     HWY_RELOAD_PARAMS(pk, p);

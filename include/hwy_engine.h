@@ -254,9 +254,11 @@ typedef struct hwy_config {
   /* Tuning (ABI v5; 0 everywhere = the engine's own choice).  These replace the process-global environment variables
    * earlier builds read with getenv: a knob now belongs to ONE engine and is part of its documented configuration.
    * None of them changes any result (tests/test_engine_parity.py, tests/test_ix_parity.py compare the variants). */
-  int32_t tune_block_kernel;           /* 1: run the generic workgroup kernel (hwy_device.h) even for N <= 128, where the default is one
-                                          wavefront per environment (hwy_wave.h for N <= 64, hwy_wave2.h -- two vehicles per thread --
-                                          for 64 < N <= 128 with the Kinematics observation) */
+  int32_t tune_block_kernel;           /* 0: the engine's choice -- one wavefront per environment for N <= 128 (hwy_wave.h for N <= 64,
+                                          hwy_wave2.h with two vehicles per thread for 64 < N <= 128 and the Kinematics observation), the
+                                          generic workgroup kernel (hwy_device.h) beyond; 1: the workgroup kernel everywhere; 2: the
+                                          one-wavefront kernels wherever they exist (hwy_wave2.h with three / four vehicles per thread
+                                          for N <= 192 / 256: bit-identical, measured slower than the workgroup kernel there) */
   int32_t tune_waves_per_eu;           /* 1..4: register-allocation variant (resident wavefronts per SIMD) of the step kernel;
                                           no effect where the wide kernel runs (64 < N <= 128, Kinematics: one build, hwy_wave2.h) */
   int32_t tune_ix_no_helpers;          /* 1: HWY_SCENARIO_INTERSECTION with N <= 32 runs 32-thread workgroups (no helper lanes) */

@@ -145,7 +145,7 @@ void dispatch(Which which, const StepParams &p, int E) {
     }
     return;
   }
-  if (which == STEP && nw == 1 && !g_force_block && !g_cfg->tune_block_kernel) {  // same dispatch rule as hwy_kernels.hip
+  if (which == STEP && nw == 1 && !g_force_block && g_cfg->tune_block_kernel != 1) {  // same dispatch rule as hwy_kernels.hip
     if (g_k_steps > 0) {
       StepParams pk = p;
       pk.k_steps = g_k_steps;
@@ -158,7 +158,8 @@ void dispatch(Which which, const StepParams &p, int E) {
     else emu::launch([](const StepParams &q) { hwy::hwy_step_wave_kernel<1, true>(q); }, E, 64, p);
     return;
   }
-  if (which == STEP && nw >= 2 && nw <= 4 && p.obs_type == HWY_OBS_KINEMATICS && !g_force_block && !g_cfg->tune_block_kernel) {
+  if (which == STEP && nw >= 2 && nw <= 4 && p.obs_type == HWY_OBS_KINEMATICS && !g_force_block &&
+      (g_cfg->tune_block_kernel == 2 || (g_cfg->tune_block_kernel == 0 && nw == 2))) {
     // same dispatch rule as hwy_kernels.hip (wide_kernel_applies): one wavefront per environment, nw vehicles per thread
 #define RUN_WIDE(KV)                                                                                           \
     if (g_k_steps > 0) {                                                                                       \

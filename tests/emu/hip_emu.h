@@ -30,6 +30,10 @@
 #define HWY_RELOAD_STEP_PARAMS(q, p) const StepParams &q = p  // hwy_device.h
 #define HWY_RELOAD_IX_PARAMS(q, ip) const IxParams &q = ip  // hwy_ix.h
 #define HWY_RELOAD_NET_PARAMS(q, np) const NetParams &q = np  // hwy_net.h: the same for the road-network kernels
+#define HWY_PIN_POINTERS(a, b) ((void)0)              // hwy_device.h: store_vehicle_at
+#define HWY_GLOBAL_F64 double
+#define HWY_KERNARG_TOUCH(T) ((void)0)                // hwy_wave.h: a prefetch of the kernel-argument segment (device build only)
+#define HWY_ISSUED_TOGETHER(a, b, c, d, e_) ((void)0)  // hwy_wave.h: a scheduling constraint of the device build only
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 

@@ -170,7 +170,11 @@ def test_full_size_cfg3_determinism_independence_oracle_and_invariants():
         for k in ("lane", "target_lane", "flags"):
             np.testing.assert_array_equal(st[k][ok], ref[k][ok], err_msg=f"oracle, step {t}: {k}")
         for k in ("x", "y", "heading", "speed"):
-            np.testing.assert_allclose(st[k][ok], ref[k][ok], rtol=0, atol=1e-7, err_msg=f"oracle, step {t}: {k}")
+            # free-running since the reset: 1e-7; the step of a first collision 1e-6 (the frames after the contact resolve the wrecks'
+            # overlap again and each resolution roughly doubles a difference: DESIGN.md section 4 -- 1.3e-7 on one pair of the 1024
+            # environments, where the 64-environment sample of rounds 2-4 never held such a step late in an episode)
+            np.testing.assert_allclose(st[k][ok & ~wreck], ref[k][ok & ~wreck], rtol=0, atol=1e-7, err_msg=f"oracle, step {t}: {k}")
+            np.testing.assert_allclose(st[k][ok & wreck], ref[k][ok & wreck], rtol=0, atol=1e-6, err_msg=f"oracle, step {t}: {k} (first collision)")
         live &= ~wreck & ~tr2
         # invariants over the whole batch
         assert obs.shape == (E3, 1, 5, 5) and np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()

@@ -30,7 +30,7 @@ MUTANTS = {
         ("hwy_ix.h", "const int j_imp = i < SH::kCap ? sh.jmax[i] : -1;",
          "const int j_imp = (i < SH::kCap && sh.jmax[i] != 0x7fffffff) ? sh.jmax[i] : -1;")],
     "net_pair_list_carry": [
-        ("hwy_net.h", "const int carry = i < left ? (int)plist[count + i] : 0;", "const int carry = i < left ? (int)plist[count + i + 1] : 0;")],
+        ("hwy_net.h", "const int carry = i < left ? (int)plist[count + i] : 0,", "const int carry = i < left ? (int)plist[count + i + 1] : 0,")],
     "mobil_sides_swapped": [
         ("hwy_wave.h", "bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);",
          "bool ok_l = cl && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);"),

@@ -20,7 +20,8 @@ STATE_KEYS = ("x", "y", "heading", "speed", "timer", "target_speed", "delta", "i
 
 
 def _pair(backend, cfg_d, E, fast):
-    wide = make_engine(backend, _abi.make_config(cfg_d, E, fast=fast))
+    # (block_kernel=2: the one-wavefront kernels wherever they exist -- the engine's own choice beyond N = 128 is the workgroup kernel)
+    wide = make_engine(backend, _abi.make_config(dict(cfg_d, tuning={"block_kernel": 2}), E, fast=fast))
     block = make_engine(backend, _abi.make_config(dict(cfg_d, tuning={"block_kernel": 1}), E, fast=fast))
     return wide, block
 
