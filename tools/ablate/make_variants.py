@@ -57,17 +57,17 @@ def cutter(start, end, repl=""):
 
 def ticks(text):
     """s_memtime stamps around the sections of the one-wavefront kernel; totals returned through the obs buffer."""
-    t = sub("  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool controlled",
+    t = sub("  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;\n  double env_time",
             "  float n_recount = 0.0f; long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};\n"
             "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
-            "  Veh me;\n  load_vehicle<1>(p, e, me);\n  const bool controlled")(text)
+            "  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;\n  double env_time")(text)
     marks = ["    // ---- A. meta-action (abstract.py:294-304",
              "    // ---- C. rank along the road ---",
              "    // lane membership (AbstractLane.on_lane, margin 1) -> bits",
              "    // ---- D. Road.act: lane-change policy (behavior.py:219-263)",
              "    const double delta = sh.delta[i];",
              "    const double self_a = free_self - gap_own;",
-             "    // abort rule for ongoing lane changes: ordered chain",
+             "    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain over Road.vehicles -- a changer c",
              "    // ---- E. Road.act: low-level control",
              "    // ---- F. Road.step: integrate",
              "    // ---- G. Road.step: collisions",
@@ -77,8 +77,8 @@ def ticks(text):
             "      n_recount += __ballot(rank != r_before) ? 1.0f : 0.0f; }\n    // lane membership")(t)
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
-    t = sub("    observe_wave<true>(q, e, eo, me, true, rank);\n  }\n  me.rank = rank;",
-            "    observe_wave<true>(q, e, eo, me, true, rank);\n  }\n  TICK(11)\n  me.rank = rank;")(t)
+    t = sub("  if (q.full_step) observe_wave<true>(q, e, eo, me, true, rank, env_time);\n  me.rank = rank;",
+            "  if (q.full_step) observe_wave<true>(q, e, eo, me, true, rank, env_time);\n  TICK(11)\n  me.rank = rank;")(t)
     t = sub("  store_vehicle<1>(q, e, me, false);\n}",
             "  store_vehicle<1>(q, e, me, false);\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 12; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
@@ -89,10 +89,10 @@ def ticks(text):
 def wide_ticks(text):
     """s_memtime stamps around the sections of the two-vehicles-per-thread kernel (hwy_wave2.h); totals through the obs buffer
     (tools/wide_section_cycles.py)."""
-    t = sub("  // the meta-actions are requested BEFORE the state (lane a fetches agent a's)\n  const int act_lane",
+    t = sub("  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;\n  double env_time",
             "  long long t_prev = clock64(); long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};\n"
             "#define TICK(k) { const long long t_now = clock64(); acc[k] += t_now - t_prev; t_prev = t_now; }\n"
-            "  const int act_lane")(text)
+            "  int done_flag = p.autoreset ? (int)p.st.done[e] : 0;\n  double env_time")(text)
     marks = ["    // ---- A. meta-action (abstract.py:294-304 -> controller.py:295-315)",
              "    // ---- C. rank along the road, lane membership masks, frame-start snapshot",
              "    double log_ratio[K];",
@@ -105,8 +105,8 @@ def wide_ticks(text):
              "  }  // frames\n\n  // ---- H. observe"]
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
-    t = sub("    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n",
-            "    observe_wide<K, true>(q, sh, e, eo, me, true, rank);\n  }\n  TICK(10)\n"
+    t = sub("    observe_wide<K, true>(q, sh, e, eo, me, true, rank, env_time);\n  }\n",
+            "    observe_wide<K, true>(q, sh, e, eo, me, true, rank, env_time);\n  }\n  TICK(10)\n"
             "  if (l == 0 && q.obs) { for (int k = 0; k < 16; ++k) q.obs[(size_t)eo * q.A * q.V * q.F + k] = (float)acc[k]; }\n")(t)
     # collisions split: [11] = publish, [12] = walk trips, [13] = list passes, (G itself: the verdict reads); [14] walk trips, [15] list passes with >= 1 pair, [18] pairs
     t = sub("long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};", "long long acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
@@ -143,16 +143,16 @@ def net_ticks(text):
     for k, m in enumerate(marks):
         t = sub(m, f"    TICK({k})\n" + m)(t)
     # collisions split: walk steps -> acc[10], list passes (+ the verdict reads) -> acc[12]; walk-step / pass / SAT counters
-    t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64\n",
-            "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 64\n        TICK(10)\n        n_trip += count > 0 ? 1.0f : 0.0f;\n")(t)
-    t = sub("        if (i < left) plist[i] = (unsigned short)carry;\n        n_list = left;", "        TICK(12)\n        if (i < left) plist[i] = (unsigned short)carry;\n        n_list = left;")(t)
+    t = sub("        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128\n",
+            "        const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128\n        TICK(10)\n        n_trip += count > 0 ? 1.0f : 0.0f;\n")(t)
+    t = sub("        if (i < left) plist[i] = (unsigned short)carry;\n        if (64 + i < left)", "        TICK(12)\n        if (i < left) plist[i] = (unsigned short)carry;\n        if (64 + i < left)")(t)
     t = sub("  }  // frames\n\n  // ---- G. observe", "  TICK(12)\n  }  // frames\n\n  // ---- G. observe")(t)
     t = sub("    TICK(10)\n  TICK(12)\n  }  // frames", "  TICK(12)\n  }  // frames")(t)
-    t = sub("          ++k;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;", "          ++k;\n          n_walk += 1.0f;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;")(t)
+    t = sub("          k += WS;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;", "          k += WS;\n          n_walk += (float)WS;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;")(t)
     t = sub("            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "            n_sat += 1.0f;\n            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
     t = sub("  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};", "  float n_walk = 0, n_trip = 0, n_sat = 0; long long t_prev = clock64(); long long acc[13] = {0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
-    t = sub("    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
-            "    TICK(11)\n    me.rank = i & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
+    t = sub("    me.rank = rank & 0xff;  // the hint the next step verifies\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
+            "    TICK(11)\n    me.rank = rank & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
             "  { float sat_any = __ballot(n_sat > 0) ? 1.0f : 0.0f; n_sat = 0; for (int j = 0; j < 64; ++j) n_sat += __shfl(sat_any, j) * 0 ; n_sat = sat_any;\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 13; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
             "    p.obs[(size_t)e * p.A * p.V * p.F + 13] = n_walk; p.obs[(size_t)e * p.A * p.V * p.F + 14] = n_trip; p.obs[(size_t)e * p.A * p.V * p.F + 15] = n_sat; } }\n}")(t)
@@ -264,7 +264,10 @@ VARIANTS = {
                           "  if (i < 8) sh.cnt[i] = 0;\n  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift);")),
                   (W, sub("              r = pair_collide(A, Bb, p.dt, &tx, &ty);", "              atomicAdd(&sh.cnt[0], 1); r = pair_collide(A, Bb, p.dt, &tx, &ty);")),
                   (W, sub("            if (!surely_apart(A, Bb, p.dt)) {", "            atomicAdd(&sh.cnt[1], 1);\n            if (!surely_apart(A, Bb, p.dt)) {")),
-                  (W, sub("        if (__ballot(rival) == 0) continue;", "        if (i == 0) atomicAdd(&sh.cnt[2], 1);\n        if (__ballot(rival) == 0) continue;\n        if (i == 0) atomicAdd(&sh.cnt[3], 1);")),
+                  # (round 5: the rank-space chain -- cnt[2] = frames with a chain, cnt[3] = walk trips of it)
+                  (W, sub("        int *const sbits = reinterpret_cast<int *>(sh.nx);  // (the post-integration bodies only live inside section G)",
+                          "        if (i == 0) atomicAdd(&sh.cnt[2], 1);\n        int *const sbits = reinterpret_cast<int *>(sh.nx);")),
+                  (W, sub("          const bool go = rem != 0;\n          const int rr = go ? ctz64(rem) : 0;", "          if (i == 0) atomicAdd(&sh.cnt[3], 1);\n          const bool go = rem != 0;\n          const int rr = go ? ctz64(rem) : 0;")),
                   (W, sub("        const bool pend = pend_l || pend_r;", "        if (i == 0) atomicAdd(&sh.cnt[4], 1);\n        const bool pend = pend_l || pend_r;")),
                   (W, sub("o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u;",
                           "o[0] = (unsigned)tl_t0; o[1] = (unsigned)tl_t1; o[2] = tl_hw; o[3] = tl_xcc; o[4] = 0u; for (int k = 0; k < 5; ++k) o[5 + k] = (unsigned)sh.cnt[k];")),
