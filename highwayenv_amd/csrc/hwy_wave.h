@@ -716,8 +716,13 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       while (cm) {  // wave-uniform
         const int c = ctz64(cm);
         cm &= cm - 1;
-        const Body other{wave_bcast(me.x, c), wave_bcast(me.y, c), wave_bcast(me.v, c), wave_bcast(me.ch, c),
-                         wave_bcast(me.sh, c)};
+        // the checker's body to every lane THROUGH LDS (one lane writes, all read the same address): the launch is bound by the VALU
+        // port and a v_readlane is a VALU instruction, an LDS access is not -- ten v_readlane per frame were
+        // 1.1 % of the headline launch (40.75 -> 40.30 us, profiles/r05_history.md section 8).  (sh.nx is free in this branch.)
+        HWY_WAVE_LDS_FENCE();
+        if (i == c) { sh.nx[0] = me.x; sh.nx[1] = me.y; sh.nx[2] = me.v; sh.nx[3] = me.ch; sh.nx[4] = me.sh; }
+        HWY_WAVE_LDS_FENCE();
+        const Body other{sh.nx[0], sh.nx[1], sh.nx[2], sh.nx[3], sh.nx[4]};
         int r = 0;
         double tx = 0, ty = 0;
         if (active && i != c) {
