@@ -18,3 +18,18 @@ for n in ("fast", "fast_driver_shape", "merge_ma4", "intersection", "v0", "cfg3"
     if n == "fast":
         print({k: (x.get("ms_per_step"), x.get("valu_issue"), x.get("wait_fraction_of_a_wavefront")) for k, x in d.get("secondary_workloads", {}).items()})
 PY
+# how the host waits at the end of a region (the driver's 20-step shape carries the latency of one synchronize per region)
+for v in unset 100 1000; do
+  if [ $v = unset ]; then unset ROC_ACTIVE_WAIT_TIMEOUT; else export ROC_ACTIVE_WAIT_TIMEOUT=$v; fi
+  for rep in 1 2; do
+    timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/ds_wait${v}_$rep.json 2>> $O/bench_misc.err
+  done
+done
+unset ROC_ACTIVE_WAIT_TIMEOUT
+python - <<'PY'
+import json, os, glob
+O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r05prof")
+for f in sorted(glob.glob(O + "/ds_wait*.json")):
+    d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+    print(os.path.basename(f), round(d["ms_per_step"] * 1e3, 2), round(d["ms_per_step_device"] * 1e3, 2), [round(x * 1e3, 2) for x in d["ms_per_step_repeats"]])
+PY
