@@ -136,6 +136,7 @@ struct StepParams {
   int32_t full_step;      // 1: advance time, observe, reward, done flags; 0: frames only
   int32_t autoreset;      // 1: envs with done[e] are re-spawned instead of stepped
   int32_t prio_shift;     // > 0: issue-priority rotation among the wavefronts of a SIMD (hwy_wave.h: WaveTurn); 0: off
+  uint32_t prio_recip;    // != 0: a turn lasts prio_shift x 64 clock ticks instead of 2^prio_shift; floor(2^32 / prio_shift)
   const int32_t *actions;  // [E][A] or nullptr
   float *obs;              // [E][A][V][F] or nullptr
   double *reward;          // [E][A]
@@ -943,10 +944,12 @@ __global__ void __launch_bounds__(NW * 64) hwy_observe_kernel(const StepParams p
 struct WaveTurn {
   unsigned long long t;
   int slot, shift;
+  unsigned recip;  // != 0: turns of shift x 64 ticks (the turn index by a multiply-high with floor(2^32 / shift): scalar instructions)
 };
-__device__ inline void wave_turn_init(WaveTurn &w, int shift) {
+__device__ inline void wave_turn_init(WaveTurn &w, int shift, unsigned recip = 0) {
 #ifdef HWY_HAVE_SETPRIO
   w.shift = shift;
+  w.recip = recip;
   w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((4 << 11) | 4 /* HW_REG_HW_ID, WAVE_ID bits 3:0 */) & 3) : 0;
   w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
 #else
@@ -956,9 +959,10 @@ __device__ inline void wave_turn_init(WaveTurn &w, int shift) {
 // Workgroup kernel (several wavefronts per environment, joined by barriers): all wavefronts of a workgroup must share one
 // priority, so the slot is the workgroup's slot on its CU (HW_ID.TG_ID) -- the wavefronts that meet on a SIMD belong to
 // different workgroups of the CU.
-__device__ inline void wave_turn_init_workgroup(WaveTurn &w, int shift) {
+__device__ inline void wave_turn_init_workgroup(WaveTurn &w, int shift, unsigned recip = 0) {
 #ifdef HWY_HAVE_SETPRIO
   w.shift = shift;
+  w.recip = recip;
   w.slot = shift > 0 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4 /* HW_REG_HW_ID, TG_ID bits 19:16 */) & 3) : 0;
   w.t = shift > 0 ? __builtin_amdgcn_s_memtime() : 0ull;
 #else
@@ -968,7 +972,8 @@ __device__ inline void wave_turn_init_workgroup(WaveTurn &w, int shift) {
 __device__ inline void wave_turn(WaveTurn &w) {
 #ifdef HWY_HAVE_SETPRIO
   if (w.shift > 0) {  // wave-uniform (SGPR)
-    const int prio = (w.slot + (int)(w.t >> w.shift)) & 3;
+    const int turn = w.recip ? (int)__umulhi((unsigned)(w.t >> 6), w.recip) : (int)(w.t >> w.shift);
+    const int prio = (w.slot + turn) & 3;
     w.t = __builtin_amdgcn_s_memtime();
     if (prio == 0) __builtin_amdgcn_s_setprio(0);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -1025,7 +1030,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       if (p.agent_index[a] == i) agent = a;
 
   WaveTurn turn;
-  wave_turn_init_workgroup(turn, p.prio_shift);
+  wave_turn_init_workgroup(turn, p.prio_shift, p.prio_recip);
 
   // static collision-check membership (index space)
   u64 chk[NW];

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -131,7 +132,8 @@ static int validate(const hwy_config *c, std::string &why) {
   if (c->tune_ix_prewarm_frames < 0) BAD("tune_ix_prewarm_frames must be >= 0");
   if (c->tune_waves_per_eu < 0 || c->tune_waves_per_eu > 4) BAD("tune_waves_per_eu must be in [0,4]");
   if (c->tune_block_kernel < 0 || c->tune_block_kernel > 2) BAD("tune_block_kernel must be 0 (engine's choice), 1 (workgroup kernel) or 2 (one-wavefront kernels)");
-  if (c->tune_prio_shift < -1 || c->tune_prio_shift > 30) BAD("tune_prio_shift must be in [-1,30] (a shift of the 64-bit clock)");
+  if (c->tune_prio_shift < -1 || (c->tune_prio_shift > 30 && c->tune_prio_shift < 64) || c->tune_prio_shift > (1 << 20))
+    BAD("tune_prio_shift must be -1 (off), 0 (engine's choice), 1..30 (a turn of 2^k clock ticks) or 64..2^20 (a turn of k x 64 ticks)");
   if (c->obs_vehicles < 1 || c->obs_vehicles > c->num_vehicles + 64) BAD("obs_vehicles out of range");
   if (c->obs_type != HWY_OBS_KINEMATICS && c->obs_type != HWY_OBS_OCCUPANCY_GRID) BAD("unknown obs_type");
   if (c->obs_type == HWY_OBS_OCCUPANCY_GRID) {
@@ -190,6 +192,7 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.rp = eng->rp;
   p.grid_ws = eng->d_grid_ws;
   p.prio_shift = eng->prio_shift;
+  p.prio_recip = eng->prio_shift >= 64 ? (uint32_t)(0x100000000ull / (unsigned long long)eng->prio_shift) : 0u;
   p.block_env = eng->d_block_env;
   p.counters = eng->d_counters;
 }
@@ -399,7 +402,16 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
     // off 161.1, 16: 159.4; 2048 x 101: 214.8 / 207.6) -- profiles/r03_history.md
     int shift = HWY_DEFAULT_PRIO_SHIFT;
     for (int f = 7; f <= cfg->frames_per_step && shift < 18; f *= 2) ++shift;  // +1 from 7 frames on, +2 from 14 on, ...
-    eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? shift : 0;
+    // Round 5: the optimum is sharp and does not sit on a power of two (turns of k x 64 ticks, tune_prio_shift >= 64; all on the final
+    // build, tools/r05_call16.sh .. 18.sh).  One-wavefront highway kernel: 5 frames 224 .. 256 (x 64 ticks: 40.4 us; 192: 40.9,
+    // 288: 40.9, 2^15: 42.9); 15 frames 768 (107.5 us; 384: 107.7, 512: 109.6, 2^16: 111.3) -- a turn of 51 x 64 ticks per frame.
+    // merge-generic (config 5): 832 (222.5 us; 768: 223.0, 2^16: 226.2); merge-v0 keeps 2^16 (149.3 us; 768 .. 960: 150 .. 152).
+    int turn = shift;
+    if (cfg->scenario == HWY_SCENARIO_HIGHWAY && cfg->num_vehicles <= 64 && !eng->force_block_kernel)
+      turn = std::max(64, 256 * cfg->frames_per_step / 5);
+    else if (cfg->scenario == HWY_SCENARIO_MERGE_GENERIC)
+      turn = std::max(64, 832 * cfg->frames_per_step / 15);
+    eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? turn : 0;
   }
   *out = eng;
   return HWY_OK;

@@ -608,7 +608,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
   const int i = threadIdx.x;
   const int every = (int)(1 / p.dt / 2);  // int(1 / dt / REGULATION_FREQUENCY) (regulation.py:38)
   WaveTurn turn;  // the wavefronts sharing a SIMD take turns at the top issue priority (hwy_wave.h)
-  wave_turn_init(turn, p.prio_shift);
+  wave_turn_init(turn, p.prio_shift, p.prio_recip);
   for (int fr = 0; fr < n_frames; ++fr) {
     wave_turn(turn);
     const bool present = !(me.flags & HWY_F_ABSENT);

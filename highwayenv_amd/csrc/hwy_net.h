@@ -694,7 +694,7 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
   }
 
   WaveTurn turn;  // the wavefronts sharing a SIMD take turns at the top issue priority (hwy_wave.h)
-  wave_turn_init(turn, p.prio_shift);
+  wave_turn_init(turn, p.prio_shift, p.prio_recip);
   Veh me;
   load_vehicle<1>(p, e, me);
   const bool present = i < N && !(me.flags & HWY_F_ABSENT);

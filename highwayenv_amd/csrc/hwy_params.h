@@ -34,6 +34,7 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.inv_rx = 1.0 / (p.rx1 - p.rx0); p.inv_ry = 1.0 / (p.ry1 - p.ry0);
   p.inv_rvx = 1.0 / (p.rvx1 - p.rvx0); p.inv_rvy = 1.0 / (p.rvy1 - p.rvy0);
   p.prio_shift = c.tune_prio_shift > 0 ? c.tune_prio_shift : 0;  // the engine turns the default on where it pays (hwy_create)
+  p.prio_recip = 0;
   p.obs_type = c.obs_type;
   p.obs_std5 = c.obs_type == HWY_OBS_KINEMATICS && c.obs_features == 5;
   for (int f = 0; f < 5; ++f) p.obs_std5 = p.obs_std5 && c.obs_feature_ids[f] == f;  // presence, x, y, vx, vy

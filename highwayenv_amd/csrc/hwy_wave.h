@@ -355,7 +355,7 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
   }
 
   WaveTurn turn;
-  wave_turn_init(turn, p.prio_shift);
+  wave_turn_init(turn, p.prio_shift, p.prio_recip);
   const bool controlled = active && (me.flags & HWY_F_CONTROLLED);
   const bool idm = active && !controlled;
   int agent = 0, act0 = HWY_IDLE;

@@ -266,9 +266,12 @@ typedef struct hwy_config {
   int32_t tune_extra_lds;              /* bytes of dynamic LDS per workgroup of the one-wavefront step kernel (<= 65536):
                                           fewer resident wavefronts per SIMD, the rest dispatched as wavefronts retire */
   int32_t tune_prio_shift;             /* one-wavefront step kernels: wavefronts sharing a SIMD take turns at the top issue
-                                          priority (s_setprio), a turn lasting 2^shift clock ticks of s_memtime;
-                                          -1 = off (hardware order: oldest wavefront first), 0 = the engine's default: 14
-                                          (~7 us) when the whole grid of the step kernel is resident at once (occupancy x
+                                          priority (s_setprio), a turn lasting 2^shift clock ticks of s_memtime for
+                                          1 <= shift <= 30, or shift x 64 ticks for 64 <= shift <= 2^20 (turn lengths
+                                          between the powers of two: the optimum is sharp, profiles/r05_history.md);
+                                          -1 = off (hardware order: oldest wavefront first), 0 = the engine's default
+                                          (a turn of ~7 us for the 5 frames of highway-fast-v0, longer with more frames)
+                                          when the whole grid of the step kernel is resident at once (occupancy x
                                           compute units >= num_envs), else off */
   int32_t tune_ix_prewarm_frames;      /* HWY_SCENARIO_INTERSECTION auto-reset: warm-up frames of the NEXT episode advanced per
                                           launch by the pre-warming workgroup of an environment (0 = a third of frames_per_step) */
