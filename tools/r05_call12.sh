@@ -33,3 +33,10 @@ for f in sorted(glob.glob(O + "/ds_wait*.json")):
     d = json.loads([l for l in open(f) if l.startswith("{")][-1])
     print(os.path.basename(f), round(d["ms_per_step"] * 1e3, 2), round(d["ms_per_step_device"] * 1e3, 2), [round(x * 1e3, 2) for x in d["ms_per_step_repeats"]])
 PY
+# the intersection kernel with turns at the issue port (off by default there since round 3)
+for x in -1 512 1024 2048 4096; do
+  timeout 150 python bench.py --workload intersection --envs-per-gpu 2048 --no-cpu-baseline --no-secondary --steps 200 --repeats 3 --rollout-k 0 --tune prio_shift=$x > $O/ix_p${x}.json 2>> $O/bench_misc.err
+  python -c "
+import json,sys
+d=json.loads([l for l in open('$O/ix_p${x}.json') if l.startswith('{')][-1]); print('ix prio_shift $x', round(d['ms_per_step']*1e3,2))"
+done
