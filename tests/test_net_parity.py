@@ -218,8 +218,10 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
     print(f"\n{scenario} [{backend}]: {n_col} first-collision env-steps, {n_full - n_edge} compared in full"
           + (f"; {n_edge} more diverged on a touching pair's knife edge (tolerated)" if n_edge else ""))
     # the budget is the measured rate, not a percentage: 9 such env-steps in 40 000 fuzz configurations, i.e.
-    # none or one per call -- a regression in the collision path shows up as several (tests/test_mutations.py)
-    assert n_edge <= 1, "knife-edge divergences must stay rare:\n" + "\n".join(edge_log)
+    # none or one per call -- and TWO in exactly one call of the 12 000 of round 5's GPU fuzz (chunk 1215, configuration 3: one lane,
+    # five vehicles of which three are agents steered into each other, 8 first collisions in 10 steps; the round-4 kernels give the same
+    # two on the same chunk) -- a regression in the collision path shows up as many (tests/test_mutations.py)
+    assert n_edge <= 2, "knife-edge divergences must stay rare:\n" + "\n".join(edge_log)
     return n_term, n_crash
 
 
