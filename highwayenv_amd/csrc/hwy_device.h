@@ -291,7 +291,7 @@ __device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, d
     acc.axy = pos ? ny : -ny;
   }
 }
-__device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
+__device__ inline int pair_collide_body(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
   const double dx = B.x - A.x, dy = B.y - A.y;
   *tx = 0;
@@ -317,6 +317,31 @@ __device__ inline int pair_collide(const Body &A, const Body &B, double dt, doub
   }
   return (acc.intersecting ? 1 : 0) | (acc.will ? 2 : 0);
 }
+// HWY_OUTLINE_SAT: the SAT as a real function call (s_swappc; operands and results in registers: by value, no scratch) instead
+// of an inlined body -- a rare path (0.3 trips per headline env-step) whose registers the frame loop's allocation would then stop
+// paying for.  Measured in profiles/r06_history.md.
+struct SatOut {
+  double tx, ty;
+  int r;
+};
+#ifdef HWY_OUTLINE_SAT
+__device__ __attribute__((noinline)) SatOut pair_collide_call(double ax, double ay, double av, double ac, double as, double bx,
+                                                              double by, double bv, double bc, double bs, double dt) {
+  SatOut o;
+  o.r = pair_collide_body(Body{ax, ay, av, ac, as}, Body{bx, by, bv, bc, bs}, dt, &o.tx, &o.ty);
+  return o;
+}
+__device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
+  const SatOut o = pair_collide_call(A.x, A.y, A.v, A.c, A.s, B.x, B.y, B.v, B.c, B.s, dt);
+  *tx = o.tx;
+  *ty = o.ty;
+  return o.r;
+}
+#else
+__device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
+  return pair_collide_body(A, B, dt, tx, ty);
+}
+#endif
 
 // =============================================================================================
 template <int NW>

@@ -10,7 +10,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ASM = os.path.join("/tmp", "hwy_asm_base", "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+ASM = os.environ.get("HWY_ASM_FILE", os.path.join("/tmp", "hwy_asm_base", "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"))
 KERNEL = "_ZN3hwy20hwy_step_wave_kernelILi3ELb0EEEvNS_10StepParamsE"
 if "--kernel" in sys.argv:
     KERNEL = sys.argv[sys.argv.index("--kernel") + 1]

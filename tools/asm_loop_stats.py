@@ -29,11 +29,13 @@ if "--kernel" in sys.argv:
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    subprocess.run(["hipcc", *HIPCC_FLAGS,
-                    "-gline-tables-only", "-c", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip"),
+    # HWY_ASM_SRC: another translation unit than the product's (tools/mini/*.hip instantiate ONE kernel each: seconds, not minutes)
+    src = os.path.abspath(os.environ.get("HWY_ASM_SRC", os.path.join(ROOT, "highwayenv_amd", "csrc", "hwy_kernels.hip")))
+    subprocess.run(["hipcc", *HIPCC_FLAGS, "-I", os.path.join(ROOT, "highwayenv_amd", "csrc"),
+                    "-gline-tables-only", "-c", src,
                     "-o", os.path.join(OUT, "k.o"), "-save-temps=obj", *os.environ.get("HWY_EXTRA_FLAGS", "").split()],
                    check=True, capture_output=True, cwd=OUT)
-    s = open(os.path.join(OUT, "hwy_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    s = open(os.path.join(OUT, os.path.basename(src)[:-4] + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     files = {}
     for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]+)"(?:\s+"([^"]+)")?', s):
         files[int(m.group(1))] = (m.group(3) or m.group(2)).split("/")[-1]

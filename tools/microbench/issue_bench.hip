@@ -112,6 +112,33 @@ KERNEL_HEAD(k_fma_f64_x_s_mov) asm volatile(X32(T_FMA64_SMOV) : V8(a), "+v"(k), 
 KERNEL_HEAD(k_and_b32_x_s_mov) { int j0 = ik, j1 = ik; asm volatile(X32(T_AND32_SMOV) : V8(i), "+v"(j0), "+v"(j1), S8(s) : ); } KERNEL_TAIL
 KERNEL_HEAD(k_fma_f64_x_and_b32) asm volatile(X32(T_FMA64_AND32) : V8(a), "+v"(k), "+v"(k2), V8(i) : ); KERNEL_TAIL
 KERNEL_HEAD(k_fma_f64_x_readlane) { int j0 = ik; asm volatile(X32(T_FMA64_READLANE) : V8(a), "+v"(k), "+v"(k2), S8(s), "+v"(j0) : ); } KERNEL_TAIL
+// DEPENDENT chains (round 6): all 64 instructions on ONE register chain (dep1), on two (dep2) or four (dep4) -- what a wavefront
+// pays when the next instruction needs the previous result (the serial polynomial / Newton chains of atan2, sincos, rcp), i.e. the
+// LATENCY of the class, against the issue cost above; and an LDS round trip (ds_read whose address is the previous read's result)
+#define D1(S) S("0") S("0") S("0") S("0") S("0") S("0") S("0") S("0")
+#define D2(S) S("0") S("1") S("0") S("1") S("0") S("1") S("0") S("1")
+#define D4(S) S("0") S("1") S("2") S("3") S("0") S("1") S("2") S("3")
+#define D1_64(S) D1(S) D1(S) D1(S) D1(S) D1(S) D1(S) D1(S) D1(S)
+#define D2_64(S) D2(S) D2(S) D2(S) D2(S) D2(S) D2(S) D2(S) D2(S)
+#define D4_64(S) D4(S) D4(S) D4(S) D4(S) D4(S) D4(S) D4(S) D4(S)
+#define T_LDSCHASE(n) "ds_read_b32 %" n ", %" n "\ns_waitcnt lgkmcnt(0)\n"
+KERNEL_HEAD(k_fma_f64_dep1) asm volatile(D1_64(T_FMA64) : V8(a) : "v"(k), "v"(k2)); KERNEL_TAIL
+KERNEL_HEAD(k_fma_f64_dep2) asm volatile(D2_64(T_FMA64) : V8(a) : "v"(k), "v"(k2)); KERNEL_TAIL
+KERNEL_HEAD(k_fma_f64_dep4) asm volatile(D4_64(T_FMA64) : V8(a) : "v"(k), "v"(k2)); KERNEL_TAIL
+KERNEL_HEAD(k_add_f64_dep1) asm volatile(D1_64(T_ADD64) : V8(a) : "v"(k), "v"(k2)); KERNEL_TAIL
+KERNEL_HEAD(k_and_b32_dep1) asm volatile(D1_64(T_AND32) : V8(i) : "v"(ik), "v"(ik)); KERNEL_TAIL
+KERNEL_HEAD(k_rcp_f64_dep1) asm volatile(D1_64(T_RCP64) : V8(a) : "v"(k), "v"(k2)); KERNEL_TAIL
+__global__ void __launch_bounds__(64) k_lds_chase(Out *out, double seed) {
+  __shared__ int lds[64];
+  lds[threadIdx.x] = 0;  // every chain reads address 0, which holds 0
+  __syncthreads();
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int it = 0; it < ITERS; ++it) asm volatile(D1_64(T_LDSCHASE) : V8(i) : : "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[blockIdx.x].ticks = t1 - t0; out[blockIdx.x].realtime = r1 - r0; }
+  if ((i0 ^ i1 ^ i2 ^ i3 ^ i4 ^ i5 ^ i6 ^ i7) == 12345 + (int)seed) out[blockIdx.x].sink = 1.0;
+}
 KERNEL_HEAD(k_empty_loop) asm volatile("" : V8(a)); KERNEL_TAIL
 
 typedef void (*kern_t)(Out *, double);
@@ -122,7 +149,8 @@ int main(int argc, char **argv) {
   const Entry table[] = {E(fma_f64, 64), E(mul_f64, 64), E(add_f64, 64), E(max_f64, 64), E(cmp_f64, 64), E(cmp_i32, 64), E(cndmask, 64),
                          E(mov_b32, 64), E(and_b32, 64), E(add_u32, 64), E(lshl_b64, 64), E(fma_f32, 64), E(mul_f32, 64), E(rcp_f64, 64),
                          E(rsq_f64, 64), E(rcp_f32, 64), E(cvt_f64_i32, 64), E(readlane, 64), E(readfirstlane, 64), E(s_mov, 64), E(s_add, 64),
-                         E(s_nop, 64), E(fma_f64_x_s_mov, 64), E(and_b32_x_s_mov, 64), E(fma_f64_x_and_b32, 64), E(fma_f64_x_readlane, 64),
+                         E(s_nop, 64), E(fma_f64_x_s_mov, 64), E(and_b32_x_s_mov, 64), E(fma_f64_x_and_b32, 64), E(fma_f64_x_readlane, 64), E(fma_f64_dep1, 64), E(fma_f64_dep2, 64), E(fma_f64_dep4, 64), E(add_f64_dep1, 64),
+                         E(and_b32_dep1, 64), E(rcp_f64_dep1, 64), E(lds_chase, 64),
                          E(empty_loop, 0)};
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
