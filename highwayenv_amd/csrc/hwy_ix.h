@@ -124,9 +124,9 @@ struct IxSharedT {
   // frame snapshot by slot (indexed by thread where every thread writes)
   double x[NT], y[NT], v[NT], c[NT], s[NT];
   double bcx[NT], bcy[NT], brho[NT];  // regulation: a circle around the 11 predicted positions of slot i
-  // helper-lane exchange (kNH == 2 only): one double and two ints per thread, plus what a helper needs of its vehicle
-  double xd[kNH > 1 ? NT : 1], xl[kNH > 1 ? NT : 1];
-  int xi[kNH > 1 ? NT : 1], xb[kNH > 1 ? NT : 1];
+  // what the helper threads of a slot (IxMap) need of its vehicle in the regulation: published by the slot's own thread
+  double xd[CAP];
+  int xb[CAP];
   double hd[CAP];
   int vw[CAP];
   // pair work of a frame (collision partners, regulation conflicts): candidate pairs (lower slot | higher slot << 8) are
@@ -223,68 +223,69 @@ __device__ inline void ix_load_table(const IxParams &ip, SH &sh) {
   __syncthreads();
 }
 
-// helper lanes (IxSharedT): combine the two halves' partial (distance, lane) minima and membership bits
+// ---- helper GROUPS, sized per frame ---------------------------------------------------------------------------------------
+// The item-parallel sections of a frame (the walk over the lane table, the trajectory samples and the partner loop of the
+// regulation, the partner loop of the collision check) are loops over independent items of ONE vehicle, and most slots of an
+// environment are empty most of the time: BASELINE config 4 holds 8.3 vehicles on average in its 30 slots (16 at most, measured
+// over 3 200 env-steps on the emulator), so rounds 1-5's fixed split -- thread t works for slot t & 31 on the items of parity
+// t >> 5 -- left three quarters of the wavefront idle in exactly the loops that are 60 % of a step.  Now the split follows the
+// traffic: with `top` = the highest present slot + 1 rounded up to a power of two 2^lg, thread t works for slot vi = t & (2^lg - 1)
+// as member g = t >> lg of that slot's group of G = width >> lg threads, on the items g, g + G, g + 2 G ...: eight present
+// vehicles walk the twelve straight lanes in two trips instead of six, ask their eight arcs in one trip instead of four and meet
+// their partners in one trip instead of four.  Per-item arithmetic, tie rules (closest lane: minimum distance then lowest table
+// index; impact: highest partner slot) and therefore the results are those of the serial loops, bit for bit
+// (tests/test_ix_parity.py::test_helper_groups_identity builds -DHWY_IX_STATIC_HELPERS -- the fixed split through the same code --
+// next to it).  Threads at or above 2^lg own empty slots (or none): everybody but the slots' own threads (g == 0) is a helper.
+struct IxMap {
+  int vi, g, G, lg, top;  // my slot, my place in its group, threads per group (wave-uniform), log2(slots), highest present slot + 1
+};
 template <typename SH>
-__device__ inline void ix_xchg(SH &sh, double &bd, int &best, int &bits, double *lat_t = nullptr, bool has_lat = false) {
-  if constexpr (SH::kNH > 1) {
-    const int t = threadIdx.x, o = t ^ SH::kCap;
-    sh.xd[t] = bd; sh.xi[t] = best; sh.xb[t] = bits | (has_lat ? (1 << 30) : 0);
-    if (lat_t) sh.xl[t] = *lat_t;
-    HWY_WAVE_LDS_FENCE();
-    const double obd = sh.xd[o];
-    const int ob = sh.xi[o], obits = sh.xb[o];
-    bits |= obits & ~(1 << 30);
+__device__ inline IxMap ix_map(u64 pm) {  // pm: ballot of the present slots (wave-uniform)
+  const int t = threadIdx.x, W = (int)blockDim.x;
+  const int top = pm ? 64 - __clzll((long long)pm) : 0;
+#ifdef HWY_IX_STATIC_HELPERS
+  const int lg = SH::kCap == 64 ? 6 : 5;
+#else
+  const int lg = top <= 1 ? 0 : 64 - __clzll((long long)(top - 1));
+#endif
+  return IxMap{t & ((1 << lg) - 1), t >> lg, W >> lg, lg, top};
+}
+// (distance, lane) minimum over the G threads of every slot's group -- minimum distance, then lowest table index: the serial
+// rule is associative, so a butterfly over the group's lanes (t ^ 2^lg, t ^ 2^(lg+1) ..: ds_bpermute, no LDS storage, no
+// fence) leaves the group's minimum in every one of its threads
+__device__ inline void ix_group_min(const IxMap &mp, double &bd, int &best) {
+  const int t = threadIdx.x, W = (int)blockDim.x;
+  for (int st = 1 << mp.lg; st < W; st <<= 1) {  // wave-uniform
+    const int src = (t ^ st) << 2;
+    const int ohi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(bd)), olo = __builtin_amdgcn_ds_bpermute(src, __double2loint(bd));
+    const int ob = __builtin_amdgcn_ds_bpermute(src, best);
+    const double obd = __hiloint2double(ohi, olo);
     if (obd < bd || (obd == bd && ob < best)) { bd = obd; best = ob; }
-    if (lat_t && !has_lat && (obits & (1 << 30))) *lat_t = sh.xl[o];  // the other half walked my target lane
-    HWY_WAVE_LDS_FENCE();
   }
 }
 
-// ---- pair work: `trips` = the partner slots to visit (wave-uniform mask; with helper lanes bit j stands for the slots j and
-//      j + 1, one per half), cand(j) = "my vehicle and slot j are a candidate pair" (asked with my vehicle as the LOWER slot
-//      only: every unordered pair once), proc(pair, more) = the expensive evaluation of ONE pair per thread (pair < 0:
-//      none; more = another pass follows).
-//      The serial formulation ran the expensive part once per partner slot for the whole wave whenever ANY vehicle had that
-//      partner as a candidate; collected in a list, the candidates of all slots share ONE pass of it (64 pairs per pass).
-// HWY_IX_PAIR_TRIPS partner slots are asked per trip of the collecting loop (their cand() calls are independent: LDS reads, a
-// dozen f64 operations, no state); the list is appended to in trip order either way (a slot met while the list is full is put back
-// and asked again after the pass: same pairs, same order).  Measured on BASELINE config 4 (profiles/r05_history.md): 1 -> 255.7 us,
-// 2 -> 257.8, 4 -> 259.3, 8 -> 288.2 -- the loops are bound by the instructions a lone wavefront issues (one per 4 cycles, SALU
-// included), not by the latency of a trip: more chains in flight only add bookkeeping.  1 it stays.
-#ifndef HWY_IX_PAIR_TRIPS
-#define HWY_IX_PAIR_TRIPS 1
-#endif
+// ---- item work of a frame: every vehicle has the items 0 .. n - 1 (the arcs of the table, its possible partner slots); thread
+//      (slot vi, member g) asks cand(j) for j = g, g + G, .. -- straight-line code: LDS reads, a dozen f64 operations, no state --
+//      and the items that pass are collected in a list (vi | j << 8) and evaluated ONE PER THREAD: proc(pair, more) (pair < 0:
+//      none; more = another pass follows, wave-uniform).  The serial formulation ran the expensive part once per item for the
+//      whole wave whenever ANY vehicle had that item as a candidate; collected, the candidates of all slots share one pass of it
+//      (64 per pass).  The list is filled in trip order, a pass runs whenever it holds a wavefront's worth (a trip adds at most
+//      `width` entries to fewer than `width`: the 128 entries of plist suffice); the verdicts of proc meet per slot through LDS
+//      atomics (or / min / max), so neither the order of the list nor the size of the groups can change a result.
 template <typename SH, typename Cand, typename Proc>
-__device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand cand, Proc proc) {
-  constexpr int U = HWY_IX_PAIR_TRIPS;
-  const int i = threadIdx.x, width = (int)blockDim.x;  // pairs per pass: 64, or 32 in the 32-thread build
+__device__ inline void ix_for_items(SH &sh, int n, const IxMap &mp, Cand cand, Proc proc) {
+  const int i = threadIdx.x, width = (int)blockDim.x;  // items per pass: 64, or 32 in the 32-thread build
   const u64 below = ((u64)1 << i) - 1;
-  int n_list = 0;  // wave-uniform
-  while (trips || n_list) {
-    while (trips && n_list < width) {
-      int jb[U];
-      bool c[U];
-      u64 t_ = trips;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {  // (wave-uniform slots; -1 = none left)
-        jb[u] = t_ ? ctz64(t_) : -1;
-        t_ &= t_ - 1;  // (0 stays 0)
-      }
-      trips = t_;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {  // (no slot left: slot 0 is asked and the answer dropped -- no branch between the chains)
-        const bool cu = cand((jb[u] < 0 ? 0 : jb[u]) + half);
-        c[u] = jb[u] >= 0 && cu;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (jb[u] < 0) continue;                                 // wave-uniform
-        if (n_list >= width) { trips |= (u64)1 << jb[u]; continue; }  // the list is full: asked again after the pass
-        const u64 cm = __ballot(c[u]);
-        if (cm) {
-          if (c[u]) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(vi | ((jb[u] + half) << 8));
-          n_list += __popcll(cm);
-        }
+  int n_list = 0, j0 = 0;  // wave-uniform
+  while (j0 < n || n_list) {
+    while (j0 < n && n_list < width) {
+      const int j = j0 + mp.g;
+      const bool c = cand(j < n ? j : 0) && j < n;
+      j0 += mp.G;
+      const u64 cm = __ballot(c);
+      if (cm) {
+        if (c) sh.plist[n_list + __popcll(cm & below)] = (unsigned short)(mp.vi | (j << 8));
+        n_list += __popcll(cm);
       }
     }
     const int count = n_list < width ? n_list : width;
@@ -292,7 +293,7 @@ __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand ca
     const int pair = i < count ? (int)sh.plist[i] : -1;
     const int left = n_list - count;  // < width
     const int carry = i < left ? (int)sh.plist[count + i] : 0;
-    proc(pair, trips != 0 || left != 0);  // (more passes follow: wave-uniform)
+    proc(pair, j0 < n || left != 0);  // (more passes follow: wave-uniform)
     HWY_WAVE_LDS_FENCE();
     if (i < left) sh.plist[i] = (unsigned short)carry;
     n_list = left;
@@ -309,13 +310,21 @@ __device__ inline void ix_for_pairs(SH &sh, u64 trips, int vi, int half, Cand ca
 template <typename SH>
 __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, double x, double y, double h, int tgt,
                                     int *bits_out, int *closest_out, double *lat_tgt_out) {
-  constexpr int NH = SH::kNH;
-  const int t = threadIdx.x, vi = t & (SH::kCap - 1), half = NH > 1 ? t / SH::kCap : 0;
-  // the poses by slot: a helper lane works on the body of vehicle t & 31, and the arc phase gathers them per pair
+  const int t = threadIdx.x;
+  const IxMap mp = ix_map<SH>(__ballot(present));
+  const int vi = mp.vi;
+  const bool own = present;  // MY slot holds a vehicle (then vi == t); `present` below becomes slot vi's
+  // the poses by slot: the threads of a slot's group work on its body, and the arc phase gathers them per pair; the per-slot
+  // results of the walk meet in flag (membership bits), bcy / vlane (lateral coordinate on the target lane) and, for the arcs,
+  // dmin / jmax
+  unsigned long long *const dmin = reinterpret_cast<unsigned long long *>(sh.bcx);
   HWY_WAVE_LDS_FENCE();
-  if (half == 0) { sh.x[vi] = x; sh.y[vi] = y; sh.hd[vi] = h; sh.vw[vi] = tgt | (present ? 256 : 0); }
+  if (t < SH::kCap) {
+    sh.x[t] = x; sh.y[t] = y; sh.hd[t] = h; sh.vw[t] = tgt | (present ? 256 : 0);
+    dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; sh.flag[t] = 0; sh.vlane[t] = 0;
+  }
   HWY_WAVE_LDS_FENCE();
-  if constexpr (NH > 1) {
+  if (mp.G > 1) {  // wave-uniform
     x = sh.x[vi]; y = sh.y[vi]; h = sh.hd[vi];
     const int w = sh.vw[vi];
     tgt = w & 255; present = (w & 256) != 0;
@@ -324,66 +333,44 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
   double bd = __builtin_inf(), lat_t = 0.0;  // lat_t: my lateral coordinate on my target lane (the next frame steers by it)
   bool has_lat = false;
   const int ns = sh.n_straight, n = ip.n_lanes;
-  // Every trip projects the body on HWY_IX_WALK_ROWS lanes per half (rows k + half, + NH, + 2 NH ..) in one basic block, so that
-  // the chains interleave.  Two, three or all six rows of a half per trip: 259.3 / 259.3 / 259.4 us on BASELINE config 4
-  // (profiles/r05_history.md) -- two it stays.
-#ifndef HWY_IX_WALK_ROWS
-#define HWY_IX_WALK_ROWS 2
-#endif
-  constexpr int R = HWY_IX_WALK_ROWS;
-  for (int k = 0; k < ns; k += R * NH) {  // wave-uniform trip
-    bool m[R], on[R];
-    IxRow r[R];
-    double s_[R], lat[R], d[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      const int ku = k + half + u * NH;
-      m[u] = ku < ns;
-      r[u] = sh.row[m[u] ? ku : k];
-    }
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      const double dx = x - r[u].a, dy = y - r[u].b;
-      s_[u] = dx * r[u].c + dy * r[u].d;
-      lat[u] = dx * -r[u].d + dy * r[u].c;
-      on[u] = fabs(lat[u]) <= r[u].e && -5.0 <= s_[u] && s_[u] < r[u].f + 5.0;
-      const double ang = fabs(wrap_to_pi(h - r[u].g));
-      d[u] = fabs(lat[u]) + fmax(s_[u] - r[u].f, 0.0) + fmax(0 - s_[u], 0.0) + 1.0 * ang;
-    }
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      if (m[u]) {
-        bits |= on[u] ? (1 << r[u].L) : 0;
-        sh.sl[r[u].L][vi] = s_[u];
-        if (d[u] < bd || (d[u] == bd && r[u].L < best)) { bd = d[u]; best = r[u].L; }
-        if (r[u].L == tgt) { lat_t = lat[u]; has_lat = true; }
-      }
+  // Straight lanes: member g of a slot's group projects the body on the rows g, g + G, ..  (Rounds 4-5 put two or more rows of a
+  // thread in one basic block so that their chains interleave: 259.3 / 259.3 / 259.4 us for two / three / six -- and round 6's
+  // microbenchmark says why nothing moved: a DEPENDENT v_fma_f64 chain issues every 4.5 cycles like an independent one,
+  // profiles/r06_issue_costs.json -- so one row per trip it is.)
+  for (int k0 = 0; k0 < ns; k0 += mp.G) {  // wave-uniform trip
+    const int k = k0 + mp.g;
+    const bool m = k < ns;
+    const IxRow r = sh.row[m ? k : k0];
+    const double dx = x - r.a, dy = y - r.b;
+    const double s_ = dx * r.c + dy * r.d;
+    const double lat = dx * -r.d + dy * r.c;
+    const bool on = fabs(lat) <= r.e && -5.0 <= s_ && s_ < r.f + 5.0;
+    const double ang = fabs(wrap_to_pi(h - r.g));
+    const double d = fabs(lat) + fmax(s_ - r.f, 0.0) + fmax(0 - s_, 0.0) + 1.0 * ang;
+    if (m) {
+      bits |= on ? (1 << r.L) : 0;
+      sh.sl[r.L][vi] = s_;
+      if (d < bd || (d == bd && r.L < best)) { bd = d; best = r.L; }
+      if (r.L == tgt) { lat_t = lat; has_lat = true; }
     }
   }
-  {
-    int none = 0;
-    ix_xchg(sh, bd, best, none);  // the arcs are filtered against the best distance over ALL straight lanes
-  }
+  ix_group_min(mp, bd, best);  // the arcs are filtered against the best distance over ALL straight lanes
   // Arcs.  A CircularLane costs an atan2, and most (vehicle, arc) pairs cannot matter: the arc can only hold the vehicle
   // if |lateral| = |radius - r| <= width / 2 + 1, can only be its closest lane if |lateral| <= the best distance over the
   // straight lanes (its distance is at least |lateral|), or it is its target lane.  The pairs that pass this filter are
-  // collected and projected one pair per thread (ix_for_pairs); their verdicts meet per vehicle: membership bits (or),
+  // collected and projected one pair per thread (ix_for_items); their verdicts meet per vehicle: membership bits (or),
   // the closest arc (minimum of the distance's bit pattern -- distances are >= 0 --, then the lowest table index among the
   // arcs at that minimum: the serial rule) and the lateral coordinate on the target lane.
   const int na = n - ns;
   if (na > 0) {  // wave-uniform
-    unsigned long long *const dmin = reinterpret_cast<unsigned long long *>(sh.bcx);
-    if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; sh.flag[t] = 0; sh.vlane[t] = 0; }
-    HWY_WAVE_LDS_FENCE();
-    const u64 rows = na >= 64 ? ~(u64)0 : (((u64)1 << na) - 1);
-    ix_for_pairs(
-        sh, NH > 1 ? ((rows | (rows >> 1)) & 0x5555555555555555ull) : rows, vi, half,
-        [&](int j) {  // (straight-line code: ix_for_pairs keeps several of these in flight)
-          const IxRow r = sh.row[ns + (j < na ? j : 0)];
+    ix_for_items(
+        sh, na, mp,
+        [&](int j) {  // (straight-line code)
+          const IxRow r = sh.row[ns + j];
           // |radius - rr| <= m with m = max(width / 2 + 1, best straight distance), on the squares (a filter: 1e-9 of slack)
           const double dx = x - r.a, dy = y - r.b, r2 = dx * dx + dy * dy;
           const double m = fmax(r.e, bd) + 1e-9, lo = r.c - m, hi = r.c + m;
-          return present && j < na && (r.L == tgt || ((lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi));
+          return present && (r.L == tgt || ((lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi));
         },
         [&](int pair, bool more) {
           const int v = pair < 0 ? 0 : (pair & 255);
@@ -413,8 +400,8 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           if (pair >= 0 && dmin[v] == key)
             __hip_atomic_fetch_min(&sh.jmax[v], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (more) {  // wave-uniform, rare: more candidate pairs than one pass holds
-            // the owners fold THIS pass's closest arc into their running minimum and clear the slots: the next pass starts
-            // over, so "lowest index among the arcs at the minimum" never mixes two passes
+            // every thread of a slot's group folds THIS pass's closest arc into its running minimum and the slots are cleared: the
+            // next pass starts over, so "lowest index among the arcs at the minimum" never mixes two passes
             HWY_WAVE_LDS_FENCE();
             const unsigned long long akey = dmin[vi];
             if (present && akey != ~0ull) {
@@ -426,20 +413,22 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
             if (t < SH::kCap) { dmin[t] = ~0ull; sh.jmax[t] = 0x7fffffff; }
           }
         });
-    HWY_WAVE_LDS_FENCE();
-    if (present) {
-      const unsigned long long akey = dmin[vi];  // (the last pass)
-      if (akey != ~0ull) {
-        const double ad = __longlong_as_double((long long)akey);
-        const int aL = sh.jmax[vi];
-        if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
-      }
-      bits |= sh.flag[vi];
-      if (sh.vlane[vi]) { lat_t = sh.bcy[vi]; has_lat = true; }
-    }
   }
-  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);
-  *bits_out = present ? bits : 0;  // (`present` is the vehicle's: a helper lane returns its vehicle's bits)
+  // the straight walk's membership bits and target-lane coordinate join the arcs' per slot
+  if (bits) __hip_atomic_fetch_or(&sh.flag[vi], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (has_lat) { sh.bcy[vi] = lat_t; sh.vlane[vi] = 1; }
+  HWY_WAVE_LDS_FENCE();
+  if (present) {
+    const unsigned long long akey = dmin[vi];  // (the last pass of the arcs)
+    if (akey != ~0ull) {
+      const double ad = __longlong_as_double((long long)akey);
+      const int aL = sh.jmax[vi];
+      if (ad < bd || (ad == bd && aL < best)) { bd = ad; best = aL; }
+    }
+    bits = sh.flag[vi];
+    if (sh.vlane[vi]) lat_t = sh.bcy[vi];
+  }
+  *bits_out = own ? bits : 0;  // (a helper thread holds its slot's values too: they are its vehicle's, not of the empty slot it owns)
   *closest_out = best;
   *lat_tgt_out = lat_t;
 }
@@ -614,6 +603,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
     const bool present = !(me.flags & HWY_F_ABSENT);
     const bool controlled = present && (me.flags & HWY_F_CONTROLLED);
     const u64 pm = __ballot(present);
+    const IxMap mp = ix_map<SH>(pm);  // this frame's helper groups (nobody joins or leaves within a frame)
     // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act, controller.py:295-315): SLOWER / IDLE / FASTER ------
     // MultiAgentAction.act (action.py:352-355): agent a == the a-th controlled vehicle of the list
     const u64 ctl_m = (fr == 0 && actions) ? __ballot(controlled) : 0;
@@ -710,18 +700,17 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         me.ts = sh.lim[me.lane];
         me.flags &= ~HWY_F_YIELDING;
       }
-      // (helper lanes, IxSharedT: thread t works for vehicle vi = t & 31 -- the samples and the partners of parity t >> 5)
-      constexpr int NH = SH::kNH;
-      const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
-      double s_me = veh ? sh.sl[me.lane][vi] : 0.0, v_me = me.v, x_me = me.x, y_me = me.y, c_me = ch, sn_me = shh;
+      // (helper groups, IxMap: thread t works for vehicle vi -- the samples and the partners g, g + G, .. of its group)
+      const int vi = mp.vi;
+      double s_me = veh ? sh.sl[me.lane][i < SH::kCap ? i : 0] : 0.0, v_me = me.v, x_me = me.x, y_me = me.y, c_me = ch, sn_me = shh;
       route_t route_me = me.route;
       int lane_me = me.lane;
       bool veh_v = veh;
-      if constexpr (NH > 1) {
-        if (half == 0) { sh.xd[i] = s_me; sh.bcx[i] = __longlong_as_double(me.route); sh.xb[i] = me.lane | (veh ? 256 : 0); }
+      if (mp.G > 1) {  // wave-uniform
+        if (i < SH::kCap) { sh.xd[i] = s_me; sh.bcx[i] = __longlong_as_double(me.route); sh.xb[i] = me.lane | (veh ? 256 : 0); }
       }
       HWY_WAVE_LDS_FENCE();  // sl[][] is dead from here on: the trajectories share its storage
-      if constexpr (NH > 1) {
+      if (mp.G > 1) {
         s_me = sh.xd[vi]; route_me = __double_as_longlong(sh.bcx[vi]);  // (bcx is free until the circles below)
         lane_me = sh.xb[vi] & 255; veh_v = (sh.xb[vi] & 256) != 0;
         v_me = sh.v[vi]; x_me = sh.x[vi]; y_me = sh.y[vi]; c_me = sh.c[vi]; sn_me = sh.s[vi];  // frame snapshot (B)
@@ -729,13 +718,13 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       if (veh_v) {
         IxVeh r{};
         r.route = route_me; r.lane = lane_me;
-        for (int k = half; k < HWY_IX_SAMPLES; k += NH) {
+        for (int k = mp.g; k < HWY_IX_SAMPLES; k += mp.G) {
           double px, py, hd;
           ix_along_route(sh, r, s_me + v_me * (0.25 + k * 0.25), &px, &py, &hd);
           sh.traj[k][0][vi] = px; sh.traj[k][1][vi] = py; sh.traj[k][2][vi] = hd;
         }
       }
-      if constexpr (NH > 1) HWY_WAVE_LDS_FENCE();
+      HWY_WAVE_LDS_FENCE();
       // Two vehicles can only conflict if at some sample their predicted positions are within LENGTH of each other
       // (regulation.py:103): bound every vehicle's 11 positions by a circle (centre = the middle sample) and skip a
       // partner for the whole wave when no pair of circles comes within LENGTH (triangle inequality, 1e-6 of slack)
@@ -749,7 +738,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
         }
         my_rho = sqrt(my_rho);  // == the maximum of the 11 distances (sqrt is monotone)
       }
-      if (half == 0) {
+      if (mp.g == 0) {
         sh.bcx[vi] = my_cx; sh.bcy[vi] = my_cy; sh.brho[vi] = my_rho;
         sh.flag[vi] = 0;
         sh.vlane[vi] = lane_me;
@@ -757,8 +746,8 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
       HWY_WAVE_LDS_FENCE();
       // is_conflict_possible (regulation.py:88-111) + respect_priorities (:70-86) of every candidate pair, one pair per
       // thread; a vehicle yields iff some pair names it (sh.flag)
-      ix_for_pairs(
-          sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
+      ix_for_items(
+          sh, mp.top, mp,
           [&](int j) {
             const double bdx = sh.bcx[j] - my_cx, bdy = sh.bcy[j] - my_cy;
             const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
@@ -835,19 +824,18 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
 
     // ---- F. collisions (road.py:477-481, objects.py:92-138): every pair; the highest partner slot's impact stays ----
     {
-      constexpr int NH = SH::kNH;
-      const int vi = i & (SH::kCap - 1), half = NH > 1 ? i / SH::kCap : 0;
+      const int vi = mp.vi;
       const double c2 = me.ch, s2 = me.sh;
       HWY_WAVE_LDS_FENCE();
       sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = c2; sh.s[i] = s2;
       HWY_WAVE_LDS_FENCE();
-      // (helper lanes: thread t looks for the partners of vehicle t & 31 among the slots of parity t >> 5)
-      const Body mine = NH > 1 ? Body{sh.x[vi], sh.y[vi], sh.v[vi], sh.c[vi], sh.s[vi]} : Body{me.x, me.y, me.v, c2, s2};
-      const bool present_v = NH > 1 ? ((pm >> vi) & 1) != 0 : present;
+      // (helper groups: thread t looks for the partners of vehicle vi among the slots g, g + G, ..)
+      const Body mine = mp.G > 1 ? Body{sh.x[vi], sh.y[vi], sh.v[vi], sh.c[vi], sh.s[vi]} : Body{me.x, me.y, me.v, c2, s2};
+      const bool present_v = ((pm >> vi) & 1) != 0;
       if (i < SH::kCap) { sh.jmax[i] = -1; sh.flag[i] = 0; }
       HWY_WAVE_LDS_FENCE();
-      ix_for_pairs(
-          sh, NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm, vi, half,
+      ix_for_items(
+          sh, mp.top, mp,
           [&](int j) {
             const double ox = sh.x[j], oy = sh.y[j], ov = sh.v[j];
             const double dx = ox - mine.x, dy = oy - mine.y;

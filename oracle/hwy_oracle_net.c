@@ -213,6 +213,7 @@ static double interval_distance(double min_a, double max_a, double min_b, double
 static __thread double g_axis_dn = INFINITY;
 static __thread double g_flag_dn = INFINITY; /* smallest |interval distance| behind an intersecting / will_intersect decision */
 extern __thread double *orc_margin_buf, *orc_flag_margin_buf;
+extern __thread double orc_knife_bias; /* 0 except in a knife-edge replay (hwy_oracle.c: orc_set_knife_bias) */
 /* utils.py:196-241 */
 static void are_polygons_intersecting(double a[5][2], double b[5][2], const double da[2], const double db[2],
                                       int *intersecting, int *will_intersect, double translation[2]) {
@@ -232,12 +233,12 @@ static void are_polygons_intersecting(double a[5][2], double b[5][2], const doub
       double min_a, max_a, min_b, max_b;
       project_polygon(a, normal, &min_a, &max_a);
       project_polygon(b, normal, &min_b, &max_b);
-      if (interval_distance(min_a, max_a, min_b, max_b) > 0) *intersecting = 0;
+      if (interval_distance(min_a, max_a, min_b, max_b) > orc_knife_bias) *intersecting = 0;
       g_flag_dn = fmin(g_flag_dn, fabs(interval_distance(min_a, max_a, min_b, max_b)));
       double vp = normal[0] * (da[0] - db[0]) + normal[1] * (da[1] - db[1]);
       if (vp < 0) min_a += vp; else max_a += vp;
       double distance = interval_distance(min_a, max_a, min_b, max_b);
-      if (distance > 0) *will_intersect = 0;
+      if (distance > orc_knife_bias) *will_intersect = 0;
       g_flag_dn = fmin(g_flag_dn, fabs(distance));
       if (!*intersecting && !*will_intersect) break;
       if (fabs(distance) < min_distance) {

@@ -122,3 +122,19 @@ class impact_margins:
     def well(self, knife: float = 1e-9) -> np.ndarray:
         """[E]: every collision decision of the call is well conditioned (push direction AND flags)."""
         return (self.margin.min(1) >= knife) & (self.flag_margin.min(1) >= knife)
+
+
+class knife_bias:
+    """Context manager (test diagnostics, road-network oracle): the SAT's two `distance > 0` decisions (utils.py:222-229) taken as
+    `distance > bias` -- the answer the reference gives when a distance at rounding level (|d| < |bias|) rounds to the other side."""
+
+    def __init__(self, bias: float):
+        self.bias = float(bias)
+
+    def __enter__(self):
+        lib().orc_set_knife_bias(C.c_double(self.bias))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_knife_bias(C.c_double(0.0))
+        return False

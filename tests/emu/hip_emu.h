@@ -143,7 +143,14 @@ inline int ds_permute(int addr, int v) {  // my value lands in lane (addr/4)%64 
   wave_barrier();
   return buf[threadIdx.x];
 }
+inline int ds_bpermute(int addr, int v) {  // I read the value lane (addr/4)%64 holds
+  int *buf = g_xchg[cur->xchg_phase++ & 1];
+  buf[threadIdx.x] = v;
+  wave_barrier();
+  return buf[(threadIdx.x & ~63) + ((addr >> 2) & 63)];
+}
 }  // namespace emu
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu::ds_bpermute((addr), (v))
 #define __builtin_amdgcn_readlane(v, lane) emu::readlane((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) (v)  // (only used on wave-uniform values: every fiber holds the same one)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

@@ -153,13 +153,14 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
     eng = make_engine(backend, cfg)
     eng.set_state(st)
     rng = np.random.default_rng(seed)
-    n_term = n_crash = n_col = n_full = n_edge = 0
+    n_term = n_crash = n_col = n_full = n_edge = n_explained = 0
     edge_log = []
     next_seed = 10_000_000 * seed
     drift = np.zeros(E, np.int64)   # steps since the env was last synchronised
     for t in range(steps):
         acts = rng.integers(0, _abi.num_actions(cfg), size=(E, cfg.num_agents)).astype(np.int32)
         obs, reward, term, trunc, info = eng.step(acts)
+        ref0 = _abi.copy_state(ref)   # (the state the step started from: a knife-edge replay below starts there again)
         with oracle.impact_margins(cfg) as m:
             o2, r2, te2, tr2, i2 = oracle.step(cfg, ref, acts)
         what = f"step {t}"
@@ -175,6 +176,7 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
         np.testing.assert_array_equal(trunc, tr2, err_msg=what)
         np.testing.assert_array_equal(info["crashed"], i2["crashed"], err_msg=what)
         got = eng.get_state()
+        got_raw = _abi.copy_state(got)
         mask_knife_edge_flags(got, ref, m.flag_margin)
         # A wreck that rests EXACTLY touching a third body while another pair pushes it: whether the touching pair "will
         # intersect" hinges on a distance of ~0 (flag_margin < KNIFE), and if it does its ~0 translation REPLACES the pending
@@ -193,8 +195,28 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
                 except AssertionError as ex:
                     if strict:
                         raise
-                    n_edge += 1
-                    edge_log.append(f"step {t} env {e}: {str(ex).strip().splitlines()[0:3]}")
+                    # The oracle says this env-step hinged on a distance below KNIFE.  "Either answer is the reference's" is
+                    # CHECKED, not assumed: the step is replayed on the oracle from the same start with that decision rounded to
+                    # either side (oracle.knife_bias), and the engine must reproduce one of the two replays in full.
+                    explained = False
+                    for bias in (KNIFE, -KNIFE):
+                        alt = _abi.copy_state(ref0)
+                        with oracle.knife_bias(bias):
+                            o3, r3, _, _, _ = oracle.step(cfg, alt, acts)
+                        try:
+                            assert_obs_close(obs[sel], o3[sel], bool(cfg.flags & _abi.C_GRID_IMAGE), what)
+                            np.testing.assert_allclose(reward[sel], r3[sel], rtol=0, atol=1e-9, err_msg=what)
+                            g3, a3 = _sub(got_raw, sel), _sub(alt, sel)
+                            mask_knife_edge_flags(g3, a3, m.flag_margin[sel])  # (the bits / pending impact of the touching slots)
+                            assert_net_state_close(g3, a3, atol=atol, what=what)
+                            explained = True
+                            break
+                        except AssertionError:
+                            pass
+                    n_explained += int(explained)
+                    if not explained:
+                        n_edge += 1
+                        edge_log.append(f"step {t} env {e}: {str(ex).strip().splitlines()[0:3]}")
         n_term += int(term.sum())
         n_crash += int(i2["crashed"].any(1).sum())
         redo = term | trunc | wreck
@@ -215,13 +237,16 @@ def _rollout_vs_oracle(backend, config, scenario, E, steps, seed, sync_every=4):
         drift[sync] = 0
         eng.set_state(got)
     eng.close()
-    print(f"\n{scenario} [{backend}]: {n_col} first-collision env-steps, {n_full - n_edge} compared in full"
-          + (f"; {n_edge} more diverged on a touching pair's knife edge (tolerated)" if n_edge else ""))
-    # the budget is the measured rate, not a percentage: 9 such env-steps in 40 000 fuzz configurations, i.e.
-    # none or one per call -- and TWO in exactly one call of the 12 000 of round 5's GPU fuzz (chunk 1215, configuration 3: one lane,
-    # five vehicles of which three are agents steered into each other, 8 first collisions in 10 steps; the round-4 kernels give the same
-    # two on the same chunk) -- a regression in the collision path shows up as many (tests/test_mutations.py)
-    assert n_edge <= 2, "knife-edge divergences must stay rare:\n" + "\n".join(edge_log)
+    print(f"\n{scenario} [{backend}]: {n_col} first-collision env-steps, {n_full - n_edge - n_explained} compared in full"
+          + (f"; {n_explained} more equal the oracle's replay with a touching pair's distance rounded the other way" if n_explained else "")
+          + (f"; {n_edge} diverged on a touching pair's knife edge and match neither replay (tolerated: at most 1)" if n_edge else ""))
+    # Round 5 widened this budget to 2 after ONE chunk of 12 000 (merge fuzz chunk 1215, configuration 3: one lane, three agents
+    # steered into each other, 8 first collisions in 10 steps) showed two such env-steps in one call.  Round 6 put it back to 1 and made
+    # the exclusion checkable instead: a knife-edge divergence the oracle itself reproduces with the decisive distance rounded to
+    # the other side (above) is an explained one and is not counted.  What remains under the budget is a step that hinges on two
+    # such distances rounded to DIFFERENT sides -- 9 such env-steps of either kind in 40 000 fuzz configurations;
+    # a regression in the collision path shows up as many (tests/test_mutations.py).
+    assert n_edge <= 1, "knife-edge divergences must stay rare:\n" + "\n".join(edge_log)
     return n_term, n_crash
 
 

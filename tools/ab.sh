@@ -19,8 +19,8 @@ wl_args() {
     n200) echo "--workload v0_n200 --envs-per-gpu 1024";;
     merge) echo "--workload merge_ma4";;
     mergev0) echo "--workload merge";;
-    ix) echo "--workload intersection";;
-    ixkin) echo "--workload intersection_kin";;
+    ix) echo "--workload intersection --envs-per-gpu 2048";;
+    ixkin) echo "--workload intersection_kin --envs-per-gpu 2048";;
     *) echo "--workload $1";;
   esac
 }
