@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 VEHICLES_COUNT = 50
 LANES = 4
-EVENT_EVERY = 8
+EVENT_EVERY = 1  # every launch of the kernel-timing region (rounds 1-5: every 8th launch of the timed regions)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock (MI355X_MICROARCH.md)
 
@@ -69,7 +69,7 @@ def _load_counters(name: str, workload: str):
     """A committed rocprofv3 PMC summary (profiles/<name>) -- returned ONLY if it was recorded for the kernel build
     being timed (its `kernel_source_sha16` equals this build's) and for this workload: counters of another build
     say nothing about this one, and PMC counters cannot be read from inside this process."""
-    for rnd in ("r05", "r04", "r03", "r02"):  # the newest round's file first
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):  # the newest round's file first
         path = os.path.join(ROOT, "profiles", name.replace("RND", rnd))
         try:
             d = json.load(open(path))
@@ -103,15 +103,32 @@ def valu_view(envs_per_gpu: int, avg_kernel_s: float, workload: str = "fast"):
     # valu_issue = that floor / the measured launch duration.  `valu_issue_if_32bit_at_2_cycles` prices the instructions that
     # are neither f64 nor cross-lane at 2 cycles -- a bound the microbenchmark says these kernels cannot reach, kept for scale.
     # (the committed counters are sums over a launch / environments: per env-step, whatever the wavefronts per environment)
-    trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
-    cycles = 4.0 * c["SQ_INSTS_VALU"] + 12.0 * trans
+    trans = c.get("SQ_INSTS_VALU_TRANS_F64")  # (None -- not 0 -- where a summary lacks the counter: the floor is then the 4-cycle one)
+    cycles_v1 = 4.0 * c["SQ_INSTS_VALU"]     # rounds 2-4: every VALU instruction 4 cycles (`valu_issue_4cyc`)
+    cycles = cycles_v1 + 12.0 * (trans or 0.0)
+    # ANY-instruction issue (round 6): a wavefront issues at most one instruction of ANY class per 4 cycles (dependent or not:
+    # profiles/r06_issue_costs.json), so with <= 2 wavefronts per SIMD -- configs 3 and 4 -- what bounds a launch is the slowest
+    # wavefront's own instruction stream, not the SIMD's VALU: issue_any = 4 x SQ_ACTIVE_INST_ANY cycles per wavefront / 2.4 GHz over
+    # the launch duration (and over the mean wavefront's life, SQ_WAVE_CYCLES).  `binding_issue_limit` names the larger of the two.
+    any_inst = c.get("SQ_ACTIVE_INST_ANY")
+    wps = d.get("waves_per_simd")
+    issue_any = (4.0 * any_inst / CLOCK_HZ / avg_kernel_s) if any_inst else None
     issue_floor_s = cycles * envs_per_gpu / (SIMDS * CLOCK_HZ)
-    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + trans
+    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + (trans or 0.0)
     narrow = max(0.0, c["SQ_INSTS_VALU"] - f64 - c.get("SQ_INSTS_VALU_INT64", 0.0) - c.get("SQ_INSTS_VALU_CVT", 0.0))
     optimistic_s = (cycles - 2.0 * narrow) * envs_per_gpu / (SIMDS * CLOCK_HZ)
     wait = c.get("SQ_WAIT_ANY")
     return {"f64_flop_per_launch": flop, "achieved": achieved, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved / 78.6,
             "valu_issue": issue_floor_s / avg_kernel_s, "valu_issue_floor_us": issue_floor_s * 1e6,
+            "valu_issue_method_version": 2,  # 1 (rounds 2-4) = `valu_issue_4cyc` below; 2 (round 5 on) adds 12 cycles per f64 transcendental
+            "valu_issue_4cyc": cycles_v1 * envs_per_gpu / (SIMDS * CLOCK_HZ) / avg_kernel_s,
+            "issue_any": issue_any,
+            "issue_any_of_mean_wavefront_life": (any_inst / c["SQ_WAVE_CYCLES"]) if any_inst else None,
+            "issue_any_method": "4 x SQ_ACTIVE_INST_ANY cycles per wavefront / 2.4 GHz / avg_kernel_us (one wavefront's own issue port)",
+            "binding_issue_limit": (None if issue_any is None else
+                                    "issue_any (one wavefront's own stream)" if issue_any > issue_floor_s / avg_kernel_s else
+                                    "valu_issue (the SIMD's VALU port, shared by its wavefronts)"),
+            "waves_per_simd": wps,
             "valu_issue_method": (f"(4 x SQ_INSTS_VALU + 12 x SQ_INSTS_VALU_TRANS_F64) cycles per env-step x {envs_per_gpu} envs / "
                                   f"({SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz) / avg_kernel_us; per-class costs measured: "
                                   "profiles/r05_issue_costs.json"),
@@ -299,6 +316,67 @@ def cpu_baseline_intersection(cfg_dict, budget_s: float = 30.0):
             "vehicle_slots": cfg.num_vehicles}
 
 
+FRONTEND_IDS = {"fast": "highway-fast-v0", "v0": "highway-v0", "v0_n100": "highway-v0", "v0_n200": "highway-v0", "merge": "merge-v0",
+                "merge_ma4": "merge-generic-v0", "intersection": "intersection-v0", "intersection_kin": "intersection-v0"}
+
+
+def frontend_view(workload: str, cfg_dict: dict, E: int, device: int, steps: int = 300, warm: int = 200) -> dict:
+    """The drop-in boundary as a USER sees it ("wall-clock around the Python step()"; the reference's seam is
+    AbstractEnv.step, envs/common/abstract.py:259-285): the same workload stepped through the package's Python classes, wall clock
+    per step() call over `steps` calls after `warm` (the engine picks its issue-priority turn there), synchronised at both ends.
+      batched_numpy  -- Batched*Env.step(numpy actions [E]) -> numpy outputs: H2D actions, the launch, ONE D2H copy of the packed
+                        outputs, per step (device spawn + auto-reset, like the headline)
+      vector_torch   -- HighwayVectorEnv(output="torch").step(int32 device tensor) -> torch views of the engine's output planes:
+                        the device-pointer path behind the gymnasium.vector interface, run on the engine's own stream
+    Never part of `value`."""
+    import torch
+    from highwayenv_amd import envs as _envs
+    from highwayenv_amd.vector import HighwayVectorEnv
+    out = {"workload": workload, "envs": E, "steps": steps, "unit": "us per step() call (wall clock)"}
+    env_id = FRONTEND_IDS[workload]
+    n_act = 3 if "intersection" in workload else 5
+    try:
+        cls = _envs.batched_class(env_id)
+        env = cls(dict(cfg_dict), num_envs=E, device=device, spawn_mode="device", autoreset=True)
+        env.reset(seed=0)
+        A = env._hcfg.num_agents
+        acts = np.random.default_rng(7).integers(0, n_act, size=(steps + warm, E, A)).astype(np.int32)
+        for t in range(warm):
+            env.step(acts[t])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for t in range(warm, warm + steps):
+            env.step(acts[t])
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out["batched_numpy"] = {"class": cls.__name__, "us_per_step": dt / steps * 1e6, "env_steps_per_s": steps * E / dt}
+        env.close()
+    except Exception as ex:  # a front end that cannot run must not cost the headline its line
+        out["batched_numpy"] = {"error": repr(ex)}
+    try:
+        lane = torch.cuda.Stream(device=device)
+        venv = HighwayVectorEnv(env_id, num_envs=E, config=dict(cfg_dict), output="torch", device=device, stream=lane)
+        venv.reset(seed=0)
+        A = venv.env._hcfg.num_agents
+        acts_d = torch.randint(0, n_act, (steps + warm, E, A) if A > 1 else (steps + warm, E), device=f"cuda:{device}", dtype=torch.int32)
+        torch.cuda.synchronize(device)
+        with torch.cuda.stream(lane):
+            for t in range(warm):
+                venv.step(acts_d[t])
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for t in range(warm, warm + steps):
+                venv.step(acts_d[t])
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+        out["vector_torch"] = {"class": "HighwayVectorEnv(output='torch')", "us_per_step": dt / steps * 1e6,
+                               "env_steps_per_s": steps * E / dt}
+        venv.close()
+    except Exception as ex:
+        out["vector_torch"] = {"error": repr(ex)}
+    return out
+
+
 def workload_config(workload: str):
     """(cfg_dict, fast, scenario) of a --workload, in the reference's config vocabulary."""
     from highwayenv_amd import _abi
@@ -380,7 +458,7 @@ def secondary_workloads(steps: int = 200, repeats: int = 3, budget_s: float = 10
             out[argv[1]] = {"workload": name, "error": f"skipped: the {budget_s:.0f} s budget of the secondary legs was spent"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), *argv, "--steps", str(steps), "--repeats", str(repeats), "--warmup", "20",
-               "--settle-ms", "100", "--no-cpu-baseline", "--no-secondary", "--rollout-k", "0"]
+               "--settle-ms", "100", "--no-cpu-baseline", "--no-secondary", "--no-frontend", "--rollout-k", "0"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left)
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -476,6 +554,11 @@ def main(argv=None, platform=None, emit=None):
                          "round-robin: the tail of one sub-batch's launch overlaps the body of the next one's), reported as "
                          "`split_batch_sS` next to the headline.  Off by default: its launches carry the headline kernel's name, "
                          "so they would mix into a rocprofv3 --stats average of the default command")
+    ap.add_argument("--shape", default=None, metavar="VEHICLES,LANES",
+                    help="developer knob: another traffic size / lane count for --workload fast (e.g. 20,3 = BASELINE config 1's shape "
+                         "batched); the line's config.workload says so.  Never the headline.")
+    ap.add_argument("--no-frontend", action="store_true",
+                    help="skip the `frontend` legs (the Python classes a user of the reference switches to, timed on the same workload)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N=1, --workload fast only: skip the short legs on BASELINE's other single-GPU configurations (config 3's "
                          "per-GPU shard, config 4, config 5) that are reported NEXT TO the headline as `secondary_workloads`")
@@ -486,6 +569,9 @@ def main(argv=None, platform=None, emit=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_only:
         raise SystemExit(self_launch(sys.argv[1:] if argv is None else list(argv), args.gpus))
     tuning = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.tune}
+    if args.shape:
+        global VEHICLES_COUNT, LANES
+        VEHICLES_COUNT, LANES = (int(x) for x in args.shape.split(","))
     TUNE_IN_EFFECT.clear()
     TUNE_IN_EFFECT.update(tuning)
     cfg_dict, fast, scenario = workload_config(args.workload)
@@ -615,7 +701,8 @@ def main(argv=None, platform=None, emit=None):
     fence()
     # HIP events on every 8th launch of the timed regions: the engine hands the pair to hipExtLaunchKernelGGL, which records the
     # DISPATCH's own begin / end timestamps into them (the clock readings rocprofv3 --kernel-trace reports) on the launch stream
-    eng.profile_enable(0 if os.environ.get("HWY_BENCH_NO_EVENTS") == "1" else EVENT_EVERY)
+    # (the timed regions carry NO events since round 6; the kernel's own duration is measured after them, see below)
+    prio_turn, prio_state = eng.prio_turn()   # chosen during the warm-up launches (hwy_get_prio_turn)
     region_s, region_dev_ms = [], []
     for r in range(R):
         t_first = args.warmup + r * args.steps
@@ -635,8 +722,20 @@ def main(argv=None, platform=None, emit=None):
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         region_s.append(el.item())
     elapsed = float(np.median(region_s))
-    kernel_ms, launches = eng.profile_read()
-    eng.profile_enable(0)
+    # The dominant kernel's own duration: one more (untimed) region of the same loop in which EVERY launch carries the HIP event pair
+    # hipExtLaunchKernelGGL fills with the dispatch's begin / end timestamps -- what rocprofv3 --kernel-trace reports, under the
+    # same condition (every dispatch signalled).  Rounds 1-5 sampled every 8th launch of the timed regions: the sampled launches
+    # alone were serialised against their neighbours, which made their average exceed the step they are part of (41.50 us against a
+    # 40.96 us device step).
+    kernel_ms, launches = 0.0, 0
+    if os.environ.get("HWY_BENCH_NO_EVENTS") != "1":
+        n_k = min(args.steps, 1000)
+        eng.profile_enable(EVENT_EVERY)
+        for t in range(args.warmup, args.warmup + n_k):
+            one_step(t)
+        fence()
+        kernel_ms, launches = eng.profile_read()
+        eng.profile_enable(0)
     # N > 1: the same loop with ONE gather per step (what a policy that needs every step's outputs on rank 0 before it can
     # act would see), reported next to the batched number
     per_step_gather = None
@@ -801,7 +900,12 @@ def main(argv=None, platform=None, emit=None):
                        "envs_per_gpu": E, "vehicles_per_env": N, "parallelism": f"env-sharded x{world}",
                        "gather": (f"one RCCL gather of every rank's (obs, reward, done) blocks to rank 0 per {K} steps"
                                   if use_dist else "none (single rank)"),
-                       "world_size_reported_by_the_process_group": dist.get_world_size() if use_dist else 1},
+                       "world_size_reported_by_the_process_group": dist.get_world_size() if use_dist else 1,
+                       "issue_priority_turn": {"turn": prio_turn, "unit": ("off" if prio_turn <= 0 else "2^k clock ticks" if prio_turn <= 30
+                                                                            else "k x 64 clock ticks"),
+                                               "chosen_by": ("--tune prio_shift" if "prio_shift" in tuning else
+                                                             {0: "scenario default (no selection: turns off or not applicable)",
+                                                              1: "engine, still sampling", 2: "engine (timed its first launches)"}[prio_state])}},
             "gather_every_1": per_step_gather,
             f"rollout_k{args.rollout_k}": rollout,
             **({f"split_batch_s{args.split_batch}": split} if split else {}),
@@ -817,8 +921,9 @@ def main(argv=None, platform=None, emit=None):
                                     "102 / 128-VGPR code)" if N <= 64 else
                                     f"hwy_step_wide_kernel<{(N + 63) // 64},{2 if N <= 128 else 1}>  (one 64-wide wavefront per env, {(N + 63) // 64} vehicles per thread)" if wide_kernel_runs(N) else
                                     f"hwy_step_kernel<{(N + 63) // 64},WPE>  ({(N + 63) // 64} wavefronts per env)"), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches, "timed_every": EVENT_EVERY,
-                         "avg_kernel_us_method": ("mean over the HIP start/stop events hipExtLaunchKernelGGL fills with the dispatch's own "
-                                                  "timestamps (unclamped)" if event_kernel_s else "wall ms_per_step (no events)"),
+                         "avg_kernel_us_method": ("mean over ALL launches of a separate region after the timed ones, each carrying the HIP "
+                                                  "start/stop events hipExtLaunchKernelGGL fills with the dispatch's own timestamps "
+                                                  "(unclamped)" if event_kernel_s else "wall ms_per_step (no events)"),
                          "event_kernel_us": (kernel_ms / launches * 1e3) if launches else None,
                          "event_exceeds_wall_step": bool(event_kernel_s and event_kernel_s > wall_step_s * 1.02),
                          "algorithmic_bytes_per_launch": b_env * E,
@@ -828,6 +933,8 @@ def main(argv=None, platform=None, emit=None):
             "ix_spawn_counters": (lambda c: dict(c, drop_rate=c["ix_spawns_dropped"] / max(1, c["ix_spawns"] + c["ix_spawns_dropped"])))(eng.counters()) if scenario == "intersection" else None,
             "host_path_env_steps_per_s": host_rate,
         }
+        if world == 1 and not args.no_frontend:
+            line["frontend"] = frontend_view(args.workload, cfg_dict, E, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, cfg_dict, fast, scenario)
         if world == 1 and args.workload == "fast" and not args.no_secondary and not tuning:

@@ -18,7 +18,7 @@ EXPORTS = [
     "hwy_abi_version", "hwy_config_size", "hwy_device_count", "hwy_status_string", "hwy_create",
     "hwy_destroy", "hwy_last_error", "hwy_set_state", "hwy_get_state", "hwy_reset", "hwy_step",
     "hwy_step_device", "hwy_rollout_device", "hwy_rollout", "hwy_step_frames", "hwy_observe", "hwy_set_autoreset", "hwy_sync",
-    "hwy_profile_enable", "hwy_profile_read", "hwy_debug_math", "hwy_get_counters", "hwy_set_block_order",
+    "hwy_profile_enable", "hwy_profile_read", "hwy_get_prio_turn", "hwy_debug_math", "hwy_get_counters", "hwy_set_block_order",
     "hwy_comm_unique_id", "hwy_comm_init", "hwy_gather", "hwy_comm_destroy",
 ]
 
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
     lib.hwy_comm_destroy.argtypes = [vp]
     lib.hwy_profile_enable.argtypes = [vp, i32]
     lib.hwy_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.hwy_get_prio_turn.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.hwy_get_prio_turn.restype = C.c_int
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name.startswith(("hwy_create", "hwy_destroy", "hwy_set", "hwy_get", "hwy_reset",

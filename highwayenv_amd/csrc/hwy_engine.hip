@@ -73,6 +73,17 @@ struct hwy_engine {
   size_t events_used = 0;
   double prof_ms = 0.0;
   int64_t prof_launches = 0;
+  // self-selection of the issue-priority turn (hwy_config.tune_prio_shift == 0 and turns apply): the first full-step launches are
+  // timed with the dispatch's own timestamps, the candidates interleaved (drift of the workload cancels), the best one is kept
+  struct TurnTuner {
+    enum { IDLE = 0, SAMPLING = 1, DONE = 2 };
+    int state = IDLE, stage = 0, launches = 0;
+    int cand[5] = {0, 0, 0, 0, 0};
+    double ms[5] = {0, 0, 0, 0, 0};
+    int n[5] = {0, 0, 0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<int> which;
+  } tuner;
   hwy::Comm *comm = nullptr;  // hwy_comm_init
   std::string err;
 };
@@ -91,6 +102,54 @@ static thread_local std::string g_create_error;
 static int fail(hwy_engine *eng, int code, const std::string &msg) {
   if (eng) eng->err = msg; else g_create_error = msg;
   return code;
+}
+
+// ---- the engine picks the length of an issue-priority turn itself ---------------------------------------------------------------
+// Scheduling only: no result depends on the turn (tests/test_engine_parity.py compares turn variants bit for bit).
+// Candidates: 0.75 / 0.875 / 1 / 1.125 / 1.25 x the scenario default, in units of 64 clock ticks (the linear encoding of
+// tune_prio_shift), visited round-robin over the first (HWY_TUNE_ROUNDS + 1) x 5 full-step launches, each timed by the dispatch's own
+// begin / end timestamps (hipExtLaunchKernelGGL: the events of hwy_profile_*); one synchronisation at the end of a stage.  If the
+// best candidate sits at an end of the range, one more stage is centred there (at most HWY_TUNE_STAGES).  While hwy_profile_enable
+// is on the tuner pauses.
+#define HWY_TUNE_ROUNDS 16
+#define HWY_TUNE_STAGES 3
+static int turn_in_ticks64(int turn) {  // the linear unit of either encoding (0 = not expressible: a turn below 64 x 64 ticks)
+  if (turn >= 64) return turn;
+  if (turn >= 12 && turn <= 26) return 1 << (turn - 6);
+  return 0;
+}
+static void tuner_arm(hwy_engine *eng, int centre_turn) {
+  auto &t = eng->tuner;
+  const int k = turn_in_ticks64(centre_turn);
+  if (k < 64) { t.state = hwy_engine::TurnTuner::DONE; return; }
+  static const int eighths[5] = {6, 7, 8, 9, 10};
+  for (int c = 0; c < 5; ++c) {
+    t.cand[c] = std::min(std::max(64, k * eighths[c] / 8), 1 << 20);
+    t.ms[c] = 0.0;
+    t.n[c] = 0;
+  }
+  t.launches = 0;
+  t.which.clear();
+  t.state = hwy_engine::TurnTuner::SAMPLING;
+}
+static int tuner_finish_stage(hwy_engine *eng) {
+  auto &t = eng->tuner;
+  HWY_HIP(eng, hipStreamSynchronize(eng->stream));
+  for (size_t k = 0; k < t.which.size(); ++k) {
+    float ms = 0;
+    HWY_HIP(eng, hipEventElapsedTime(&ms, t.events[k].first, t.events[k].second));
+    if (k < 5) continue;  // the first round: every candidate's first launch follows another turn's launch pattern
+    t.ms[t.which[k]] += ms;
+    t.n[t.which[k]]++;
+  }
+  int best = 2;
+  for (int c = 0; c < 5; ++c)
+    if (t.n[c] > 0 && t.n[best] > 0 && t.ms[c] / t.n[c] < t.ms[best] / t.n[best]) best = c;
+  eng->prio_shift = t.cand[best];
+  const bool at_end = (best == 0 && t.cand[0] > 64) || (best == 4 && t.cand[4] < (1 << 20));
+  if (at_end && ++t.stage < HWY_TUNE_STAGES) tuner_arm(eng, t.cand[best]);
+  else t.state = hwy_engine::TurnTuner::DONE;
+  return HWY_OK;
 }
 
 extern "C" int hwy_abi_version(void) { return HWY_ABI_VERSION; }
@@ -191,8 +250,7 @@ static void fill_params(const hwy_engine *eng, StepParams &p) {
   p.autoreset = eng->autoreset;
   p.rp = eng->rp;
   p.grid_ws = eng->d_grid_ws;
-  p.prio_shift = eng->prio_shift;
-  p.prio_recip = eng->prio_shift >= 64 ? (uint32_t)(0x100000000ull / (unsigned long long)eng->prio_shift) : 0u;
+  hwy::set_prio_turn(p, eng->prio_shift);
   p.block_env = eng->d_block_env;
   p.counters = eng->d_counters;
 }
@@ -411,7 +469,12 @@ extern "C" int hwy_create(const hwy_config *cfg, int device, void *stream, hwy_e
       turn = std::max(64, 256 * cfg->frames_per_step / 5);
     else if (cfg->scenario == HWY_SCENARIO_MERGE_GENERIC)
       turn = std::max(64, 832 * cfg->frames_per_step / 15);
+    if (turn >= 64) turn = std::min(turn, 1 << 20);  // (the validated range of the linear encoding, whatever frames_per_step is)
     eng->prio_shift = (resident > 0 && cfg->num_envs <= resident) ? turn : 0;
+    // The optimum is sharp and depends on (envs, vehicles, frames) -- profiles/r05_history.md section 10: up to 7 % between neighbours --
+    // and the defaults above were swept on BASELINE's shapes only: the engine refines its own choice on its first launches
+    // (tuner_*: below).  An explicit tune_prio_shift (> 0, or -1 = off) is never touched.
+    if (eng->prio_shift > 0) tuner_arm(eng, eng->prio_shift);
   }
   *out = eng;
   return HWY_OK;
@@ -423,6 +486,7 @@ extern "C" int hwy_destroy(hwy_engine *eng) {
   if (eng->stream) (void)hipStreamSynchronize(eng->stream);
   if (eng->comm) { hwy::comm_destroy(eng->comm); eng->comm = nullptr; }
   for (auto &pr : eng->events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto &pr : eng->tuner.events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   void *ptrs[] = {eng->d_f64, eng->d_packed, eng->d_time, eng->d_done, eng->d_episode, eng->d_actions, eng->d_out, eng->d_roll,
                   eng->d_mask, eng->d_seeds, eng->d_grid_ws, eng->d_route, eng->d_road_steps, eng->d_gnet,
                   eng->d_shadow_f64, eng->d_shadow_packed, eng->d_shadow_route, eng->d_shadow_meta, eng->d_counters, eng->d_block_env};
@@ -565,7 +629,28 @@ extern "C" int hwy_get_state(hwy_engine *eng, hwy_state *h) {
 }
 
 // ---- kernel timing ----------------------------------------------------------------------------------
+static hipError_t launch_step_any(const hwy_engine *eng, const StepParams &p);
 static int timed_launch(hwy_engine *eng, const StepParams &p) {
+  auto &tn = eng->tuner;
+  if (tn.state == hwy_engine::TurnTuner::SAMPLING && !eng->profiling && p.full_step) {
+    const int c = tn.launches % 5;
+    if (tn.events.size() <= (size_t)tn.launches) {
+      hipEvent_t a, b;
+      HWY_HIP(eng, hipEventCreate(&a));
+      HWY_HIP(eng, hipEventCreate(&b));
+      tn.events.emplace_back(a, b);
+    }
+    StepParams q = p;
+    hwy::set_prio_turn(q, tn.cand[c]);
+    auto &pr = tn.events[tn.launches];
+    hwy::set_launch_events(pr.first, pr.second);
+    const hipError_t err = launch_step_any(eng, q);
+    hwy::set_launch_events(nullptr, nullptr);
+    HWY_HIP(eng, err);
+    tn.which.push_back(c);
+    if (++tn.launches == 5 * (HWY_TUNE_ROUNDS + 1)) return tuner_finish_stage(eng);
+    return HWY_OK;
+  }
   if (!eng->profiling || (eng->launch_counter++ % eng->profiling) != 0) {
     HWY_HIP(eng, launch_step_any(eng, p));
     return HWY_OK;
@@ -592,6 +677,12 @@ static int drain_events(hwy_engine *eng) {
     eng->prof_launches++;
   }
   eng->events_used = 0;
+  return HWY_OK;
+}
+extern "C" int hwy_get_prio_turn(hwy_engine *eng, int32_t *turn, int32_t *state) {
+  if (!eng) return HWY_ERR_INVALID_ARG;
+  if (turn) *turn = eng->prio_shift;
+  if (state) *state = eng->tuner.state;
   return HWY_OK;
 }
 extern "C" int hwy_profile_enable(hwy_engine *eng, int32_t enabled) {

@@ -14,6 +14,13 @@
 
 namespace hwy {
 
+// The length of an issue-priority turn in either encoding of hwy_config.tune_prio_shift (1..30: 2^k clock ticks; >= 64: k x 64 ticks,
+// evaluated with a multiply-high by floor(2^32 / k)): the ONLY place the pair (shift, reciprocal) is formed, so the two cannot
+// diverge (a shift >= 64 with a zero reciprocal would be a 64-bit shift by >= 64 in wave_turn).
+inline void set_prio_turn(StepParams &p, int turn) {
+  p.prio_shift = turn > 0 ? turn : 0;
+  p.prio_recip = turn >= 64 ? (uint32_t)(0x100000000ull / (unsigned long long)turn) : 0u;
+}
 inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   std::memset(&p, 0, sizeof p);
   p.N = c.num_vehicles; p.A = c.num_agents; p.L = c.lanes_count; p.T = c.frames_per_step;
@@ -33,8 +40,7 @@ inline void params_from_config(const hwy_config &c, int pitch, StepParams &p) {
   p.inv_lane_width = 1.0 / p.lane_width;
   p.inv_rx = 1.0 / (p.rx1 - p.rx0); p.inv_ry = 1.0 / (p.ry1 - p.ry0);
   p.inv_rvx = 1.0 / (p.rvx1 - p.rvx0); p.inv_rvy = 1.0 / (p.rvy1 - p.rvy0);
-  p.prio_shift = c.tune_prio_shift > 0 ? c.tune_prio_shift : 0;  // the engine turns the default on where it pays (hwy_create)
-  p.prio_recip = 0;
+  set_prio_turn(p, c.tune_prio_shift > 0 ? c.tune_prio_shift : 0);  // the engine turns the default on where it pays (hwy_create)
   p.obs_type = c.obs_type;
   p.obs_std5 = c.obs_type == HWY_OBS_KINEMATICS && c.obs_features == 5;
   for (int f = 0; f < 5; ++f) p.obs_std5 = p.obs_std5 && c.obs_feature_ids[f] == f;  // presence, x, y, vx, vy

@@ -219,6 +219,13 @@ class Engine:
         self._check(self._lib.hwy_profile_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def prio_turn(self):
+        """(turn, state) of hwy_get_prio_turn: the issue-priority turn in use (tune_prio_shift's encoding) and whether the engine
+        chose it itself (0 = no selection, 1 = still sampling its first launches, 2 = chosen)."""
+        turn, state = C.c_int32(), C.c_int32()
+        self._check(self._lib.hwy_get_prio_turn(self._h, C.byref(turn), C.byref(state)))
+        return turn.value, state.value
+
 
 def device_count() -> int:
     return _lib.load().hwy_device_count()

@@ -454,6 +454,17 @@ int hwy_profile_enable(hwy_engine *eng, int32_t enabled);
 int hwy_profile_read(hwy_engine *eng, double *total_ms, int64_t *launches);
 
 /*
+ * The issue-priority turn in use (the encoding of hwy_config.tune_prio_shift: 0 = none, 1..30 = 2^k clock ticks, >= 64 = k x 64
+ * ticks) and the state of the engine's own selection: with tune_prio_shift == 0 and a scenario whose wavefronts take turns, the
+ * engine times its first 85 full-step launches per stage (five turn lengths around the scenario default, interleaved; the dispatch
+ * timestamps of hwy_profile_*) and keeps the fastest -- scheduling only, no result depends on it.  state: 0 = no selection (explicit
+ * value, turns off, or a kernel without turns), 1 = still sampling, 2 = chosen.  The reference has no counterpart (a CPU
+ * single-thread loop: envs/common/abstract.py:287-317); this is the knob a `configure()`d shape other than BASELINE's needs
+ * (envs/highway_env.py:25-53).
+ */
+int hwy_get_prio_turn(hwy_engine *eng, int32_t *turn, int32_t *state);
+
+/*
  * Multi-GPU, one process (and one engine) per GPU.  The reference's only vectorisation is gymnasium's process-level
  * vector env (tests/envs/test_gym.py:158-165); here the environments are block-partitioned over the engines of a node,
  * nothing is exchanged while stepping, and the per-step (obs | reward | done) blocks of every rank are gathered to a root

@@ -14,6 +14,7 @@ wl_args() {
   case $1 in
     fast) echo "--workload fast --envs-per-gpu 4096";;
     fast[0-9]*) echo "--workload fast --envs-per-gpu ${1#fast}";;
+    cfg1) echo "--workload fast --envs-per-gpu 4096 --shape 20,3";;
     v0) echo "--workload v0 --envs-per-gpu 4096";;
     cfg3) echo "--workload v0_n100 --envs-per-gpu 1024";;
     n200) echo "--workload v0_n200 --envs-per-gpu 1024";;
@@ -30,7 +31,7 @@ for rep in $(seq 1 $REPS); do
       name=${V%%:*}; tune=""
       if [ "$V" != "$name" ]; then for t in $(echo ${V#*:} | tr ',' ' '); do tune="$tune --tune $t"; done; fi
       if [ "$name" = "-" ]; then unset HWY_ENGINE_LIB; else export HWY_ENGINE_LIB=$B/libhwy_engine_$name.so; fi
-      timeout 300 python bench.py $(wl_args $W) --no-cpu-baseline --no-secondary --rollout-k 0 --steps ${STEPS:-300} --repeats 3 $tune "$@" \
+      timeout 300 python bench.py $(wl_args $W) --no-cpu-baseline --no-secondary --no-frontend --rollout-k 0 --steps ${STEPS:-300} --repeats 3 $tune "$@" \
         > "$O/${W}_$(echo $V | tr ':=,' '___')_$rep.json" 2>> $O/err.txt
     done
   done
@@ -40,11 +41,13 @@ python - "$O" <<'PY'
 import json, glob, os, sys, collections, statistics
 O = sys.argv[1]
 rows = collections.defaultdict(list)
+turns = {}
 for f in sorted(glob.glob(O + "/*_[0-9]*.json")):
     key = os.path.basename(f).rsplit("_", 1)[0]
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         rows[key].append((d["ms_per_step"] * 1e3, d.get("ms_per_step_device", 0) * 1e3, d["roofline"]["avg_kernel_us"]))
+        turns[key] = d["config"].get("issue_priority_turn", {}).get("turn")
     except Exception as ex:
         rows[key].append(None)
 for key, v in rows.items():
@@ -53,5 +56,5 @@ for key, v in rows.items():
         print(f"{key:44s} unreadable")
         continue
     med = [statistics.median(c) for c in zip(*ok)]
-    print(f"{key:44s} wall {med[0]:8.2f}  device {med[1]:8.2f}  kernel {med[2]:8.2f} us   runs " + " ".join(f"{x[0]:.2f}" for x in ok))
+    print(f"{key:44s} wall {med[0]:8.2f}  device {med[1]:8.2f}  kernel {med[2]:8.2f} us   turn {turns.get(key)}  runs " + " ".join(f"{x[0]:.2f}" for x in ok))
 PY

@@ -167,8 +167,8 @@ def ix_ticks(text):
             "#define IXTICK(k) { if (threadIdx.x == 0) { const long long t_ = clock64(); sh.tk[k] += t_ - sh.tprev; sh.tprev = t_; } }\n"
             "// ---- lane geometry from the LDS table, per-thread lane index")(t)
     # inside the table walk: [11] = prologue + straight lanes, [12] = exchange + arcs, the final exchange stays in [5]
-    t = sub("  {\n    int none = 0;\n    ix_xchg(sh, bd, best, none);", "  IXTICK(11)\n  {\n    int none = 0;\n    ix_xchg(sh, bd, best, none);")(t)
-    t = sub("  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);\n  *bits_out", "  IXTICK(12)\n  ix_xchg(sh, bd, best, bits, &lat_t, has_lat);\n  *bits_out")(t)
+    t = sub("  ix_group_min(mp, bd, best);  // the arcs are filtered", "  IXTICK(11)\n  ix_group_min(mp, bd, best);  // the arcs are filtered")(t)
+    t = sub("  // the straight walk's membership bits and target-lane coordinate join the arcs' per slot\n", "  IXTICK(12)\n")(t)
     # inside the regulation: [13] = samples + circles, the partner loop stays in [3]
     t = sub("      // is_conflict_possible (regulation.py:88-111) + respect_priorities", "      IXTICK(13)\n      // is_conflict_possible (regulation.py:88-111) + respect_priorities")(t)
     t = sub("    // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act", "    IXTICK(fr == 0 ? 0 : 6)\n    // ---- A. meta-action (abstract.py:294-304 -> MDPVehicle.act")(t)

@@ -7,3 +7,6 @@
 namespace hwy {
 template __global__ void hwy_step_wide_kernel<2, 2>(const StepParams);
 }
+namespace hwy {
+template __global__ void hwy_step_wide_kernel<2, 1>(const StepParams);
+}
