@@ -1369,7 +1369,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
           int r = 0;
           double tx = 0, ty = 0;
           // conservative reject first (never drops a pair the exact pre-check of objects.py:124-127 keeps):
-          // the SAT routine is a real function call and is only reached by vehicles within ~5.5 m + |v| dt
+          // the SAT routine (inlined: ~220 instructions) is only reached by vehicles within ~5.5 m + |v| dt
           bool near = false;
           if (active && i != c) {
             const double dx = sh.x[c] - me.x, dy = sh.y[c] - me.y;

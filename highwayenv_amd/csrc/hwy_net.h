@@ -1063,7 +1063,8 @@ __device__ __forceinline__ void net_policy_step(const NetParams &np, NetShared &
     net_observe<GRID>(np, sh, e, eo, me, true, (!GRID && p.n_frames > 0 && !has_tie) ? rank : -1);
   }
   {
-    me.rank = rank & 0xff;  // the hint the next step verifies
+    // the hint the next step verifies; a call without frames (hwy_step_frames(0), hwy_observe) never formed one and keeps the old one
+    if (p.n_frames > 0) me.rank = rank & 0xff;
     store_vehicle<1>(p, e, me, false);
   }
 }

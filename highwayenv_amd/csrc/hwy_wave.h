@@ -416,7 +416,7 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       sh.idx[rank] = i;
     }
     HWY_WAVE_LDS_FENCE();
-    const u64 m_own = sh.lane_mask[me.lane + 1], m_left = sh.lane_mask[me.lane], m_right = sh.lane_mask[me.lane + 2];
+    const u64 m_own = sh.lane_mask[me.lane + 1];  // (the side lanes' masks are read by the compacted MOBIL tasks)
     const u64 m_tgt = sh.lane_mask[me.tgt + 1];
 
     wave_turn(turn);
@@ -432,81 +432,155 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
     // neighbours: ranks on own / left / right / target lane (bit scans), or the literal scan on ties
     int fo = -1, ro = -1, fl = -1, rl = -1, frt = -1, rrt = -1, ft = -1, rt_ = -1;
     const bool left_ok = me.lane - 1 >= 0, right_ok = me.lane + 1 < p.L;
-    if (!has_tie) {
-      mask_neighbours(m_own, rank, &fo, &ro);
-      mask_neighbours(m_left, rank, &fl, &rl);
-      mask_neighbours(m_right, rank, &frt, &rrt);
-      mask_neighbours(m_tgt, rank, &ft, &rt_);
-    } else {
-      // literal scans return vehicle INDICES; convert to ranks through the (just written) table
-      int a, b;
-      wave_neighbours_scan(p, me.x, me.x, me.y, i, me.lane, &a, &b);
-      fo = a; ro = b;
-      wave_neighbours_scan(p, me.x, me.x, me.y, i, left_ok ? me.lane - 1 : me.lane, &a, &b);
-      fl = a; rl = b;
-      wave_neighbours_scan(p, me.x, me.x, me.y, i, right_ok ? me.lane + 1 : me.lane, &a, &b);
-      frt = a; rrt = b;
-      wave_neighbours_scan(p, me.x, me.x, me.y, i, me.tgt, &a, &b);
-      ft = a; rt_ = b;
-      // index -> rank: rank_of[j] == the rank lane j computed
-      const int r_fo = fo, r_fl = fl, r_fr = frt, r_ft = ft, r_rl = rl, r_rr = rrt;
-      int rk;
-      fo = fl = frt = ft = rl = rrt = -1;
-      for (int j = 0; j < N; ++j) {
-        rk = wave_bcast_i(rank, j);
-        fo = (r_fo == j) ? rk : fo; fl = (r_fl == j) ? rk : fl; frt = (r_fr == j) ? rk : frt;
-        ft = (r_ft == j) ? rk : ft; rl = (r_rl == j) ? rk : rl; rrt = (r_rr == j) ? rk : rrt;
-      }
-    }
-    // gather the leaders' bodies (rank-ordered snapshot => one LDS trip); all issued together
-    const int g_fo = fo < 0 ? 0 : fo, g_fl = fl < 0 ? 0 : fl, g_fr = frt < 0 ? 0 : frt;
-    const double fo_x = sh.x[g_fo], fo_v = sh.v[g_fo], fo_c = sh.c[g_fo], fo_s = sh.s[g_fo];
-    const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
-    const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
-
-    // Straight-line (branch-free) evaluation for every lane: a wavefront pays for a branch as soon as one
-    // lane takes it, and nearly every frame some vehicle drives / decides, so predication costs nothing
-    // extra while giving the scheduler one large block of independent f64 chains to interleave.
     const double delta = sh.delta[i];
     const double free_self = B::idm_free_from_log(log_ratio, delta);
-    const double gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
-    // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
-    // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
-    const double self_a = free_self - gap_own;
     const bool moving = !(fabs(me.v) < 1);
     const bool cl = decide && left_ok && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
     const bool cr = decide && right_ok && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
-    const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
-    const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
-    bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
-    bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
-    // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED.
-    // Evaluated only for candidates that passed the (pow-free) incentive test, one side per pass (a
-    // vehicle that needs both sides checked -- rare -- takes a second pass); the follower's log speed
-    // ratio comes from the snapshot, so the test costs one exp and one gap term.
-    {
-      bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
-      while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
-        const bool pend = pend_l || pend_r;
-        const bool left = pend_l;
-        const int rf = pend ? (left ? rl : rrt) : 0;
-        const double lr_f = sh.lr[rf];
-        const double g = B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
-        // a_f = 3 (1 - E) - g with E = exp(delta * lr_f) >= 0, so a_f <= 3 - g: g beyond 5 is unsafe whatever E is; and a
-        // follower below its target speed (lr_f < 0, delta > 0) has E <= 1 (+ an ulp), so a_f >= -g: g below 2 is safe
-        // whatever E is.  Both with a 1e-6 margin, far above any rounding of the three operations involved -- the verdicts
-        // are the ones the full expression gives.  The exp runs only if some pending lane falls between the two.
-        const bool sure_unsafe = g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
-        const bool sure_safe = lr_f < 0.0 && delta > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6;
-        bool safe = sure_safe;
-        if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
-          const double a_f = B::idm_free_from_log(lr_f, delta) - g;
-          safe = !(a_f < -HWY_LC_MAX_BRAKING);
+    bool ok_l = false, ok_r = false;
+    double gap_own = 0.0, gap_new = 0.0;  // gap_new: the IDM gap term towards the leader on the side MOBIL picks in this frame
+#ifndef HWY_WAVE_MOBIL_PER_THREAD
+    if (!has_tie) {  // wave-uniform
+      // Every vehicle needs its leader on its own lane and -- while it changes lanes -- on its target lane in every frame.  MOBIL
+      // (behavior.py:265-324: both side lanes' leaders and followers, two more gap terms, the follower's braking) is only
+      // evaluated by a vehicle whose timer has run out: once per second, i.e. by a fifth (highway-fast-v0) or a fifteenth
+      // (highway-v0) of the traffic in a given frame.  Rounds 1-5 evaluated both candidate lanes of EVERY vehicle side by side in
+      // every frame, predicated; now the (vehicle, side) pairs that do decide are COMPACTED: decider number d hands (free-road term,
+      // own-lane acceleration, delta, rank | lane | side bits) over through LDS, thread t evaluates side t & 1 of decider t >> 1
+      // from the rank-ordered snapshot (the decider's own body is there too) -- one candidate per thread instead of two per
+      // thread for everybody -- and the verdicts come back as a ballot, the chosen side's gap term through LDS (it is the target-lane
+      // term of the low-level control of this very frame).  Same operations on the same values: bit-identical to the per-thread
+      // form (-DHWY_WAVE_MOBIL_PER_THREAD builds it; tests/test_wide_kernel.py::test_compacted_mobil_identity).
+      mask_neighbours(m_own, rank, &fo, &ro);
+      mask_neighbours(m_tgt, rank, &ft, &rt_);
+      const int g_fo = fo < 0 ? 0 : fo;
+      gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[g_fo], sh.v[g_fo], sh.c[g_fo], sh.s[g_fo]) : 0.0;
+      const double self_a = free_self - gap_own;
+      const u64 dm = __ballot(cl || cr);
+      if (dm) {  // wave-uniform
+        int *const word = reinterpret_cast<int *>(sh.nc);  // (the post-integration bodies only live inside section G)
+        const int d = __popcll(dm & (((u64)1 << i) - 1));
+        HWY_WAVE_LDS_FENCE();
+        if (cl || cr) {
+          sh.nx[d] = free_self; sh.ny[d] = self_a; sh.nv[d] = delta;
+          word[d] = rank | (me.lane << 8) | (cl ? 1 << 16 : 0) | (cr ? 1 << 17 : 0);
         }
-        if (pend) {
-          if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
+        HWY_WAVE_LDS_FENCE();
+        const int n_tasks = 2 * __popcll(dm);
+        for (int base = 0; base < n_tasks; base += 64) {  // wave-uniform: one pass unless more than 32 vehicles decide at once
+          const int t = base + i;
+          const bool tv = t < n_tasks;
+          const int dd = tv ? t >> 1 : 0, side = t & 1;
+          const int w = word[dd];
+          const int rk = w & 255, ln = (w >> 8) & 255;
+          const bool en = tv && ((w >> (16 + side)) & 1);
+          const double fs = sh.nx[dd], sa = sh.ny[dd], dl = sh.nv[dd];
+          const u64 m = sh.lane_mask[ln + (side ? 2 : 0)];
+          int f, r;
+          mask_neighbours(m, rk, &f, &r);
+          const double ex = sh.x[rk], ev = sh.v[rk], ec = sh.c[rk], es = sh.s[rk];
+          const int gf = f < 0 ? 0 : f;
+          const double gap = f >= 0 ? B::idm_gap(ex, ev, ec, es, sh.x[gf], sh.v[gf], sh.c[gf], sh.s[gf]) : 0.0;
+          // incentive (jerk = self_pred_a - self_a, POLITENESS == 0), then safety: the new follower must not have to brake harder
+          // than LANE_CHANGE_MAX_BRAKING_IMPOSED -- only for candidates that passed the (pow-free) incentive test
+          bool ok = en && !(((fs - gap) - sa) < HWY_LC_MIN_ACC_GAIN);
+          const bool pend = ok && r >= 0;
+          if (__ballot(pend) != 0) {  // wave-uniform
+            const int rf = pend ? r : 0;
+            const double lr_f = sh.lr[rf];
+            const double g = B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], ex, ev, ec, es);
+            // a_f = 3 (1 - E) - g with E = exp(delta * lr_f) >= 0, so a_f <= 3 - g: g beyond 5 is unsafe whatever E is; and a
+            // follower below its target speed (lr_f < 0, delta > 0) has E <= 1 (+ an ulp), so a_f >= -g: g below 2 is safe
+            // whatever E is.  Both with a 1e-6 margin, far above any rounding of the three operations involved -- the verdicts
+            // are the ones the full expression gives.  The exp runs only if some pending task falls between the two.
+            const bool sure_unsafe = g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
+            const bool sure_safe = lr_f < 0.0 && dl > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6;
+            bool safe = sure_safe;
+            if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
+              const double a_f = B::idm_free_from_log(lr_f, dl) - g;
+              safe = !(a_f < -HWY_LC_MAX_BRAKING);
+            }
+            if (pend) ok = safe;
+          }
+          const u64 okm = __ballot(ok);
+          sh.ns[i] = gap;
+          HWY_WAVE_LDS_FENCE();
+          if ((cl || cr) && 2 * d >= base && 2 * d < base + 64) {
+            const int bits = (int)(okm >> (2 * d - base)) & 3;
+            ok_l = (bits & 1) != 0;
+            ok_r = (bits & 2) != 0;
+            if (bits) gap_new = sh.ns[2 * d - base + (ok_r ? 1 : 0)];  // right wins if both pass
+          }
+          HWY_WAVE_LDS_FENCE();
         }
       }
+    } else
+#endif
+    {
+      if (!has_tie) {
+        mask_neighbours(m_own, rank, &fo, &ro);
+        mask_neighbours(sh.lane_mask[me.lane], rank, &fl, &rl);
+        mask_neighbours(sh.lane_mask[me.lane + 2], rank, &frt, &rrt);
+        mask_neighbours(m_tgt, rank, &ft, &rt_);
+      } else {
+        // literal scans return vehicle INDICES; convert to ranks through the (just written) table
+        int a, b;
+        wave_neighbours_scan(p, me.x, me.x, me.y, i, me.lane, &a, &b);
+        fo = a; ro = b;
+        wave_neighbours_scan(p, me.x, me.x, me.y, i, left_ok ? me.lane - 1 : me.lane, &a, &b);
+        fl = a; rl = b;
+        wave_neighbours_scan(p, me.x, me.x, me.y, i, right_ok ? me.lane + 1 : me.lane, &a, &b);
+        frt = a; rrt = b;
+        wave_neighbours_scan(p, me.x, me.x, me.y, i, me.tgt, &a, &b);
+        ft = a; rt_ = b;
+        // index -> rank: rank_of[j] == the rank lane j computed
+        const int r_fo = fo, r_fl = fl, r_fr = frt, r_ft = ft, r_rl = rl, r_rr = rrt;
+        int rk;
+        fo = fl = frt = ft = rl = rrt = -1;
+        for (int j = 0; j < N; ++j) {
+          rk = wave_bcast_i(rank, j);
+          fo = (r_fo == j) ? rk : fo; fl = (r_fl == j) ? rk : fl; frt = (r_fr == j) ? rk : frt;
+          ft = (r_ft == j) ? rk : ft; rl = (r_rl == j) ? rk : rl; rrt = (r_rr == j) ? rk : rrt;
+        }
+      }
+      // gather the leaders' bodies (rank-ordered snapshot => one LDS trip); all issued together
+      const int g_fo = fo < 0 ? 0 : fo, g_fl = fl < 0 ? 0 : fl, g_fr = frt < 0 ? 0 : frt;
+      const double fo_x = sh.x[g_fo], fo_v = sh.v[g_fo], fo_c = sh.c[g_fo], fo_s = sh.s[g_fo];
+      const double fl_x = sh.x[g_fl], fl_v = sh.v[g_fl], fl_c = sh.c[g_fl], fl_s = sh.s[g_fl];
+      const double fr_x = sh.x[g_fr], fr_v = sh.v[g_fr], fr_c = sh.c[g_fr], fr_s = sh.s[g_fr];
+      gap_own = fo >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fo_x, fo_v, fo_c, fo_s) : 0.0;
+      // MOBIL (behavior.py:265-324), both candidates side by side.  jerk = self_pred_a - self_a with
+      // self_* = free_self - gap_*  (POLITENESS == 0: the followers' terms are multiplied by 0.0)
+      const double self_a = free_self - gap_own;
+      const double gap_l = fl >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fl_x, fl_v, fl_c, fl_s) : 0.0;
+      const double gap_r = frt >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
+      ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      // safety: the new follower must not have to brake harder than LANE_CHANGE_MAX_BRAKING_IMPOSED.
+      // Evaluated only for candidates that passed the (pow-free) incentive test, one side per pass (a
+      // vehicle that needs both sides checked -- rare -- takes a second pass); the follower's log speed
+      // ratio comes from the snapshot, so the test costs one exp and one gap term.
+      {
+        bool pend_l = ok_l && rl >= 0, pend_r = ok_r && rrt >= 0;
+        while (__ballot(pend_l || pend_r) != 0) {  // wave-uniform
+          const bool pend = pend_l || pend_r;
+          const bool left = pend_l;
+          const int rf = pend ? (left ? rl : rrt) : 0;
+          const double lr_f = sh.lr[rf];
+          const double g = B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], me.x, me.v, me.ch, me.sh);
+          const bool sure_unsafe = g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
+          const bool sure_safe = lr_f < 0.0 && delta > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6;
+          bool safe = sure_safe;
+          if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
+            const double a_f = B::idm_free_from_log(lr_f, delta) - g;
+            safe = !(a_f < -HWY_LC_MAX_BRAKING);
+          }
+          if (pend) {
+            if (left) { ok_l = safe; pend_l = false; } else { ok_r = safe; pend_r = false; }
+          }
+        }
+      }
+      gap_new = ok_r ? gap_r : gap_l;  // (only read when MOBIL picks a side)
     }
     // side_lanes order is [left, right] and the loop does not break: right wins if both pass
     if (ok_l) me.tgt = me.lane - 1;
@@ -584,9 +658,13 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
     if (drives && me.lane != me.tgt) {
       // leader on the target lane.  For a vehicle that was already changing lanes m_tgt is that lane's
       // mask; for one that decided just now the target is the left/right lane evaluated above.
-      const int f2 = (me.tgt == tgt_old) ? ft : (me.tgt == me.lane - 1 ? fl : frt);
-      double a2 = free_self;
-      if (f2 >= 0) a2 = free_self - B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f2], sh.v[f2], sh.c[f2], sh.s[f2]);
+      // (decided just now: the gap term towards the new target lane's leader is the one MOBIL's incentive test evaluated -- 0.0
+      //  without a leader, and free_self - 0.0 == free_self)
+      double a2 = free_self - gap_new;
+      if (me.tgt == tgt_old) {
+        a2 = free_self;
+        if (ft >= 0) a2 = free_self - B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[ft], sh.v[ft], sh.c[ft], sh.s[ft]);
+      }
       accel = (a2 < accel) ? a2 : accel;  // Python min(a, b)
     }
     accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);

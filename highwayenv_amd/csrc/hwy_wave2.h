@@ -606,16 +606,19 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       left_ok[h] = mv.lane - 1 >= 0;
       right_ok[h] = mv.lane + 1 < p.L;
       if (!has_tie) {
-        u64 m_own[K], m_left[K], m_right[K], m_tgt[K];
+        u64 m_own[K], m_tgt[K];
 #pragma unroll
-        for (int w = 0; w < K; ++w) {
-          m_own[w] = sh.lane_mask[mv.lane + 1][w]; m_left[w] = sh.lane_mask[mv.lane][w];
-          m_right[w] = sh.lane_mask[mv.lane + 2][w]; m_tgt[w] = sh.lane_mask[mv.tgt + 1][w];
-        }
+        for (int w = 0; w < K; ++w) { m_own[w] = sh.lane_mask[mv.lane + 1][w]; m_tgt[w] = sh.lane_mask[mv.tgt + 1][w]; }
         fo[h] = wide_mask_front<K>(m_own, rank[h]);
+        ft[h] = wide_mask_front<K>(m_tgt, rank[h]);  // (only read by a vehicle on its way to another lane)
+        fl[h] = frt[h] = rl[h] = rrt[h] = -1;
+#ifdef HWY_WAVE_MOBIL_PER_THREAD
+        u64 m_left[K], m_right[K];
+#pragma unroll
+        for (int w = 0; w < K; ++w) { m_left[w] = sh.lane_mask[mv.lane][w]; m_right[w] = sh.lane_mask[mv.lane + 2][w]; }
         wide_mask_neighbours<K>(m_left, rank[h], &fl[h], &rl[h]);
         wide_mask_neighbours<K>(m_right, rank[h], &frt[h], &rrt[h]);
-        ft[h] = wide_mask_front<K>(m_tgt, rank[h]);  // (only read by a vehicle on its way to another lane)
+#endif
       }
     }
     if (has_tie) {  // wave-uniform: literal scans (vehicle INDICES), converted to ranks below
@@ -650,6 +653,93 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       free_self[0] = HWY_COMFORT_ACC_MAX * (1 - e0);
       free_self[1] = HWY_COMFORT_ACC_MAX * (1 - e1);
     }
+    double gap_new[K], gap_lr[K][2];  // gap_new: the IDM gap term towards the leader on the side MOBIL picks in this frame
+#ifndef HWY_WAVE_MOBIL_PER_THREAD
+    if (!has_tie) {  // wave-uniform
+      // MOBIL compacted (hwy_wave.h, round 6): with a decision per vehicle and second, a fifteenth of highway-v0's traffic decides
+      // in a given frame -- ~7 of config 3's 101 vehicles -- while rounds 4-5 evaluated both side lanes of BOTH vehicles of every
+      // thread in every frame.  Decider number d hands (free-road term, own-lane acceleration, delta, rank | lane | side bits) over
+      // through LDS; thread t evaluates side t & 1 of decider t >> 1 from the rank-ordered snapshot; verdicts come back as a
+      // ballot, the chosen side's gap term through LDS.  Same operations on the same values as the per-thread form
+      // (-DHWY_WAVE_MOBIL_PER_THREAD): bit-identical.
+      bool cl[K], cr[K];
+      u64 dm[K];
+      int n_dec = 0, d[K];
+#pragma unroll
+      for (int h = 0; h < K; ++h) {
+        const Veh &mv = me[h];
+        const int g_fo = fo[h] < 0 ? 0 : fo[h];
+        delta[h] = mv.delta;
+        if constexpr (K != 2) free_self[h] = B::idm_free_from_log(log_ratio[h], delta[h]);
+        gap_own[h] = fo[h] >= 0 ? B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, sh.x[g_fo], sh.v[g_fo], sh.c[g_fo], sh.s[g_fo]) : 0.0;
+        const bool moving = !(fabs(mv.v) < 1);
+        cl[h] = decide[h] && left_ok[h] && B::reachable(p, mv.lane - 1, mv.x, mv.y) && moving;
+        cr[h] = decide[h] && right_ok[h] && B::reachable(p, mv.lane + 1, mv.x, mv.y) && moving;
+        ok_l[h] = ok_r[h] = false;
+        gap_new[h] = 0.0;
+        dm[h] = __ballot(cl[h] || cr[h]);
+        d[h] = n_dec + __popcll(dm[h] & (((u64)1 << l) - 1));
+        n_dec += __popcll(dm[h]);
+      }
+      if (n_dec) {  // wave-uniform
+        int *const word = reinterpret_cast<int *>(sh.nc);  // (the post-integration bodies only live inside section G)
+        HWY_WAVE_LDS_FENCE();
+#pragma unroll
+        for (int h = 0; h < K; ++h)
+          if (cl[h] || cr[h]) {
+            sh.nx[d[h]] = free_self[h]; sh.ny[d[h]] = free_self[h] - gap_own[h]; sh.nv[d[h]] = delta[h];
+            word[d[h]] = rank[h] | (me[h].lane << 8) | (cl[h] ? 1 << 16 : 0) | (cr[h] ? 1 << 17 : 0);
+          }
+        HWY_WAVE_LDS_FENCE();
+        const int n_tasks = 2 * n_dec;
+        for (int base = 0; base < n_tasks; base += 64) {  // wave-uniform
+          const int t = base + l;
+          const bool tv = t < n_tasks;
+          const int dd = tv ? t >> 1 : 0, side = t & 1;
+          const int w_ = word[dd];
+          const int rk = w_ & 255, ln = (w_ >> 8) & 255;
+          const bool en = tv && ((w_ >> (16 + side)) & 1);
+          const double fs = sh.nx[dd], sa = sh.ny[dd], dl = sh.nv[dd];
+          u64 m[K];
+#pragma unroll
+          for (int w = 0; w < K; ++w) m[w] = sh.lane_mask[ln + (side ? 2 : 0)][w];
+          int f, r;
+          wide_mask_neighbours<K>(m, rk, &f, &r);
+          const double ex = sh.x[rk], ev = sh.v[rk], ec = sh.c[rk], es = sh.s[rk];
+          const int gf = f < 0 ? 0 : f;
+          const double gap = f >= 0 ? B::idm_gap(ex, ev, ec, es, sh.x[gf], sh.v[gf], sh.c[gf], sh.s[gf]) : 0.0;
+          bool ok = en && !(((fs - gap) - sa) < HWY_LC_MIN_ACC_GAIN);
+          const bool pend = ok && r >= 0;
+          if (__ballot(pend) != 0) {  // wave-uniform: safety of the new follower (hwy_wave.h)
+            const int rf = pend ? r : 0;
+            const double lr_f = sh.lr[rf];
+            const double g = B::idm_gap(sh.x[rf], sh.v[rf], sh.c[rf], sh.s[rf], ex, ev, ec, es);
+            const bool sure_unsafe = g > HWY_COMFORT_ACC_MAX + HWY_LC_MAX_BRAKING + 1e-6;
+            const bool sure_safe = lr_f < 0.0 && dl > 0.0 && g <= HWY_LC_MAX_BRAKING - 1e-6;
+            bool safe = sure_safe;
+            if (__ballot(pend && !sure_unsafe && !sure_safe) != 0) {  // wave-uniform
+              const double a_f = B::idm_free_from_log(lr_f, dl) - g;
+              safe = !(a_f < -HWY_LC_MAX_BRAKING);
+            }
+            if (pend) ok = safe;
+          }
+          const u64 okm = __ballot(ok);
+          sh.ns[l] = gap;
+          HWY_WAVE_LDS_FENCE();
+#pragma unroll
+          for (int h = 0; h < K; ++h)
+            if ((cl[h] || cr[h]) && 2 * d[h] >= base && 2 * d[h] < base + 64) {
+              const int bits = (int)(okm >> (2 * d[h] - base)) & 3;
+              ok_l[h] = (bits & 1) != 0;
+              ok_r[h] = (bits & 2) != 0;
+              if (bits) gap_new[h] = sh.ns[2 * d[h] - base + (ok_r[h] ? 1 : 0)];  // right wins if both pass
+            }
+          HWY_WAVE_LDS_FENCE();
+        }
+      }
+    } else
+#endif
+    {
 #pragma unroll
     for (int h = 0; h < K; ++h) {
       const Veh &mv = me[h];
@@ -669,6 +759,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       const double gap_r = frt[h] >= 0 ? B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
       ok_l[h] = cl && !(((free_self[h] - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
       ok_r[h] = cr && !(((free_self[h] - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
+      gap_lr[h][0] = gap_l; gap_lr[h][1] = gap_r;
     }
     // safety of the new follower, only for candidates that passed the incentive test, one side per pass (hwy_wave.h)
     {
@@ -709,6 +800,9 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
           any_pend = any_pend || pend_l[h] || pend_r[h];
         }
       }
+    }
+#pragma unroll
+      for (int h = 0; h < K; ++h) gap_new[h] = ok_r[h] ? gap_lr[h][1] : gap_lr[h][0];  // (only read when MOBIL picks a side)
     }
     // side_lanes order is [left, right] and the loop does not break: right wins if both pass
 #pragma unroll
@@ -879,10 +973,13 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       {
         // leader on the target lane: that lane's mask for an ongoing change, the left / right lane evaluated above otherwise
         // (gathered unconditionally -- a conditional LDS read is a branch with its own round trip -- and selected)
-        const int f2 = (mv.tgt == tgt_old[h]) ? ft[h] : (mv.tgt == mv.lane - 1 ? fl[h] : frt[h]);
+        // (decided just now: the gap term towards the new target lane's leader is the one MOBIL's incentive test evaluated -- 0.0
+        //  without a leader, and free_self - 0.0 == free_self)
+        const int f2 = ft[h];
         const int g2 = f2 < 0 ? 0 : f2;
         const double g2x = sh.x[g2], g2v = sh.v[g2], g2c = sh.c[g2], g2s = sh.s[g2];
-        const double a2 = f2 >= 0 ? free_self[h] - B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, g2x, g2v, g2c, g2s) : free_self[h];
+        const double a2_t = f2 >= 0 ? free_self[h] - B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, g2x, g2v, g2c, g2s) : free_self[h];
+        const double a2 = (mv.tgt == tgt_old[h]) ? a2_t : free_self[h] - gap_new[h];
         accel = (drives[h] && mv.lane != mv.tgt && a2 < accel) ? a2 : accel;  // Python min(a, b)
       }
       accel = clipd(accel, -HWY_ACC_MAX, HWY_ACC_MAX);

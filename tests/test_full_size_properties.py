@@ -346,8 +346,14 @@ def test_full_size_intersection_determinism_independence_oracle_and_invariants()
     rng = np.random.default_rng(7)
     n_checked = n_reset = n_col = n_col_full = 0
     done_prev = np.zeros(E_ix, bool)
+    # batch independence: 24 picked environments re-run on a SMALL engine, where environment pick[k] sits at index k (another
+    # workgroup, another row of every plane, another partner in the pre-warm pairing): a bug that depends on the environment's
+    # index gives the same wrong answer on two engines of the same size, not here
+    pick = np.sort(np.random.default_rng(99).choice(E_ix, size=min(24, E_ix), replace=False))
+    _, _, small = make_ix(len(pick), host_traffic=True)
     for t in range(30):
         st = eng.get_state()
+        small.set_state({k: np.ascontiguousarray(v[pick]) for k, v in st.items()})
         # invariants of the traffic management: compact list, exactly one controlled vehicle, valid lanes / routes
         pres = (st["flags"] & _abi.F_ABSENT) == 0
         n = pres.sum(1)
@@ -392,6 +398,11 @@ def test_full_size_intersection_determinism_independence_oracle_and_invariants()
         np.testing.assert_array_equal(s_obs[live], obs[live], err_msg=f"host- vs device-traffic engine, step {t}")
         np.testing.assert_array_equal(s_rew[live], reward[live])
         np.testing.assert_array_equal(s_term[live], term[live])
+        p_obs, p_rew, p_term, _, _ = small.step(acts[pick])
+        lp = live[pick]
+        np.testing.assert_array_equal(p_obs[lp], obs[pick][lp], err_msg=f"batch independence (24 picked environments), step {t}")
+        np.testing.assert_array_equal(p_rew[lp], reward[pick][lp])
+        np.testing.assert_array_equal(p_term[lp], term[pick][lp])
         assert obs.shape == (E_ix, 1, 4, 11, 11) and np.isfinite(obs).all() and (np.abs(obs) <= 1 + 1e-6).all()
         assert np.isfinite(reward).all()
         assert (reward[done_prev] == 0).all() and not term[done_prev].any()
@@ -402,5 +413,5 @@ def test_full_size_intersection_determinism_independence_oracle_and_invariants()
           f"free-running: no car below 0.5 m/s), {n_col} of them with a wreck on the road, {n_col_full} of those in full")
     assert n_col_full >= 0.9 * n_col
     pool.close()
-    for e_ in (eng, eng2, sub):
+    for e_ in (eng, eng2, sub, small):
         e_.close()

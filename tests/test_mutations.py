@@ -31,11 +31,8 @@ MUTANTS = {
          "const int j_imp = (i < SH::kCap && sh.jmax[i] != 0x7fffffff) ? sh.jmax[i] : -1;")],
     "net_pair_list_carry": [
         ("hwy_net.h", "const int carry = i < left ? (int)plist[count + i] : 0,", "const int carry = i < left ? (int)plist[count + i + 1] : 0,")],
-    "mobil_sides_swapped": [
-        ("hwy_wave.h", "bool ok_l = cl && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);",
-         "bool ok_l = cl && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);"),
-        ("hwy_wave.h", "bool ok_r = cr && !(((free_self - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);",
-         "bool ok_r = cr && !(((free_self - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);")],
+    "mobil_sides_swapped": [   # (the compacted MOBIL tasks of round 6: side 0 = left reads row lane, side 1 = right row lane + 2)
+        ("hwy_wave.h", "const u64 m = sh.lane_mask[ln + (side ? 2 : 0)];", "const u64 m = sh.lane_mask[ln + (side ? 0 : 2)];")],
 }
 # (mutant, pytest selection, extra environment, must the selection pass?)  The selections are the suite's own tests: the fuzz families
 # at their default chunk numbers (what `pytest -m gpu` runs on the GPU box, here on the emulator) and the directed pile-up test.
