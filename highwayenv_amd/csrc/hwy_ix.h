@@ -266,8 +266,8 @@ __device__ inline void ix_group_min(const IxMap &mp, double &bd, int &best) {
 
 // ---- item work of a frame: every vehicle has the items 0 .. n - 1 (the arcs of the table, its possible partner slots); thread
 //      (slot vi, member g) asks cand(j) for j = g, g + G, .. -- straight-line code: LDS reads, a dozen f64 operations, no state --
-//      and the items that pass are collected in a list (vi | j << 8) and evaluated ONE PER THREAD: proc(pair, more) (pair < 0:
-//      none; more = another pass follows, wave-uniform).  The serial formulation ran the expensive part once per item for the
+//      and the items that pass are collected in a list (vi | j << 8) and evaluated ONE PER THREAD: proc(pair, more, count) (pair < 0:
+//      none; more = another pass follows, count = entries of this pass, in sh.plist[0 .. count): wave-uniform).  The serial formulation ran the expensive part once per item for the
 //      whole wave whenever ANY vehicle had that item as a candidate; collected, the candidates of all slots share one pass of it
 //      (64 per pass).  The list is filled in trip order, a pass runs whenever it holds a wavefront's worth (a trip adds at most
 //      `width` entries to fewer than `width`: the 128 entries of plist suffice); the verdicts of proc meet per slot through LDS
@@ -293,7 +293,7 @@ __device__ inline void ix_for_items(SH &sh, int n, const IxMap &mp, Cand cand, P
     const int pair = i < count ? (int)sh.plist[i] : -1;
     const int left = n_list - count;  // < width
     const int carry = i < left ? (int)sh.plist[count + i] : 0;
-    proc(pair, j0 < n || left != 0);  // (more passes follow: wave-uniform)
+    proc(pair, j0 < n || left != 0, count);  // (more passes follow; entries of this pass: both wave-uniform)
     HWY_WAVE_LDS_FENCE();
     if (i < left) sh.plist[i] = (unsigned short)carry;
     n_list = left;
@@ -372,7 +372,7 @@ __device__ inline void ix_lane_pass(const IxParams &ip, SH &sh, bool present, do
           const double m = fmax(r.e, bd) + 1e-9, lo = r.c - m, hi = r.c + m;
           return present && (r.L == tgt || ((lo <= 0.0 || lo * lo <= r2) && r2 <= hi * hi));
         },
-        [&](int pair, bool more) {
+        [&](int pair, bool more, int) {
           const int v = pair < 0 ? 0 : (pair & 255);
           unsigned long long key = 0;
           int L = 0;
@@ -753,22 +753,38 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
             const double reach = my_rho + sh.brho[j] + HWY_VEH_LENGTH + 1e-6;  // (a filter: squares compare as well)
             return veh_v && vi < j && ((pm >> j) & 1) && bdx * bdx + bdy * bdy <= reach * reach;
           },
-          [&](int pair, bool) {
-            if (pair < 0) return;
-            const int a = pair & 255, b = pair >> 8;  // a < b: v1 = a, v2 = b
-            bool conflict = false;
-            for (int k = 0; k < HWY_IX_SAMPLES && !conflict; ++k) {
+          [&](int pair, bool, int count) {
+            // is_conflict_possible tests the 11 predicted poses of a pair one after the other (regulation.py:95-110; any one
+            // that intersects makes the conflict).  Rounds 1-5 ran that loop per pair and thread -- eleven trips of the wavefront,
+            // and the rotated-rectangle test (~400 instructions) in every trip in which ANY pair came within LENGTH -- now the
+            // (pair, sample) items of the pass are spread over the wavefront, one per thread: a handful of candidate pairs x 11
+            // samples are one or two trips.  A hit sets bit 15 of the pair's list entry (vi | j << 8 uses 14 bits).
+            const int width = (int)blockDim.x, n_items = count * HWY_IX_SAMPLES;
+            unsigned *const words = reinterpret_cast<unsigned *>(sh.plist);
+            HWY_WAVE_LDS_FENCE();  // (every thread has read its own entry before anybody marks one)
+            for (int it0 = 0; it0 < n_items; it0 += width) {  // wave-uniform
+              const int it = it0 + i;
+              const bool valid = it < n_items;
+              const int q = valid ? (int)(((unsigned)it * 47663u) >> 19) : 0;  // it / 11 (exact below 5 000)
+              const int k = valid ? it - HWY_IX_SAMPLES * q : 0;
+              const int pw = (int)sh.plist[q] & 0x3fff;
+              const int a = pw & 255, b = pw >> 8;  // a < b: v1 = a, v2 = b
               const double ax = sh.traj[k][0][a], ay = sh.traj[k][1][a], bx = sh.traj[k][0][b], by = sh.traj[k][1][b];
               const double dx = bx - ax, dy = by - ay;
-              if (sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH) continue;
-              const double ah = sh.traj[k][2][a], bh = sh.traj[k][2][b];
-              double ca, sa, cb, sb;
-              sincos_bounded(ah, &sa, &ca);
-              sincos_bounded(bh, &sb, &cb);
-              // rotated_rectangles_intersect(rect(lower slot), rect(higher slot))
-              conflict = ix_corner_inside(ax, ay, ca, sa, bx, by, cb, sb) || ix_corner_inside(bx, by, cb, sb, ax, ay, ca, sa);
+              bool conflict = false;
+              if (valid && !(sqrt(dx * dx + dy * dy) > HWY_VEH_LENGTH)) {
+                const double ah = sh.traj[k][2][a], bh = sh.traj[k][2][b];
+                double ca, sa, cb, sb;
+                sincos_bounded(ah, &sa, &ca);
+                sincos_bounded(bh, &sb, &cb);
+                // rotated_rectangles_intersect(rect(lower slot), rect(higher slot))
+                conflict = ix_corner_inside(ax, ay, ca, sa, bx, by, cb, sb) || ix_corner_inside(bx, by, cb, sb, ax, ay, ca, sa);
+              }
+              if (conflict) __hip_atomic_fetch_or(&words[q >> 1], 0x8000u << (16 * (q & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (conflict) {
+            HWY_WAVE_LDS_FENCE();
+            if (pair >= 0 && ((words[i >> 1] >> (16 * (i & 1))) & 0x8000u)) {  // (read through the type the marks were written in)
+              const int a = pair & 255, b = pair >> 8;
               const int p1 = sh.prio[sh.vlane[a]], p2 = sh.prio[sh.vlane[b]];
               bool low_yields;
               if (p1 > p2) low_yields = false;
@@ -843,7 +859,7 @@ __device__ inline void ix_frames(const IxParams &ip, SH &sh, int e, IxVeh &me, i
             // objects.py:124-127 (the pre-check sphere: a dozen instructions per trip)
             return present_v && vi < j && ((pm >> j) & 1) && dx * dx + dy * dy <= lim * lim;
           },
-          [&](int pair, bool) {
+          [&](int pair, bool, int) {
             // one PAIR per thread: the provable-separation test (hwy_device.h: provably (False, False) without the SAT) and, if
             // any pair of the wavefront survives it, the SAT.  (Rounds 1-3 ran the separation test inside the partner loop,
             // under divergence, once per trip in which any thread had a partner inside its sphere: nearly every trip in a queue.)
