@@ -257,8 +257,15 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 // a1 > b1, which picks the OTHER candidate exactly in the containment case (two cars nose to tail on one lane centre,
 // lateral axis: found by tests/test_collision_steps.py against the reference's traces).  So every direction yields
 // both signed distances and the minimum is folded in the reference's own order of the 8 normals (first minimum wins).
+// The four axis directions one after the other: the ILP-first scheduler otherwise interleaves them, and the SAT -- a rare path -- then
+// holds ~100 VGPRs at once, which is what sets the register count (and, under a 128-register budget, the spills) of every kernel it
+// is inlined into.  A scheduling fence between two directions: same instructions, same results, a third of the registers.
+#ifndef HWY_SAT_FENCE
+#define HWY_SAT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define HWY_SAT_SETTLE(f) asm volatile("" : "+v"(f))
+#endif
 struct SatAcc {
-  bool intersecting, will;
+  int flags;  // bit 0: intersecting, bit 1: will_intersect (both start set; an axis that separates clears its bit)
   double min_distance, axx, axy;
   int order;  // position of the winning normal in the reference's loop over the 8 normals
 };
@@ -266,16 +273,23 @@ struct SatAcc {
 // minimum at once.  `first_minus`: the reference meets -n first (the body axis u: order -u .. +u) or +n first (w: +w .. -w);
 // k0 / k1 = positions of the two normals in the reference's loop, so "first minimum wins" becomes "smaller |d|, then
 // smaller position" and no per-axis result has to stay live until its turn.
+// SETTLE = false: without the register-allocation constraints (the two-wavefront workgroup kernel: with them, this toolchain's
+// greedy register allocator crashes on exactly that instantiation -- ROCm 7.2 clang 22, -disable-machine-licm + iterative-ilp)
+template <bool SETTLE = true>
 __device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
                                 double vp, double cdx, double cdy, int k_plus, int k_minus) {
   double min_a = ca_ - ra, max_a = ca_ + ra;
   const double min_b = cb_ - rb, max_b = cb_ + rb;
-  if ((min_a < min_b ? min_b - max_a : min_a - max_b) > 0) acc.intersecting = false;
+  int clr = (min_a < min_b ? min_b - max_a : min_a - max_b) > 0 ? 1 : 0;
   if (vp < 0) min_a += vp; else max_a += vp;
   const double g1 = min_b - max_a, g2 = min_a - max_b;
   const double dn = min_a < min_b ? g1 : g2;  // normal +n
   const double dm = max_a > max_b ? g2 : g1;  // normal -n: the intervals are the exact negations, [-max, -min]
-  if (dn > 0) acc.will = false;                // (disjoint intervals: dn == dm)
+  clr |= dn > 0 ? 2 : 0;                       // (disjoint intervals: dn == dm)
+  acc.flags &= ~clr;
+  // (the two verdicts of THIS direction are folded in here and now: left as booleans the optimiser gathers the compares of all four
+  //  directions at the end of the routine, and every direction's intervals stay live until then -- see HWY_SAT_FENCE)
+  if constexpr (SETTLE) HWY_SAT_SETTLE(acc.flags);
   // the better of the two normals of this direction (ties: the one the reference meets first)
   const double an = fabs(dn), am = fabs(dm);
   const bool take_minus = am < an || (am == an && k_minus < k_plus);
@@ -291,6 +305,7 @@ __device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, d
     acc.axy = pos ? ny : -ny;
   }
 }
+template <bool SETTLE = true>
 __device__ inline int pair_collide_body(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const double diagonal = sqrt(HWY_VEH_LENGTH * HWY_VEH_LENGTH + HWY_VEH_WIDTH * HWY_VEH_WIDTH);
   const double dx = B.x - A.x, dy = B.y - A.y;
@@ -303,19 +318,22 @@ __device__ inline int pair_collide_body(const Body &A, const Body &B, double dt,
   const double ddx = A.v * A.c * dt - B.v * B.c * dt, ddy = A.v * A.s * dt - B.v * B.s * dt;
   const double cdx = A.x - B.x, cdy = A.y - B.y;  // centre difference (mean of the corners)
   const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);  // |cos|, |sin| of (h_b - h_a)
-  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0, 8};
+  SatAcc acc{3, __builtin_inf(), 0.0, 0.0, 8};
   // the reference's order of the 8 normals: -u_a, +w_a, +u_a, -w_a, -u_b, +w_b, +u_b, -w_b  (positions 0..7)
   // u_a = (cos h_a, sin h_a), w_a = (-sin h_a, cos h_a)
-  sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy, 2, 0);
-  sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy, 1, 3);
+  sat_axis<SETTLE>(acc, A.c, A.s, A.x * A.c + A.y * A.s, hl, B.x * A.c + B.y * A.s, hl * cr + hw * sr, A.c * ddx + A.s * ddy, cdx, cdy, 2, 0);
+  if constexpr (SETTLE) HWY_SAT_FENCE();
+  sat_axis<SETTLE>(acc, -A.s, A.c, A.y * A.c - A.x * A.s, hw, B.y * A.c - B.x * A.s, hl * sr + hw * cr, A.c * ddy - A.s * ddx, cdx, cdy, 1, 3);
+  if constexpr (SETTLE) HWY_SAT_FENCE();
   // u_b, w_b
-  sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy, 6, 4);
-  sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy, 5, 7);
-  if (acc.will) {
+  sat_axis<SETTLE>(acc, B.c, B.s, A.x * B.c + A.y * B.s, hl * cr + hw * sr, B.x * B.c + B.y * B.s, hl, B.c * ddx + B.s * ddy, cdx, cdy, 6, 4);
+  if constexpr (SETTLE) HWY_SAT_FENCE();
+  sat_axis<SETTLE>(acc, -B.s, B.c, A.y * B.c - A.x * B.s, hl * sr + hw * cr, B.y * B.c - B.x * B.s, hw, B.c * ddy - B.s * ddx, cdx, cdy, 5, 7);
+  if (acc.flags & 2) {
     *tx = acc.min_distance * acc.axx;
     *ty = acc.min_distance * acc.axy;
   }
-  return (acc.intersecting ? 1 : 0) | (acc.will ? 2 : 0);
+  return acc.flags;
 }
 // HWY_OUTLINE_SAT: the SAT as a real function call (s_swappc; operands and results in registers: by value, no scratch) instead
 // of an inlined body -- a rare path (0.3 trips per headline env-step) whose registers the frame loop's allocation would then stop
@@ -331,6 +349,7 @@ __device__ __attribute__((noinline)) SatOut pair_collide_call(double ax, double 
   o.r = pair_collide_body(Body{ax, ay, av, ac, as}, Body{bx, by, bv, bc, bs}, dt, &o.tx, &o.ty);
   return o;
 }
+template <bool SETTLE = true>
 __device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
   const SatOut o = pair_collide_call(A.x, A.y, A.v, A.c, A.s, B.x, B.y, B.v, B.c, B.s, dt);
   *tx = o.tx;
@@ -338,8 +357,9 @@ __device__ inline int pair_collide(const Body &A, const Body &B, double dt, doub
   return o.r;
 }
 #else
+template <bool SETTLE = true>
 __device__ inline int pair_collide(const Body &A, const Body &B, double dt, double *tx, double *ty) {
-  return pair_collide_body(A, B, dt, tx, ty);
+  return pair_collide_body<SETTLE>(A, B, dt, tx, ty);
 }
 #endif
 
@@ -352,6 +372,7 @@ struct EnvBlock {
   struct Shared {
     double x[NV], y[NV], v[NV], c[NV], s[NV], ts[NV];
     double aux0[NV], aux1[NV];   // collision translation exchange / observation keys
+    double rpx[NV], rpy[NV], rpv[NV];  // full pairwise collisions: post-integration position / speed in the frame's RANK order
     int lane[NV], tgt[NV], perm[NV];
     u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
     u64 bal0[2 * NW], bal1[2 * NW], bal2[2 * NW];  // block_ballot slot pairs
@@ -535,7 +556,7 @@ struct EnvBlock {
     return hwy::surely_apart(body_of(sh, a), body_of(sh, b), dt);
   }
   __device__ static inline int pair_collide(const Shared &sh, int a, int b, double dt, double *tx, double *ty) {
-    return hwy::pair_collide(body_of(sh, a), body_of(sh, b), dt, tx, ty);
+    return hwy::pair_collide<NW != 2>(body_of(sh, a), body_of(sh, b), dt, tx, ty);
   }
 
   // ---- Vehicle.to_dict feature (vehicle/kinematics.py:237-261) ---------------------------------------
@@ -1061,6 +1082,10 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
   u64 chk[NW];
   int ph0 = 0, ph1 = 0, ph2 = 0;  // block_ballot phases of the three slot pairs
   B::block_ballot(sh, active && (me.flags & HWY_F_CHECK_COLLISIONS), sh.bal0, ph0, chk);
+  // (kept in LDS for the sparse-checker loop of section G: wave-uniform masks the frame loop would otherwise hold in 2 NW VGPRs --
+  //  the scalar registers are long gone -- on top of the SAT's peak; published by the barrier of the first frame's snapshot)
+  if (i == 0)
+    for (int w = 0; w < NW; ++w) sh.chk[w] = chk[w];
   // rank along the road, carried from frame to frame and from step to step (hint in the packed word) and merely VERIFIED
   // (section C); sh.perm = its inverse.  Idle threads keep their own slot so that the table stays a permutation.
   int rank = active ? me.rank : i;
@@ -1273,54 +1298,65 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
     __syncthreads();  // all reads of the frame-start snapshot are done
     publish<NW>(sh, me, active);
-    if (active) sh.aux0[i] = x_old;
-    if (all_check) {  // (block-uniform) per-vehicle verdict slots of the pair pass below
+    if (all_check) {  // (block-uniform)
+      // frame-start x, and the post-integration position and speed, once more in the RANK order of this frame's start: a step of
+      // the walk below then reads ONE slot (rank + k) of four planes and the index table -- no dependent second round trip
+      if (active) { sh.aux0[rank] = x_old; sh.rpx[rank] = me.x; sh.rpy[rank] = me.y; sh.rpv[rank] = me.v; }
+      // per-vehicle verdict slots of the pair pass below
       sh.jmax[i] = -1;
       sh.hit[i] = 0;
     }
     // the barrier that publishes the snapshot also answers "did any body move further / is any faster than the scan's bound"
     const bool wide = __syncthreads_or(all_check && active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
     if (all_check) {
-      // Full pairwise (highway-v0): outward scan in rank order from my own rank, bounded by the frame-start
-      // distance (collision radius + the most two vehicles can move relative to each other in one frame);
-      // the partner with the highest index is the last writer of `impact` in the reference's (i, j>i) loop.
-      // sh.x/y/v/c/s now hold the post-integration bodies by index, sh.aux0 the frame-start x by index.
-      // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
-      // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the scan is the literal all-pairs loop
-      // Every unordered pair once, by the thread of its lower index: the walk only COLLECTS the pairs that pass the sphere
-      // pre-check and the provable-separation test (one list per wavefront); the SAT then runs one PAIR per thread, and the
-      // verdicts meet per vehicle in LDS -- across wavefronts, hence the workgroup barrier between "highest partner with a
-      // pending impact" (ds_max) and the winner's write of its translation (hwy_wave.h has the one-wavefront version).
+      // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among neighbours along the
+      // road: every vehicle walks FORWARD in the rank order of this frame's start (each unordered pair is met once, from its
+      // rear end), bounded by the frame-start distance (collision radius + the most two vehicles can move relative to each
+      // other in one frame), and only COLLECTS the partners inside the reference's own pre-check sphere (objects.py:124-127) --
+      // a dozen VALU instructions per candidate, one list per wavefront.  The list pass then runs, one PAIR per thread, the
+      // provable-separation test and -- if any pair of the wavefront survives it -- the SAT; the verdicts meet per vehicle in
+      // LDS, across wavefronts, hence the workgroup barrier between "highest partner with a pending impact" (ds_max: the
+      // partner with the highest index is the last writer of `impact` in the reference's (i, j > i) loop) and the winner's
+      // write of its translation.  (hwy_wave2.h has the one-wavefront version of the same walk; rounds 1-5 walked outward in
+      // both directions through the index table and ran the separation test inside the walk, under divergence.)
+      // The bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
+      // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the walk is the literal all-pairs loop.
       unsigned short *const plist = sh.plist[i >> 6];
       const int lane_id_ = i & 63;
       const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
       const u64 below = ((u64)1 << lane_id_) - 1;
-      const Body mine{me.x, me.y, me.v, me.ch, me.sh};
       int n_list = 0, k = 1;  // wave-uniform
-      bool go_a = active, go_b = active, walking = true, any_pass = false;
+      bool go = active, walking = true, any_pass = false;
       for (;;) {
         while (walking && n_list < 64) {
-          const int ra = rank - k, rb = rank + k;
-          go_a = go_a && ra >= 0;
-          go_b = go_b && rb < N;
-          const int qa = sh.perm[go_a ? ra : 0], qb = sh.perm[go_b ? rb : 0];
-          go_a = go_a && !(fabs(sh.aux0[qa] - x_old) > reach);  // sh.aux0: frame-start x by index
-          go_b = go_b && !(fabs(sh.aux0[qb] - x_old) > reach);
-          ++k;
-          if (__ballot(go_a || go_b) == 0 || k > N) walking = false;
+          // two walk steps per trip (k and k + 1): every LDS read of the trip is issued before anything depends on one (the
+          // slots are clamped by the range alone; `go`, which depends on what is read, is folded in afterwards)
+          bool keep[2];
+          int q[2], rb[2];
+          double x0[2], px[2], py[2], pv[2];
 #pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const int q = side ? qb : qa;
-            bool keep = false;
-            if ((side ? go_b : go_a) && i < q) {
-              const Body other{sh.x[q], sh.y[q], sh.v[q], sh.c[q], sh.s[q]};
-              const double dx = other.x - me.x, dy = other.y - me.y;
-              const double lim = 5.5 + fmax(fabs(me.v), fabs(other.v)) * p.dt;
-              keep = !(dx * dx + dy * dy > lim * lim) && !hwy::surely_apart(mine, other, p.dt);
-            }
-            const u64 km = __ballot(keep);
+          for (int u = 0; u < 2; ++u) {
+            rb[u] = rank + (k + u);
+            const int r = rb[u] < N ? rb[u] : 0;
+            x0[u] = sh.aux0[r];  // frame-start x in rank order
+            px[u] = sh.rpx[r]; py[u] = sh.rpy[r]; pv[u] = sh.rpv[r];
+            q[u] = sh.perm[r];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const bool near = !(fabs(x0[u] - x_old) > reach);
+            go = go & (rb[u] < N) & near;
+            const double dx = px[u] - me.x, dy = py[u] - me.y;
+            const double lim = 5.5 + fmax(fabs(me.v), fabs(pv[u])) * p.dt;
+            keep[u] = go & !(dx * dx + dy * dy > lim * lim);
+          }
+          k += 2;
+          if (__ballot(go) == 0 || k > N) walking = false;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const u64 km = __ballot(keep[u]);
             if (km) {
-              if (keep) plist[n_list + __popcll(km & below)] = (unsigned short)(i | (q << 8));
+              if (keep[u]) plist[n_list + __popcll(km & below)] = (unsigned short)(i | (q[u] << 8));
               n_list += __popcll(km);
             }
           }
@@ -1331,15 +1367,20 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
         const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
         const int c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
         const int c1 = 64 + lane_id_ < left ? (int)plist[count + 64 + lane_id_] : 0;
-        const int a = pair & 255, b = pair >> 8;  // a < b: the reference's `self` and `other`
+        const int u0 = pair < 0 ? 0 : (pair & 255), u1 = pair < 0 ? 0 : (pair >> 8);  // (no pair: slot 0, discarded)
+        const int a = u0 < u1 ? u0 : u1, b = u0 < u1 ? u1 : u0;  // a < b: the reference's `self` and `other`
+        const Body A = B::body_of(sh, a), Bb = B::body_of(sh, b);
+        const bool cand = pair >= 0 && !hwy::surely_apart(A, Bb, p.dt);
         int r = 0;
         double tx = 0.0, ty = 0.0;
-        if (pair >= 0) {
-          r = B::pair_collide(sh, a, b, p.dt, &tx, &ty);
-          if (r & 1) sh.hit[a] = sh.hit[b] = 1;
-          if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
-            __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__ballot(cand) != 0) {  // wave-uniform
+          if (cand) {
+            r = hwy::pair_collide<NW != 2>(A, Bb, p.dt, &tx, &ty);
+            if (r & 1) sh.hit[a] = sh.hit[b] = 1;
+            if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
+              __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
         __syncthreads();
@@ -1362,7 +1403,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       // sparse checkers (highway-fast-v0: the ego only): for each checker c, thread q evaluates the pair
       // {c, q}; q applies it to itself (ascending c == loop order), c gathers from all q.
       for (int w = 0; w < NW; ++w) {
-        u64 m = chk[w];
+        u64 m = sh.chk[w];
         while (m) {  // block-uniform
           const int c = w * 64 + ctz64(m);
           m &= m - 1;

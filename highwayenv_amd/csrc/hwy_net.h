@@ -184,17 +184,20 @@ __device__ inline int net_pair_collide(const NetBody &A, const NetBody &B, doubl
   const double ddx = A.v * A.c * dt - B.v * B.c * dt, ddy = A.v * A.s * dt - B.v * B.s * dt;
   const double cdx = A.x - B.x, cdy = A.y - B.y;
   const double cr = fabs(A.c * B.c + A.s * B.s), sr = fabs(B.s * A.c - B.c * A.s);
-  SatAcc acc{true, true, __builtin_inf(), 0.0, 0.0, 8};
+  SatAcc acc{3, __builtin_inf(), 0.0, 0.0, 8};
   // the reference's order of the 8 normals (hwy_device.h: sat_axis): -u_a, +w_a, +u_a, -w_a, -u_b, +w_b, +u_b, -w_b
   sat_axis(acc, A.c, A.s, A.x * A.c + A.y * A.s, A.hl, B.x * A.c + B.y * A.s, B.hl * cr + B.hw * sr, A.c * ddx + A.s * ddy, cdx, cdy, 2, 0);
+  HWY_SAT_FENCE();
   sat_axis(acc, -A.s, A.c, A.y * A.c - A.x * A.s, A.hw, B.y * A.c - B.x * A.s, B.hl * sr + B.hw * cr, A.c * ddy - A.s * ddx, cdx, cdy, 1, 3);
+  HWY_SAT_FENCE();
   sat_axis(acc, B.c, B.s, A.x * B.c + A.y * B.s, A.hl * cr + A.hw * sr, B.x * B.c + B.y * B.s, B.hl, B.c * ddx + B.s * ddy, cdx, cdy, 6, 4);
+  HWY_SAT_FENCE();
   sat_axis(acc, -B.s, B.c, A.y * B.c - A.x * B.s, A.hl * sr + A.hw * cr, B.y * B.c - B.x * B.s, B.hw, B.c * ddy - B.s * ddx, cdx, cdy, 5, 7);
-  if (acc.will) {
+  if (acc.flags & 2) {
     *tx = acc.min_distance * acc.axx;
     *ty = acc.min_distance * acc.axy;
   }
-  return (acc.intersecting ? 1 : 0) | (acc.will ? 2 : 0);
+  return acc.flags;
 }
 
 // ---- rank along x among the PRESENT slots (0 = smallest x; equal x ordered by slot); absent / idle lanes take

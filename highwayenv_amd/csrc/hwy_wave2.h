@@ -653,7 +653,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       free_self[0] = HWY_COMFORT_ACC_MAX * (1 - e0);
       free_self[1] = HWY_COMFORT_ACC_MAX * (1 - e1);
     }
-    double gap_new[K], gap_lr[K][2];  // gap_new: the IDM gap term towards the leader on the side MOBIL picks in this frame
+    double gap_new[K], gap_sl[K], gap_sr[K];  // (gap_sl / gap_sr: separate arrays -- a [K][2] indexed by the verdict went to scratch memory); gap_new: the IDM gap term towards the leader on the side MOBIL picks in this frame
 #ifndef HWY_WAVE_MOBIL_PER_THREAD
     if (!has_tie) {  // wave-uniform
       // MOBIL compacted (hwy_wave.h, round 6): with a decision per vehicle and second, a fifteenth of highway-v0's traffic decides
@@ -759,7 +759,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       const double gap_r = frt[h] >= 0 ? B::idm_gap(mv.x, mv.v, mv.ch, mv.sh, fr_x, fr_v, fr_c, fr_s) : 0.0;
       ok_l[h] = cl && !(((free_self[h] - gap_l) - self_a) < HWY_LC_MIN_ACC_GAIN);
       ok_r[h] = cr && !(((free_self[h] - gap_r) - self_a) < HWY_LC_MIN_ACC_GAIN);
-      gap_lr[h][0] = gap_l; gap_lr[h][1] = gap_r;
+      gap_sl[h] = gap_l; gap_sr[h] = gap_r;
     }
     // safety of the new follower, only for candidates that passed the incentive test, one side per pass (hwy_wave.h)
     {
@@ -802,7 +802,7 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       }
     }
 #pragma unroll
-      for (int h = 0; h < K; ++h) gap_new[h] = ok_r[h] ? gap_lr[h][1] : gap_lr[h][0];  // (only read when MOBIL picks a side)
+      for (int h = 0; h < K; ++h) gap_new[h] = ok_r[h] ? gap_sr[h] : gap_sl[h];  // (only read when MOBIL picks a side)
     }
     // side_lanes order is [left, right] and the loop does not break: right wins if both pass
 #pragma unroll

@@ -35,6 +35,8 @@
 #define HWY_KERNARG_TOUCH(T) ((void)0)                // hwy_wave.h: a prefetch of the kernel-argument segment (device build only)
 #define HWY_ISSUED_TOGETHER(a, b, c, d, e_) ((void)0)  // hwy_wave.h: a scheduling constraint of the device build only
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
+#define HWY_SAT_FENCE() ((void)0)                     // hwy_device.h: scheduling / register-allocation constraints of the SAT (device build only)
+#define HWY_SAT_SETTLE(f) ((void)0)
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };

@@ -41,8 +41,11 @@ def test_one_wavefront_kernel_four_waves_per_simd_no_vgpr_spills(res, full_scan)
     for wpe in (1, 2, 3, 4):
         for fam in ("hwy_step_wave_kernel", "hwy_rollout_wave_kernel"):
             r = res[f"hwy::{fam}<{wpe}, {full_scan}>"]
-            assert r["vgpr_spill"] == 0 and r["scratch"] <= 36 and r["sgpr_spill"] <= 80, r   # (SGPRs spill to VGPR lanes, outside the frame loop)
-            assert waves_per_simd(r["vgpr"]) >= 4, r
+            # (SGPRs spill to VGPR lanes, outside the frame loop: 73 before round 6's compacted MOBIL tasks, 83 .. 85 with them)
+            assert r["vgpr_spill"] == 0 and r["scratch"] <= 36 and r["sgpr_spill"] <= 88, r
+            # round 6: the SAT evaluates its four axis directions one after the other (hwy_device.h: HWY_SAT_FENCE) -- 99 / 117
+            # registers where the interleaved form held 111 / 129 (and one spilled VGPR in the <4, true> build)
+            assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr"] <= 120, r
             assert 16 * r["lds"] <= LDS_PER_CU, r
             assert r["workgroup"] == 64
 
@@ -50,10 +53,10 @@ def test_one_wavefront_kernel_four_waves_per_simd_no_vgpr_spills(res, full_scan)
 def test_merge_kernel_four_waves_per_simd(res):
     """hwy_net_step_kernel<4, false> (BASELINE config 5): 128 VGPRs at 4 waves/SIMD -- the round-2 build spilled 54 there."""
     r = res["hwy::hwy_net_step_kernel<4, false>"]
-    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] <= 4, r
+    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] == 0, r  # (3 spilled before the sequential SAT of round 6)
     assert 16 * r["lds"] <= LDS_PER_CU, r
     r = res["hwy::hwy_net_rollout_kernel<4, false>"]
-    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] <= 12, r
+    assert waves_per_simd(r["vgpr"]) >= 4 and r["vgpr_spill"] <= 4, r
 
 
 def test_intersection_kernel_allocation(res):
@@ -71,11 +74,13 @@ def test_intersection_kernel_allocation(res):
 
 def test_workgroup_kernel_allocation(res):
     """hwy_step_kernel<W, WPE> (N > 64: W wavefronts per environment).  The 3-wave builds hold no spills; the 4-wave builds
-    (batches beyond 3 resident wavefronts per SIMD) trade a few spilled VGPRs for the fourth wavefront."""
+    (batches beyond 3 resident wavefronts per SIMD) carried 16 .. 34 spilled VGPRs through round 5 -- the SAT's interleaved axis
+    directions on top of the frame loop's state, and the sparse-checker loop unrolled over the workgroup's wavefronts with one
+    inlined SAT each -- and hold 2 since round 6 (W = 2 keeps the old SAT: hwy_device.h, sat_axis<SETTLE>)."""
     for w in (1, 2, 3, 4):
         r3, r4 = res[f"hwy::hwy_step_kernel<{w}, 3>"], res[f"hwy::hwy_step_kernel<{w}, 4>"]
         assert r3["vgpr_spill"] == 0 and waves_per_simd(r3["vgpr"]) >= 3, r3
-        assert waves_per_simd(r4["vgpr"]) >= 4 and r4["vgpr_spill"] <= 48, r4
+        assert waves_per_simd(r4["vgpr"]) >= 4 and r4["vgpr_spill"] <= (24 if w == 2 else 4), r4
         assert r3["workgroup"] == 64 * w and r3["lds"] == r4["lds"]
         # LDS never limits below what the registers allow: (waves/SIMD x 4 SIMDs) / W workgroups per CU
         assert (12 // w) * r3["lds"] <= LDS_PER_CU and (16 // w) * r4["lds"] <= LDS_PER_CU, (r3, r4)

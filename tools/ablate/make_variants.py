@@ -195,7 +195,9 @@ def ix_ticks(text):
     k = once(k, "  if (i == 0) ip.road_steps[e] = road_steps;\n}",
              "  if (i == 0) ip.road_steps[e] = road_steps;\n  IXTICK(10)\n"
              "  if (i == 0 && p.obs) { float *o = p.obs + (size_t)eo * p.A * (p.obs_type == HWY_OBS_KINEMATICS ? p.V * p.F : p.F * p.gW * p.gH);\n"
-             "    for (int q = 0; q < 14; ++q) o[q] = (float)sh.tk[q]; o[14] = (float)role; o[15] = (float)n_run; }\n}")
+             "    for (int q = 0; q < 14; ++q) o[q] = (float)sh.tk[q]; o[14] = (float)role; o[15] = (float)n_run;\n"
+             "    const unsigned hw_ = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_ = __builtin_amdgcn_s_getreg((31 << 11) | 20);\n"
+             "    o[16] = (float)((((xcc_ & 0xf) * 8 + ((hw_ >> 13) & 7)) * 16 + ((hw_ >> 8) & 0xf)) * 4 + ((hw_ >> 4) & 3)); o[17] = (float)blockIdx.x; }\n}")
     return head + k
 
 
@@ -282,7 +284,13 @@ VARIANTS = {
                           "    return;"))],
     # intersection kernel (hwy_ix.h): sections removed (timing only)
     "ixbase": [],
-    "ixticks": [(IX, ix_ticks)],
+    # (+ the step workgroups honour hwy_set_block_order: tools/ix_placement_probe.py)
+    "ixticks": [(IX, ix_ticks),
+                (IX, sub("  ix_policy_block<CAP, NT>(ip, sh, (int)blockIdx.x, (int)blockIdx.x);\n}\n\n// hwy_rollout_device on the intersection",
+                         "  const int b_ = (int)blockIdx.x, bx_ = (ip.s.block_env && b_ < ip.num_envs) ? (int)ip.s.block_env[b_] : b_;\n"
+                         "  ix_policy_block<CAP, NT>(ip, sh, bx_, bx_);\n}\n\n// hwy_rollout_device on the intersection")),
+                ("hwy_engine.hip", sub("  if (eng->cfg.scenario != HWY_SCENARIO_HIGHWAY || eng->cfg.num_vehicles > 64 || eng->force_block_kernel || E > 65535)",
+                                       "  if (!is_ix(eng) && (eng->cfg.scenario != HWY_SCENARIO_HIGHWAY || eng->cfg.num_vehicles > 64 || eng->force_block_kernel || E > 65535))"))],
     "ixnoreg": [(IX, sub("    if (road_steps % every == 0) {  // wave-uniform", "    if (false) {"))],
     "ixnocoll": [(IX, sub("      for (u64 m = NH > 1 ? ((pm | (pm >> 1)) & 0x5555555555555555ull) : pm; m; m &= m - 1) {  // wave-uniform, ascending", "      for (u64 m = 0; m; m &= m - 1) {"))],
     "ixnoarc": [(IX, sub("    const bool need = mine && present && (fabs(lat) <= sh.wid[L] / 2 + 1.0 || !(fabs(lat) > bd) || L == tgt);", "    const bool need = false;"))],
