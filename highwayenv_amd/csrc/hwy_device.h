@@ -244,6 +244,43 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
   return gap_lat > margin || gap_lon > margin;
 }
 
+// ---- how far the forward walk of the full pairwise collision check has to look ------------------------------------------------
+// The walk visits partners in the order of the FRAME-START x and stops at the first one further than `reach` ahead.  A pair (i, q),
+// x0_i <= x0_q, can only pass the reference's pre-check sphere (objects.py:124-127) if x_q - x_i <= 5.5 + max(|v_i|, |v_q|) dt after
+// the integration, and x_q - x_i >= (x0_q - x0_i) - 2 D with D = the largest |x - x0| of the environment in this frame (impact
+// displacements included).  So reach = 5.5 + S dt + 2 D, S = the largest |v| after the integration, misses nothing -- with the
+// ACTUAL maxima of the frame, not the 50 m/s + 3 m constants of rounds 2-5 (21.5 m: three to four partners per vehicle in dense
+// traffic where 11 m -- one or two -- suffice) and without their fallback to the all-pairs loop for faster bodies.  The maxima are
+// taken over the HIGH WORDS of the doubles (monotone in |x|; wave_max_u32 below) and rounded up: (key + 1, 0) is above
+// every double with that high word.  A non-finite operand gives an infinite reach (the literal all-pairs loop).  A filter only:
+// which pairs are FOUND does not depend on it (1e-6 of slack against the rounding of the sums), so no result does.
+// Maximum of a 32-bit value over the 64 lanes of the wavefront (call it with ALL lanes enabled, 0 from lanes that have nothing to
+// say), wave-uniform result.  Six v_max_u32 with DPP operands -- a scan within each row of 16 lanes, then across the rows
+// (row_bcast15 / row_bcast31: GFX9) -- and a v_readlane: the obvious alternative, one ds_max_u32 per lane on a shared LDS word,
+// serialises its 64 lanes on ONE address in a pipeline the whole CU shares (measured: highway-v0 109 -> 160 us).
+#ifndef HWY_WAVE_MAX_U32
+__device__ inline unsigned wave_max_u32(unsigned v) {
+  int x = (int)v;
+#define HWY_DPP_MAX_(ctrl, rows) \
+  { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false); x = (int)(o_ > (unsigned)x ? o_ : (unsigned)x); }
+  HWY_DPP_MAX_(0x111, 0xf)  // row_shr:1
+  HWY_DPP_MAX_(0x112, 0xf)  // row_shr:2
+  HWY_DPP_MAX_(0x114, 0xf)  // row_shr:4
+  HWY_DPP_MAX_(0x118, 0xf)  // row_shr:8  -> lane 15 of every row holds the row's maximum
+  HWY_DPP_MAX_(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  HWY_DPP_MAX_(0x143, 0xc)  // row_bcast:31 into rows 2 and 3  -> lane 63 holds the wavefront's
+#undef HWY_DPP_MAX_
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+#define HWY_WAVE_MAX_U32(v) ::hwy::wave_max_u32(v)
+#endif
+__device__ inline unsigned reach_key(double x) { return (unsigned)__double2hiint(x) & 0x7fffffffu; }
+__device__ inline double reach_from_keys(unsigned key_d, unsigned key_v, double dt) {
+  if (key_d >= 0x7fe00000u || key_v >= 0x7fe00000u) return __builtin_inf();
+  const double D = __hiloint2double((int)(key_d + 1u), 0), S = __hiloint2double((int)(key_v + 1u), 0);
+  return ((5.5 + S * dt) + 2.0 * D) + 1e-6;
+}
+
 // ---- rectangle SAT with swept extension (utils.py:196-241, objects.py:122-138,169-181) -----------
 // a = lower-index vehicle (the reference's `self`), b = the other.  Returns bit0 intersecting,
 // bit1 will_intersect; translation in (*tx,*ty) when will_intersect.
@@ -372,6 +409,7 @@ struct EnvBlock {
   struct Shared {
     double x[NV], y[NV], v[NV], c[NV], s[NV], ts[NV];
     double aux0[NV], aux1[NV];   // collision translation exchange / observation keys
+    unsigned gmax[2];  // full pairwise collisions: reach_key maxima of the frame (displacement along x, speed)
     double rpx[NV], rpy[NV], rpv[NV];  // full pairwise collisions: post-integration position / speed in the frame's RANK order
     int lane[NV], tgt[NV], perm[NV];
     u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
@@ -396,6 +434,20 @@ struct EnvBlock {
       u64 *slot = slot_pair + phase * NW;
       phase ^= 1;
       if ((i & 63) == 0) slot[i >> 6] = b;
+      __syncthreads();
+      for (int w = 0; w < NW; ++w) out[w] = slot[w];
+    }
+  }
+  // the same exchange for any wave-uniform word: out[w] = the value wavefront w passed.  Must be called by ALL threads.
+  __device__ static inline void block_share(Shared &sh, u64 value, u64 *slot_pair, int &phase, u64 out[NW]) {
+    if (NW == 1) {
+      out[0] = value;
+      __syncthreads();  // (callers order LDS traffic around the exchange: a one-wavefront workgroup's barrier costs next to nothing)
+    } else {
+      const int i = threadIdx.x;
+      u64 *slot = slot_pair + phase * NW;
+      phase ^= 1;
+      if ((i & 63) == 0) slot[i >> 6] = value;
       __syncthreads();
       for (int w = 0; w < NW; ++w) out[w] = slot[w];
     }
@@ -1296,9 +1348,17 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
 
     wave_turn(turn);
     // ---- G. Road.step: collisions (road.py:477-481, objects.py:92-138) ------------------------------------
+    if (i < 2) sh.gmax[i] = 0;  // (last read behind the second barrier of the previous frame's section G)
     __syncthreads();  // all reads of the frame-start snapshot are done
     publish<NW>(sh, me, active);
     if (all_check) {  // (block-uniform)
+      {  // this frame's largest displacement along x and largest speed (reach_key): per wavefront, then one ds_max per wavefront
+        const unsigned kd = HWY_WAVE_MAX_U32(active ? reach_key(me.x - x_old) : 0u), kv = HWY_WAVE_MAX_U32(active ? reach_key(me.v) : 0u);
+        if (lane_id == 0) {
+          __hip_atomic_fetch_max(&sh.gmax[0], kd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_max(&sh.gmax[1], kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       // frame-start x, and the post-integration position and speed, once more in the RANK order of this frame's start: a step of
       // the walk below then reads ONE slot (rank + k) of four planes and the index table -- no dependent second round trip
       if (active) { sh.aux0[rank] = x_old; sh.rpx[rank] = me.x; sh.rpy[rank] = me.y; sh.rpv[rank] = me.v; }
@@ -1306,8 +1366,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       sh.jmax[i] = -1;
       sh.hit[i] = 0;
     }
-    // the barrier that publishes the snapshot also answers "did any body move further / is any faster than the scan's bound"
-    const bool wide = __syncthreads_or(all_check && active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
+    __syncthreads();
     if (all_check) {
       // Full pairwise (highway-v0).  A pair can only collide if it is within ~5.5 m + |v| dt, i.e. among neighbours along the
       // road: every vehicle walks FORWARD in the rank order of this frame's start (each unordered pair is met once, from its
@@ -1319,14 +1378,12 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       // partner with the highest index is the last writer of `impact` in the reference's (i, j > i) loop) and the winner's
       // write of its translation.  (hwy_wave2.h has the one-wavefront version of the same walk; rounds 1-5 walked outward in
       // both directions through the index table and ran the separation test inside the walk, under divergence.)
-      // The bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in this frame and are not faster
-      // than 50 m/s afterwards; checked on the actual values, block-wide -- otherwise the walk is the literal all-pairs loop.
       unsigned short *const plist = sh.plist[i >> 6];
       const int lane_id_ = i & 63;
-      const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      const double reach = reach_from_keys(sh.gmax[0], sh.gmax[1], p.dt);  // (see reach_key: this frame's actual maxima)
       const u64 below = ((u64)1 << lane_id_) - 1;
       int n_list = 0, k = 1;  // wave-uniform
-      bool go = active, walking = true, any_pass = false;
+      bool go = active, walking = true, any_impact = false;
       for (;;) {
         while (walking && n_list < 64) {
           // two walk steps per trip (k and k + 1): every LDS read of the trip is issued before anything depends on one (the
@@ -1361,38 +1418,51 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
             }
           }
         }
-        if (__syncthreads_or(walking || n_list > 0) == 0) break;  // block-uniform
-        any_pass = true;
+        // The list pass of this round: this wavefront's pairs (if it has any -- no other wavefront's data is waited for: the
+        // bodies were published before the walk), then ONE barrier per round that also carries two bits per wavefront -- "I
+        // have more to do" and "one of my pairs holds a pending impact" (a slot per wavefront, B::block_share) -- instead of
+        // the three to four barriers per round of rounds 1-5; the winner's write of its translation, which needs every
+        // wavefront's ds_max, runs behind that barrier and only in the rounds in which some pair of the WORKGROUP collides.
         const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
-        const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
-        const int c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
-        const int c1 = 64 + lane_id_ < left ? (int)plist[count + 64 + lane_id_] : 0;
-        const int u0 = pair < 0 ? 0 : (pair & 255), u1 = pair < 0 ? 0 : (pair >> 8);  // (no pair: slot 0, discarded)
-        const int a = u0 < u1 ? u0 : u1, b = u0 < u1 ? u1 : u0;  // a < b: the reference's `self` and `other`
-        const Body A = B::body_of(sh, a), Bb = B::body_of(sh, b);
-        const bool cand = pair >= 0 && !hwy::surely_apart(A, Bb, p.dt);
-        int r = 0;
+        int r = 0, a = 0, b = 0, c0 = 0, c1 = 0;
         double tx = 0.0, ty = 0.0;
-        if (__ballot(cand) != 0) {  // wave-uniform
-          if (cand) {
-            r = hwy::pair_collide<NW != 2>(A, Bb, p.dt, &tx, &ty);
-            if (r & 1) sh.hit[a] = sh.hit[b] = 1;
-            if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
-              __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (count > 0) {  // wave-uniform
+          const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
+          c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
+          c1 = 64 + lane_id_ < left ? (int)plist[count + 64 + lane_id_] : 0;
+          const int u0 = pair < 0 ? 0 : (pair & 255), u1 = pair < 0 ? 0 : (pair >> 8);  // (no pair: slot 0, discarded)
+          a = u0 < u1 ? u0 : u1;  // a < b: the reference's `self` and `other`
+          b = u0 < u1 ? u1 : u0;
+          const Body A = B::body_of(sh, a), Bb = B::body_of(sh, b);
+          const bool cand = pair >= 0 && !hwy::surely_apart(A, Bb, p.dt);
+          if (__ballot(cand) != 0) {  // wave-uniform
+            if (cand) {
+              r = hwy::pair_collide<NW != 2>(A, Bb, p.dt, &tx, &ty);
+              if (r & 1) sh.hit[a] = sh.hit[b] = 1;
+              if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
+                __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&sh.jmax[b], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
           }
         }
-        __syncthreads();
-        if (r & 2) {
+        u64 rb[NW];
+        B::block_share(sh, ((walking || left > 0) ? 1u : 0u) | (__ballot((r & 2) != 0) ? 2u : 0u), sh.bal1, ph1, rb);
+        u64 round_bits = 0;
+        for (int w = 0; w < NW; ++w) round_bits |= rb[w];
+        if (r & 2) {  // (behind the barrier: every wavefront's ds_max has landed)
           if (sh.jmax[a] == b) { sh.aux1[a] = tx / 2; sh.ipy[a] = ty / 2; }
           if (sh.jmax[b] == a) { sh.aux1[b] = -tx / 2; sh.ipy[b] = -ty / 2; }
         }
-        if (lane_id_ < left) plist[lane_id_] = (unsigned short)c0;
-        if (64 + lane_id_ < left) plist[64 + lane_id_] = (unsigned short)c1;
+        if (count > 0) {  // (after this wavefront's own reads of the entries: its lanes run in lockstep, its LDS operations in order)
+          if (lane_id_ < left) plist[lane_id_] = (unsigned short)c0;
+          if (64 + lane_id_ < left) plist[64 + lane_id_] = (unsigned short)c1;
+        }
         n_list = left;
+        if (round_bits & 2) any_impact = true;
+        if (!(round_bits & 1)) break;  // block-uniform
       }
-      if (any_pass) __syncthreads();  // (block-uniform; without a pass nobody wrote a verdict slot since its reset)
+      if (any_impact) __syncthreads();  // (block-uniform: the translations written behind the last round's barrier)
       if (active && sh.jmax[i] >= 0) {
         me.impx = sh.aux1[i];
         me.impy = sh.ipy[i];
@@ -1519,6 +1589,10 @@ __device__ inline double math_probe(int op, double x) {
     case 31: { double a, b; fast_rcp2(3.0 * x, x, a, b); return b; }
     case 32: { double a, b; fast_rsqrt2(x, 3.0 * x, a, b); return a; }
     case 33: { double a, b; fast_rsqrt2(3.0 * x, x, a, b); return b; }
+    // the collision walk's reach bound: 40 = the wavefront's maximum of reach_key (call with whole wavefronts), 41 = the double the
+    // key is rounded up to
+    case 40: return (double)HWY_WAVE_MAX_U32(reach_key(x));
+    case 41: return __hiloint2double((int)(reach_key(x) + 1u), 0);
     default: return wrap_to_pi(x);
   }
 }

@@ -937,7 +937,7 @@ extern "C" int hwy_set_autoreset(hwy_engine *eng, int32_t enabled, uint64_t base
 }
 
 extern "C" int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n) {
-  if (!eng || !in || !out || n < 0 || op < 0 || (op > 11 && (op < 20 || op > 33))) return HWY_ERR_INVALID_ARG;
+  if (!eng || !in || !out || n < 0 || op < 0 || (op > 11 && (op < 20 || op > 33) && op != 40 && op != 41)) return HWY_ERR_INVALID_ARG;
   if (n == 0) return HWY_OK;
   HWY_HIP(eng, hipSetDevice(eng->device));
   double *d_in = nullptr, *d_out = nullptr;

@@ -705,7 +705,8 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       // other within one frame.  Everything within reach is visited, so the result equals the full loop; "last pair in loop
       // order wins" == the partner with the highest index.
       sh.nx[i] = me.x; sh.ny[i] = me.y; sh.nv[i] = me.v; sh.nc[i] = me.ch; sh.ns[i] = me.sh;
-      const bool wide = __ballot(active && !(fabs(me.x - x_old) <= 50.0 * p.dt + 3.0 && fabs(me.v) <= 50.0)) != 0;
+      // this frame's largest displacement along x and largest speed (hwy_device.h: reach_key, wave_max_u32)
+      const unsigned key_d = HWY_WAVE_MAX_U32(active ? reach_key(me.x - x_old) : 0u), key_v = HWY_WAVE_MAX_U32(active ? reach_key(me.v) : 0u);
       HWY_WAVE_LDS_FENCE();
       // The walk only COLLECTS the partners inside the reference's own pre-check sphere (objects.py:124-127), a dozen VALU
       // instructions per candidate; the list pass then runs, one PAIR per thread, the provable-separation test and -- if any
@@ -716,11 +717,9 @@ __device__ __forceinline__ void wave_policy_step(const StepParams &p, WaveShared
       unsigned short *const plist = reinterpret_cast<unsigned short *>(sh.v);  // 256 entries: lower slot | higher slot << 8
       jmax[i] = -1;
       hit[i] = 0;
-      // radius + relative motion, for bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and
-      // are not faster than 50 m/s afterwards (the radius term).  Both are checked on the actual values (`wide`,
-      // wave-uniform): the reference does not clamp speeds (clip_actions only pulls them back, kinematics.py:155-168)
-      // and hwy_set_state accepts any, so a faster body or a larger push turns the scan into the literal all-pairs loop.
-      const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      // radius + relative motion from the ACTUAL maxima of this frame (hwy_device.h: reach_from_keys; rounds 2-5 assumed 50 m/s
+      // and a 3 m impact -- 21.5 m -- and fell back to the all-pairs loop for anything faster)
+      const double reach = reach_from_keys(key_d, key_v, p.dt);
       const u64 below = ((u64)1 << i) - 1;
       int n_list = 0, k = 1;  // wave-uniform
       bool go_b = active, walking = true;

@@ -1018,8 +1018,8 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
       // provable-separation test and -- if any pair of the wavefront survives it -- the SAT; the verdicts meet per vehicle in LDS
       // ("last pair in loop order wins" == ds_max on the partner index, then the winner's write: hwy_wave.h has the
       // argument).  The list is a ring.
-      bool wide_any_ = false;
       HWY_WAVE_LDS_FENCE();  // every gather of the frame-start snapshot is done: all of it but x and idx is dead from here on
+      unsigned key_d = 0, key_v = 0;
 #pragma unroll
       for (int h = 0; h < K; ++h) {
         const int v = vi[h], r = rank[h];
@@ -1029,13 +1029,16 @@ __device__ __forceinline__ void wide_policy_step(const StepParams &p, WideShared
         if (active[h]) { sh.lr[r] = me[h].x; sh.c[r] = me[h].y; sh.v[r] = me[h].v; }
         sh.jmax[v] = -1;
         sh.hit[v] = 0;
-        wide_any_ = wide_any_ || (active[h] && !(fabs(me[h].x - x_old[h]) <= 50.0 * p.dt + 3.0 && fabs(me[h].v) <= 50.0));
+        // this frame's largest displacement along x and largest speed (hwy_device.h: reach_key)
+        const unsigned kd_ = active[h] ? reach_key(me[h].x - x_old[h]) : 0u, kv_ = active[h] ? reach_key(me[h].v) : 0u;
+        key_d = kd_ > key_d ? kd_ : key_d;
+        key_v = kv_ > key_v ? kv_ : key_v;
       }
-      // the bound assumes bodies that moved at most 50 m/s * dt + a 3 m impact along x in THIS frame and are not faster than
-      // 50 m/s afterwards; checked on the actual values (wave-uniform) -- otherwise the walk is the literal all-pairs loop
-      const bool wide = __ballot(wide_any_) != 0;
+      key_d = HWY_WAVE_MAX_U32(key_d);
+      key_v = HWY_WAVE_MAX_U32(key_v);
       HWY_WAVE_LDS_FENCE();
-      const double reach = wide ? __builtin_inf() : (5.5 + 50.0 * p.dt) + 2.0 * (50.0 * p.dt + 3.0);
+      // radius + relative motion from the ACTUAL maxima of this frame (hwy_device.h: reach_from_keys)
+      const double reach = reach_from_keys(key_d, key_v, p.dt);
       const u64 below = ((u64)1 << l) - 1;
       constexpr int PASS = 64 * K, RING = 512;  // at most PASS - 1 + 2 steps x 64 K entries are pending at any time
       int n_list = 0, head = 0, k = 1;  // wave-uniform

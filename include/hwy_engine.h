@@ -438,6 +438,8 @@ int hwy_set_block_order(hwy_engine *eng, const int32_t *env_of_block);
  * 9 atan2_bounded(x, 0.75), 10 atan2_bounded(0.5, x), 11 atan2_bounded(-0.5, x),
  * 6 fast_rsqrt, 7 wrap_to_pi; 20 .. 33: the paired forms (log_pos2, exp_bounded2, sincos_bounded2, asin_bounded2, fast_rcp2,
  * fast_rsqrt2: first / second result, see math_probe in csrc/hwy_device.h), which must equal the scalar ones bit for bit.
+ * 40 / 41: the collision walk's reach bound (hwy_device.h: the wavefront's maximum of reach_key -- call with whole wavefronts, n a
+ * multiple of 64 --, and the double a key is rounded up to).
  * Lets the accuracy claims (<= 2 ulp on the stated domains) be checked on the GPU.
  */
 int hwy_debug_math(hwy_engine *eng, int32_t op, const double *in, double *out, int64_t n);

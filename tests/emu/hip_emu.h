@@ -37,6 +37,7 @@
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
 #define HWY_SAT_FENCE() ((void)0)                     // hwy_device.h: scheduling / register-allocation constraints of the SAT (device build only)
 #define HWY_SAT_SETTLE(f) ((void)0)
+#define HWY_WAVE_MAX_U32(v) emu::wave_max_u32(v)          // hwy_device.h: DPP reduction on the device
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 
 struct emu_dim3 { int x = 0, y = 0, z = 0; };
@@ -150,6 +151,15 @@ inline int ds_bpermute(int addr, int v) {  // I read the value lane (addr/4)%64 
   buf[threadIdx.x] = v;
   wave_barrier();
   return buf[(threadIdx.x & ~63) + ((addr >> 2) & 63)];
+}
+}  // namespace emu
+namespace emu {
+inline unsigned wave_max_u32(unsigned v) {  // butterfly over the 64 fibers of the wavefront
+  for (int st = 1; st < 64; st <<= 1) {
+    const unsigned o = (unsigned)ds_bpermute((((int)threadIdx.x & 63) ^ st) << 2, (int)v);
+    v = o > v ? o : v;
+  }
+  return v;
 }
 }  // namespace emu
 #define __builtin_amdgcn_ds_bpermute(addr, v) emu::ds_bpermute((addr), (v))

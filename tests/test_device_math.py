@@ -96,3 +96,31 @@ def test_paired_routines_are_bit_identical_to_the_scalar_ones(eng):
     s, c = eng.debug_math(SIN, ang), eng.debug_math(COS, ang)
     for op, want in ((24, s), (25, c), (26, s), (27, c)):
         np.testing.assert_array_equal(eng.debug_math(op, ang), want, err_msg=f"op {op}")
+
+
+def test_reach_key_rounds_up(eng):
+    """hwy_device.h reach_key / reach_from_keys: the double a high-word key is rounded up to is never below the value it stands for
+    (a bound too small would let the forward collision walk stop before a partner inside the pre-check sphere)."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-60, 60, 20000), 10.0 ** rng.uniform(-300, 6, 20000), [0.0, -0.0, 2.0, 1e-310, 5e-324]])
+    up = eng.debug_math(41, x)
+    assert (up >= np.abs(x)).all()
+    big = np.abs(x) > 1e-300
+    assert (up[big] <= np.abs(x[big]) * (1 + 2.0 ** -19)).all()  # (the high word keeps 20 bits of the mantissa)
+
+
+@pytest.mark.gpu
+def test_wave_max_u32_on_the_device():
+    """hwy_device.h wave_max_u32 (six DPP v_max_u32 + v_readlane): every lane of a wavefront gets the maximum of the 64 keys --
+    whole wavefronts of random values, the maximum planted in every lane position once."""
+    from highwayenv_amd.engine import Engine
+    e = Engine(_abi.make_config(_abi.highway_fast_default_config(), 1, fast=True))
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0.0, 50.0, (128, 64))
+    for lane in range(64):
+        x[lane, lane] = 100.0 + lane
+    x[64:, :] *= 10.0 ** rng.integers(-8, 3, (64, 1))
+    got = e.debug_math(40, x.ravel()).reshape(x.shape)
+    key = (np.abs(x).view(np.uint64) >> 32).astype(np.float64)
+    assert (got == key.max(axis=1, keepdims=True)).all()
+    e.close()

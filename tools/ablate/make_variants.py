@@ -307,7 +307,10 @@ VARIANTS = {
               (IX, sub("((r.d * sa) * sh.irad[r.L] + r.g)", "(r.d * sa / r.c + r.g)"))],
     # generic workgroup kernel (hwy_device.h)
     "base": [],
-    "nocollide": [(D, cutter("    if (all_check) {\n      // Full pairwise (highway-v0): outward scan", "  }  // frames", "    if (false) {}\n"))],
+    "nocollide": [(D, sub("    if (all_check) {\n      // Full pairwise (highway-v0).  A pair can only collide", "    if (false) {\n      // Full pairwise (highway-v0).  A pair can only collide"))],
+    "nowalk": [(D, sub("      bool go = active, walking = true, any_impact = false;", "      bool go = false, walking = true, any_impact = false;"))],
+    "nomobil": [(D, sub("    if (decide) {\n      me.timer = 0.0;", "    if (false) {\n      me.timer = 0.0;"))],
+    "norankcheck": [(D, sub("    if (__syncthreads_or(stale)) {  // block-uniform", "    __syncthreads(); if (false) {"))],
     "nologexp": NO_LOGEXP,
     "nosincos": [(D, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))],
     "nosteer": [(D, sub("      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "      tb = inv_v * 1e-9;"))],
