@@ -258,6 +258,11 @@ __device__ inline bool surely_apart(const Body &A, const Body &B, double dt) {
 // say), wave-uniform result.  Six v_max_u32 with DPP operands -- a scan within each row of 16 lanes, then across the rows
 // (row_bcast15 / row_bcast31: GFX9) -- and a v_readlane: the obvious alternative, one ds_max_u32 per lane on a shared LDS word,
 // serialises its 64 lanes on ONE address in a pipeline the whole CU shares (measured: highway-v0 109 -> 160 us).
+// LDS written and read by ONE wavefront of a multi-wavefront workgroup: its LDS instructions execute in order, only the compiler
+// must keep them so (the CPU emulation of tests/emu, whose threads are fibers, needs a rendezvous of that wavefront's fibers).
+#ifndef HWY_WAVEFRONT_FENCE
+#define HWY_WAVEFRONT_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#endif
 #ifndef HWY_WAVE_MAX_U32
 __device__ inline unsigned wave_max_u32(unsigned v) {
   int x = (int)v;
@@ -1235,35 +1240,92 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       else B::neighbours_scan(p, sh, me.lane, i, me.x, &f_own, &r_own);
       free_self = B::idm_free(p, me.v, me.ts, me.delta);
     }
-    if (decide) {
-      me.timer = 0.0;
-      // self_a: my IDM acceleration behind my current leader (old_preceding)
-      const double self_a = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own],
-                                                                sh.c[f_own], sh.s[f_own]) : 0.0);
-      for (int side = 0; side < 2; ++side) {  // side_lanes: [id-1], [id+1]  (road.py:200-211)
-        const int cand = me.lane + (side == 0 ? -1 : 1);
-        if (cand < 0 || cand >= p.L) continue;
-        if (!B::reachable(p, cand, me.x, me.y)) continue;
-        if (fabs(me.v) < 1) continue;
-        // mobil(cand)  (behavior.py:265-324; route is None; POLITENESS == 0 so the followers' terms are
-        // multiplied by 0.0 -- finite by construction -- and only the safety criterion needs new_following)
-        int nprec, nfoll;
-        if (!has_tie) B::neighbours_ranked(sh, cand, rank, &nprec, &nfoll);
-        else B::neighbours_scan(p, sh, cand, i, me.x, &nprec, &nfoll);
-        // mobil() is a pure predicate: safety (new follower's braking) AND incentive (my gain) -- evaluated
-        // incentive first because it needs no pow() and rejects ~98% of the candidates
-        const double self_pred_a = free_self - (nprec >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[nprec], sh.v[nprec],
-                                                                        sh.c[nprec], sh.s[nprec]) : 0.0);
-        const double jerk = self_pred_a - self_a;
-        if (jerk < HWY_LC_MIN_ACC_GAIN) continue;
-        if (nfoll >= 0) {
-          const double nf_pred_a = B::idm_free(p, sh.v[nfoll], sh.ts[nfoll], me.delta) -
-                                   B::idm_gap(sh.x[nfoll], sh.v[nfoll], sh.c[nfoll], sh.s[nfoll], me.x, me.v, me.ch, me.sh);
-          if (nf_pred_a < -HWY_LC_MAX_BRAKING) continue;
+    if (!has_tie) {  // block-uniform
+      // MOBIL compacted per wavefront (hwy_wave.h has the one-wavefront version, round 6): a vehicle decides once per second, so in
+      // a given frame ~4 of a wavefront's 64 vehicles do -- and rounds 1-5 ran both side lanes one after the other for the whole
+      // wavefront whenever ONE of them decided.  Decider number d of the wavefront hands (free-road term, own-lane acceleration,
+      // delta, index | lane | side bits | rank) over through the wavefront's own stretch of LDS planes that only section G uses;
+      // lane t of the wavefront evaluates side t & 1 of decider t >> 1 from the frame-start snapshot (the very doubles the decider
+      // holds in registers); the verdicts come back as a ballot.  Same operations on the same values as the per-thread form below
+      // (kept for frames with equal x): bit-identical.
+      const bool moving = !(fabs(me.v) < 1);
+      const bool cl = decide && me.lane - 1 >= 0 && B::reachable(p, me.lane - 1, me.x, me.y) && moving;
+      const bool cr = decide && me.lane + 1 < p.L && B::reachable(p, me.lane + 1, me.x, me.y) && moving;
+      if (decide) me.timer = 0.0;
+      const u64 dm = __ballot(cl || cr);
+      if (dm) {  // wave-uniform
+        const int wbase = wave * 64, n_dec = __popcll(dm);
+        const int d = __popcll(dm & (((u64)1 << lane_id) - 1));
+        if (cl || cr) {
+          // self_a: my IDM acceleration behind my current leader (old_preceding)
+          const double self_a = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own],
+                                                                    sh.c[f_own], sh.s[f_own]) : 0.0);
+          sh.rpx[wbase + d] = free_self; sh.rpy[wbase + d] = self_a; sh.rpv[wbase + d] = me.delta;
+          sh.jmax[wbase + d] = i | (me.lane << 8) | (cl ? 1 << 12 : 0) | (cr ? 1 << 13 : 0) | (rank << 16);
         }
-        me.tgt = cand;
+        HWY_WAVEFRONT_FENCE();  // (written and read by this wavefront only)
+        int bits = 0;
+        for (int base = 0; base < 2 * n_dec; base += 64) {  // wave-uniform
+          const int t = base + lane_id;
+          const bool tv = t < 2 * n_dec;
+          const int dd = tv ? t >> 1 : 0, side = t & 1;
+          const int w_ = sh.jmax[wbase + dd];
+          const int vi = w_ & 255, ln = (w_ >> 8) & 15, rk = (w_ >> 16) & 255;
+          const bool en = tv && ((w_ >> (12 + side)) & 1);
+          const double fs = sh.rpx[wbase + dd], sa = sh.rpy[wbase + dd], dl = sh.rpv[wbase + dd];
+          const double ex = sh.x[vi], ev = sh.v[vi], ec = sh.c[vi], es = sh.s[vi];
+          // mobil(cand)  (behavior.py:265-324; route is None; POLITENESS == 0 so the followers' terms are multiplied by 0.0 --
+          // finite by construction -- and only the safety criterion needs new_following): incentive first, it needs no pow()
+          // and rejects ~98 % of the candidates
+          int nprec, nfoll;
+          B::neighbours_ranked(sh, en ? ln + (side ? 1 : -1) : ln, rk, &nprec, &nfoll);
+          const int gp = nprec < 0 ? 0 : nprec;
+          const double self_pred_a = fs - (nprec >= 0 ? B::idm_gap(ex, ev, ec, es, sh.x[gp], sh.v[gp], sh.c[gp], sh.s[gp]) : 0.0);
+          const double jerk = self_pred_a - sa;
+          bool ok = en && !(jerk < HWY_LC_MIN_ACC_GAIN);
+          const bool pend = ok && nfoll >= 0;
+          if (__ballot(pend) != 0) {  // wave-uniform: the new follower's braking
+            const int gf = pend ? nfoll : 0;
+            const double nf_pred_a = B::idm_free(p, sh.v[gf], sh.ts[gf], dl) - B::idm_gap(sh.x[gf], sh.v[gf], sh.c[gf], sh.s[gf], ex, ev, ec, es);
+            if (pend) ok = !(nf_pred_a < -HWY_LC_MAX_BRAKING);
+          }
+          const u64 okm = __ballot(ok);
+          if ((cl || cr) && 2 * d >= base && 2 * d < base + 64) bits = (int)(okm >> (2 * d - base)) & 3;
+        }
+        // side_lanes order is [left, right] and the loop does not break: right wins if both pass
+        if (bits & 1) me.tgt = me.lane - 1;
+        if (bits & 2) me.tgt = me.lane + 1;
       }
-    }
+    } else
+      if (decide) {
+        me.timer = 0.0;
+        // self_a: my IDM acceleration behind my current leader (old_preceding)
+        const double self_a = free_self - (f_own >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[f_own], sh.v[f_own],
+                                                                  sh.c[f_own], sh.s[f_own]) : 0.0);
+        for (int side = 0; side < 2; ++side) {  // side_lanes: [id-1], [id+1]  (road.py:200-211)
+          const int cand = me.lane + (side == 0 ? -1 : 1);
+          if (cand < 0 || cand >= p.L) continue;
+          if (!B::reachable(p, cand, me.x, me.y)) continue;
+          if (fabs(me.v) < 1) continue;
+          // mobil(cand)  (behavior.py:265-324; route is None; POLITENESS == 0 so the followers' terms are
+          // multiplied by 0.0 -- finite by construction -- and only the safety criterion needs new_following)
+          int nprec, nfoll;
+          if (!has_tie) B::neighbours_ranked(sh, cand, rank, &nprec, &nfoll);
+          else B::neighbours_scan(p, sh, cand, i, me.x, &nprec, &nfoll);
+          // mobil() is a pure predicate: safety (new follower's braking) AND incentive (my gain) -- evaluated
+          // incentive first because it needs no pow() and rejects ~98% of the candidates
+          const double self_pred_a = free_self - (nprec >= 0 ? B::idm_gap(me.x, me.v, me.ch, me.sh, sh.x[nprec], sh.v[nprec],
+                                                                          sh.c[nprec], sh.s[nprec]) : 0.0);
+          const double jerk = self_pred_a - self_a;
+          if (jerk < HWY_LC_MIN_ACC_GAIN) continue;
+          if (nfoll >= 0) {
+            const double nf_pred_a = B::idm_free(p, sh.v[nfoll], sh.ts[nfoll], me.delta) -
+                                     B::idm_gap(sh.x[nfoll], sh.v[nfoll], sh.c[nfoll], sh.s[nfoll], me.x, me.v, me.ch, me.sh);
+            if (nf_pred_a < -HWY_LC_MAX_BRAKING) continue;
+          }
+          me.tgt = cand;
+        }
+      }
     // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
     {
       // A rival is ANOTHER vehicle on its way to another lane (with the target it had at the start of the frame or the one

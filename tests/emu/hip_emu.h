@@ -37,6 +37,7 @@
 #define HWY_WAVE_LDS_FENCE() __syncthreads()  // hwy_wave.h: the 64 fibers of a workgroup need a real rendezvous
 #define HWY_SAT_FENCE() ((void)0)                     // hwy_device.h: scheduling / register-allocation constraints of the SAT (device build only)
 #define HWY_SAT_SETTLE(f) ((void)0)
+#define HWY_WAVEFRONT_FENCE() emu::wave_barrier()          // hwy_device.h: LDS handed over within one wavefront of a workgroup
 #define HWY_WAVE_MAX_U32(v) emu::wave_max_u32(v)          // hwy_device.h: DPP reduction on the device
 #define HWY_KC(c) (c)  // hwy_math.h: SGPR-pinned constant (an AMDGPU inline-asm constraint on the device)
 
