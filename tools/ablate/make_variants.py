@@ -111,7 +111,7 @@ def wide_ticks(text):
     # collisions split: [11] = publish, [12] = walk trips, [13] = list passes, (G itself: the verdict reads); [14] walk trips, [15] list passes with >= 1 pair, [18] pairs
     t = sub("long long acc[11] = {0,0,0,0,0,0,0,0,0,0,0};", "long long acc[24] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
     t = sub("for (int k = 0; k < 16; ++k) q.obs", "for (int k = 0; k < 24; ++k) q.obs")(t)
-    t = sub("      const double reach = wide ? __builtin_inf()", "      TICK(11)\n      const double reach = wide ? __builtin_inf()")(t)
+    t = sub("      const double reach = reach_from_keys(key_d, key_v, p.dt);", "      TICK(11)\n      const double reach = reach_from_keys(key_d, key_v, p.dt);")(t)
     t = sub("        const int count = n_list < PASS ? n_list : PASS;\n",
             "        const int count = n_list < PASS ? n_list : PASS;\n        TICK(12)\n        acc[15] += count > 0; acc[18] += count;\n")(t)
     t = sub("        head = (head + count) & (RING - 1);\n", "        head = (head + count) & (RING - 1);\n        TICK(13)\n")(t)
@@ -151,8 +151,8 @@ def net_ticks(text):
     t = sub("          k += WS;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;", "          k += WS;\n          n_walk += (float)WS;\n          if (__ballot(go_b) == 0 || k >= n_present) walking = false;")(t)
     t = sub("            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);", "            n_sat += 1.0f;\n            r = net_pair_collide(A, Bb, p.dt, &tx, &ty);")(t)
     t = sub("  long long t_prev = clock64(); long long acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};", "  float n_walk = 0, n_trip = 0, n_sat = 0; long long t_prev = clock64(); long long acc[13] = {0,0,0,0,0,0,0,0,0,0,0,0,0};")(t)
-    t = sub("    me.rank = rank & 0xff;  // the hint the next step verifies\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
-            "    TICK(11)\n    me.rank = rank & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
+    t = sub("    if (p.n_frames > 0) me.rank = rank & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n}",
+            "    TICK(11)\n    if (p.n_frames > 0) me.rank = rank & 0xff;\n    store_vehicle<1>(p, e, me, false);\n  }\n"
             "  { float sat_any = __ballot(n_sat > 0) ? 1.0f : 0.0f; n_sat = 0; for (int j = 0; j < 64; ++j) n_sat += __shfl(sat_any, j) * 0 ; n_sat = sat_any;\n"
             "  if (i == 0 && p.obs) { for (int k = 0; k < 13; ++k) p.obs[(size_t)e * p.A * p.V * p.F + k] = (float)acc[k];\n"
             "    p.obs[(size_t)e * p.A * p.V * p.F + 13] = n_walk; p.obs[(size_t)e * p.A * p.V * p.F + 14] = n_trip; p.obs[(size_t)e * p.A * p.V * p.F + 15] = n_sat; } }\n}")(t)
@@ -262,8 +262,8 @@ VARIANTS = {
                           "  }\n}")),
                   # event counters (LDS atomics): SAT trips, near pairs, chain links (all / with a rival), follower-test trips, recounts
                   (W, sub("struct WaveShared {", "struct WaveShared {\n  int cnt[8];")),
-                  (W, sub("  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift);",
-                          "  if (i < 8) sh.cnt[i] = 0;\n  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift);")),
+                  (W, sub("  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift, p.prio_recip);",
+                          "  if (i < 8) sh.cnt[i] = 0;\n  WaveTurn turn;\n  wave_turn_init(turn, p.prio_shift, p.prio_recip);")),
                   (W, sub("              r = pair_collide(A, Bb, p.dt, &tx, &ty);", "              atomicAdd(&sh.cnt[0], 1); r = pair_collide(A, Bb, p.dt, &tx, &ty);")),
                   (W, sub("            if (!surely_apart(A, Bb, p.dt)) {", "            atomicAdd(&sh.cnt[1], 1);\n            if (!surely_apart(A, Bb, p.dt)) {")),
                   # (round 5: the rank-space chain -- cnt[2] = frames with a chain, cnt[3] = walk trips of it)
@@ -320,6 +320,10 @@ VARIANTS = {
 
 # compiler-flag experiments on the unmodified sources
 FLAG_VARIANTS = {
+    # (the stamped road-network kernel with the SAT's register-allocation constraints crashes this toolchain's register allocator --
+    #  hwy_device.h: sat_axis<SETTLE> has the same story for the two-wavefront workgroup kernel; the stamps only time sections)
+    "nticks": ["-DHWY_SAT_FENCE()=((void)0)", "-DHWY_SAT_SETTLE(f)=((void)0)"],
+    "nresetticks": ["-DHWY_SAT_FENCE()=((void)0)", "-DHWY_SAT_SETTLE(f)=((void)0)"],
     "f_base": [],
     "f_noslp": ["-fno-slp-vectorize"],
     "f_nounroll": ["-fno-unroll-loops"],
