@@ -67,6 +67,7 @@ timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 1024 --no-cpu-base
 timeout 200 python bench.py --workload v0_n100 --envs-per-gpu 2048 --no-cpu-baseline --steps 300 --repeats 3 --tune block_kernel=1 > $O/bench_cfg3_2048_block_kernel.json 2>> $O/bench_misc.err
 # the fuzz last (the longest single item): chunks HWY_FUZZ_FIRST .. + HWY_FUZZ_CHUNKS of every family on the final library
 [ -z "$HWY_PROFILE_SKIP_TESTS" ] && { HWY_FUZZ_CHUNKS=${HWY_FUZZ_CHUNKS:-300} HWY_FUZZ_FIRST=${HWY_FUZZ_FIRST:-0} timeout 2400 python -m pytest tests/test_fuzz_configs.py -m gpu -q -s -p no:cacheprovider > $O/gpu_fuzz.txt 2>&1; tail -2 $O/gpu_fuzz.txt; }
-# keep the merged output small: only the stats / counter CSVs
+# keep the merged output small: only the stats / counter CSVs (gpurun merges at most 64 MiB back; tools/pmc_sq.sh leaves its raw passes in gpurun_out/pmc_*)
+rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/pmc_sq_*.json
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O
