@@ -315,8 +315,10 @@ struct SatAcc {
 // minimum at once.  `first_minus`: the reference meets -n first (the body axis u: order -u .. +u) or +n first (w: +w .. -w);
 // k0 / k1 = positions of the two normals in the reference's loop, so "first minimum wins" becomes "smaller |d|, then
 // smaller position" and no per-axis result has to stay live until its turn.
-// SETTLE = false: without the register-allocation constraints (the two-wavefront workgroup kernel: with them, this toolchain's
-// greedy register allocator crashes on exactly that instantiation -- ROCm 7.2 clang 22, -disable-machine-licm + iterative-ilp)
+// SETTLE = false: without the register-allocation constraints.  An escape hatch, unused at present: midway through round 6 this
+// toolchain's greedy register allocator (ROCm 7.2 clang 22, -disable-machine-licm + iterative-ilp together) segfaulted on the
+// two-wavefront workgroup kernel -- and on the stamped road-network build of tools/ablate -- with the constraints in place; later
+// changes to the surrounding code made it go away, nothing that was understood.
 template <bool SETTLE = true>
 __device__ inline void sat_axis(SatAcc &acc, double nx, double ny, double ca_, double ra, double cb_, double rb,
                                 double vp, double cdx, double cdy, int k_plus, int k_minus) {
@@ -613,7 +615,7 @@ struct EnvBlock {
     return hwy::surely_apart(body_of(sh, a), body_of(sh, b), dt);
   }
   __device__ static inline int pair_collide(const Shared &sh, int a, int b, double dt, double *tx, double *ty) {
-    return hwy::pair_collide<NW != 2>(body_of(sh, a), body_of(sh, b), dt, tx, ty);
+    return hwy::pair_collide(body_of(sh, a), body_of(sh, b), dt, tx, ty);
   }
 
   // ---- Vehicle.to_dict feature (vehicle/kinematics.py:237-261) ---------------------------------------
@@ -1499,7 +1501,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
           const bool cand = pair >= 0 && !hwy::surely_apart(A, Bb, p.dt);
           if (__ballot(cand) != 0) {  // wave-uniform
             if (cand) {
-              r = hwy::pair_collide<NW != 2>(A, Bb, p.dt, &tx, &ty);
+              r = hwy::pair_collide(A, Bb, p.dt, &tx, &ty);
               if (r & 1) sh.hit[a] = sh.hit[b] = 1;
               if (r & 2) {  // "last pair in loop order wins" == the partner with the highest index
                 __hip_atomic_fetch_max(&sh.jmax[a], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

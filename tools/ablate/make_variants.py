@@ -97,8 +97,8 @@ def wide_ticks(text):
              "    // ---- C. rank along the road, lane membership masks, frame-start snapshot",
              "    double log_ratio[K];",
              "    // ---- D. Road.act: lane-change policy (behavior.py:219-263)",
-             "    // Straight-line evaluation for every slot",
-             "    // safety of the new follower, only for candidates",
+             "    if constexpr (K == 2) {  // EnvBlock::idm_free_from_log for both vehicles at once",
+             "      if (n_dec) {  // wave-uniform",
              "    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain over Road.vehicles",
              "    // ---- E. Road.act: low-level control, F. Road.step: integrate",
              "    // ---- G. Road.step: collisions (road.py:477-481",

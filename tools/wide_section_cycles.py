@@ -30,8 +30,8 @@ for t in range(60):
         rows.append(r)
         tot += r.mean(0)
         n += 1
-names = ["load", "A meta-action", "C rank check", "C snapshot + masks", "D neighbour ranks", "D gaps + mobil incentive",
-         "D follower safety", "D abort chain", "E+F control + integrate", "G collisions", "H observe"]
+names = ["load", "A meta-action", "C rank check", "C snapshot + masks", "D neighbour ranks", "D free road + own gap   ",
+         "D MOBIL tasks    ", "D abort chain", "E+F control + integrate", "G collisions", "H observe"]
 tot /= n
 for k, nm in enumerate(names):
     print(f"{nm:26s} {tot[k]:10.0f} ticks/step/wave  {100 * tot[k] / tot[:11].sum():5.1f}%")
