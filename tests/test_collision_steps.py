@@ -146,8 +146,10 @@ def _inject_fast_bodies(st, rng, n_vehicles, speeds, lanes_y=None):
 @pytest.mark.parametrize("kernel", ["wave", "block", "two_waves"])
 def test_fast_bodies_are_not_missed_by_the_bounded_scan(backend, kernel):
     """Road.step tests ALL pairs (road.py:477-481) and nothing clamps a speed (clip_actions only pulls it back,
-    kinematics.py:155-168; hwy_set_state accepts any).  The kernels walk outwards in rank order up to a reach derived
-    from 50 m/s: bodies at 60..600 m/s must switch the walk to the literal all-pairs loop.  Flags exact vs the oracle."""
+    kinematics.py:155-168; hwy_set_state accepts any).  The kernels walk forward in rank order up to a reach derived from the
+    frame's ACTUAL largest displacement and speed (hwy_device.h: reach_from_keys; rounds 2-5: from 50 m/s, with an all-pairs
+    fallback): bodies at 60..600 m/s that close 8..46 m within one frame must be found.  Flags exact vs the oracle
+    (tests/test_mutations.py: a reach that forgets the frame's motion fails here)."""
     cfg_d = _abi.highway_default_config()
     cfg_d.update({"vehicles_count": 100 if kernel == "two_waves" else 40, "lanes_count": 4})
     if kernel == "block":

@@ -1,6 +1,6 @@
 """Mutation check of the parity rules (round-3 verdict): the randomised engine-vs-oracle comparisons tolerate -- and count -- a
 few knife-edge cases of the reference itself (a push direction, a touching pair, a lane index or a queue order decided by the
-last bit).  Could those rules hide a real defect?  Three bugs are seeded into the kernel SOURCE, the CPU emulator is built from
+last bit).  Could those rules hide a real defect?  Four bugs are seeded into the kernel SOURCE, the CPU emulator is built from
 each mutated copy (tests/emu: the same headers the GPU build compiles), and the comparison that covers the mutated path must
 FAIL on it -- while passing on the unmutated build:
 
@@ -9,7 +9,9 @@ FAIL on it -- while passing on the unmutated build:
 * `net_pair_list_carry`  -- the road-network kernel's pair list carries the overflow of a pass (> 64 close pairs) to the next
   pass shifted by one entry: only visible with more close pairs than one pass holds;
 * `mobil_sides_swapped`  -- the one-wavefront kernel weighs the LEFT lane change with the right lane's gap and vice versa
-  (behavior.py:265-324).
+  (behavior.py:265-324);
+* `reach_ignores_motion` -- the forward collision walk of the three highway kernels stops at the pre-check radius of bodies at rest,
+  forgetting what the frame moved them (road.py:477-481 tests ALL pairs): only visible with bodies that close a gap within one frame.
 
 Each case runs the real test functions in a subprocess with HWY_EMU_LIB pointing at the mutant."""
 import os
@@ -31,6 +33,8 @@ MUTANTS = {
          "const int j_imp = (i < SH::kCap && sh.jmax[i] != 0x7fffffff) ? sh.jmax[i] : -1;")],
     "net_pair_list_carry": [
         ("hwy_net.h", "const int carry = i < left ? (int)plist[count + i] : 0,", "const int carry = i < left ? (int)plist[count + i + 1] : 0,")],
+    "reach_ignores_motion": [   # (round 6: the forward collision walk's reach from the frame's maxima, hwy_device.h reach_from_keys)
+        ("hwy_device.h", "return ((5.5 + S * dt) + 2.0 * D) + 1e-6;", "return ((5.5 + 0.0 * S * dt) + 0.0 * D) + 1e-6;")],
     "mobil_sides_swapped": [   # (the compacted MOBIL tasks of round 6: side 0 = left reads row lane, side 1 = right row lane + 2)
         ("hwy_wave.h", "const u64 m = sh.lane_mask[ln + (side ? 2 : 0)];", "const u64 m = sh.lane_mask[ln + (side ? 0 : 2)];")],
 }
@@ -42,6 +46,7 @@ CASES = [
     ("ix_first_pair_wins", ["tests/test_fuzz_configs.py", "-m", "gpu", "-k", "intersection"], dict(FUZZ, HWY_FUZZ_FIRST="1")),
     ("net_pair_list_carry", ["tests/test_pileup.py", "-m", "not gpu", "-k", "merge"], {}),
     ("mobil_sides_swapped", ["tests/test_fuzz_configs.py", "-m", "gpu", "-k", "test_random_configurations_vs_oracle"], FUZZ),
+    ("reach_ignores_motion", ["tests/test_collision_steps.py", "-m", "not gpu", "-k", "fast_bodies_are_not_missed"], {}),
 ]
 
 
