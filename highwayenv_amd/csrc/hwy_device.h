@@ -420,6 +420,8 @@ struct EnvBlock {
     double rpx[NV], rpy[NV], rpv[NV];  // full pairwise collisions: post-integration position / speed in the frame's RANK order
     int lane[NV], tgt[NV], perm[NV];
     u64 mask[HWY_MAX_LANES][NW];  // lane membership in rank space
+    u64 amask[HWY_MAX_LANES][NW]; // abort chain: the vehicles heading for lane T from another lane, in rank space (row T)
+    int acode[NV];                // abort chain, index space: decided in this frame | changer << 1
     u64 bal0[2 * NW], bal1[2 * NW], bal2[2 * NW];  // block_ballot slot pairs
     u64 chk[NW];                  // vehicles with check_collisions (index space)
     // full pairwise collisions: per-wavefront list of candidate pairs (lower index | higher index << 8) and the per-vehicle
@@ -992,9 +994,10 @@ template <int NW>
 __device__ inline void publish(typename EnvBlock<NW>::Shared &sh, const Veh &me, bool active) {
   const int i = threadIdx.x;
   if (active) {
-    sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = me.ch; sh.s[i] = me.sh; sh.ts[i] = me.ts;
+    sh.x[i] = me.x; sh.y[i] = me.y; sh.v[i] = me.v; sh.c[i] = me.ch; sh.s[i] = me.sh;
     sh.lane[i] = me.lane; sh.tgt[i] = me.tgt;
   }
+  sh.ts[i] = me.ts;  // (every thread: section G of the step reads its own slot back, see there)
 }
 
 // =============================================================================================
@@ -1201,7 +1204,7 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       for (int L = 0; L < p.L; ++L) {
         const bool m = inr && (fabs(yj - L * p.lane_width) <= p.lane_width / 2 + 1.0);
         const u64 b = __ballot(m);
-        if (lane_id == 0) sh.mask[L][wave] = b;
+        if (lane_id == 0) { sh.mask[L][wave] = b; sh.amask[L][wave] = 0; }  // (amask: the abort chain of section D ORs into it)
       }
     };
     write_masks();
@@ -1328,7 +1331,10 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
           me.tgt = cand;
         }
       }
-    // abort rule for ongoing lane changes: ordered chain (Gauss-Seidel over Road.vehicles order)
+    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain (Gauss-Seidel over Road.vehicles order).
+    // A changer c (on its way to lane T since an earlier frame) aborts if ANOTHER vehicle r heading for T from a third lane -- with
+    // the target r has when c acts: its current one for r before c in the list, the frame-start one for r after c -- is ahead of it
+    // by less than the desired gap d*(c, r).
     {
       // A rival is ANOTHER vehicle on its way to another lane (with the target it had at the start of the frame or the one
       // it has now): with at most one such vehicle in the environment no link can block
@@ -1336,24 +1342,98 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
       B::block_ballot2(sh, active && (me.lane != tgt_old || me.lane != me.tgt), changer, sh.bal0, sh.bal2, ph0, ph2, mv, cm);
       int n_movers = 0;
       for (int w = 0; w < NW; ++w) n_movers += __popcll(mv[w]);
-      for (int w = 0; w < NW && n_movers > 1; ++w) {
-        u64 m = cm[w];
-        while (m) {  // block-uniform loop
-          const int ci = w * 64 + ctz64(m);
-          m &= m - 1;
-          const int Tc = sh.tgt[ci];  // the changer's target lane (unchanged so far this frame)
-          const double xc = sh.x[ci], vc = sh.v[ci], cc = sh.c[ci], sc = sh.s[ci];
-          // what vehicle ci reads from me: my target AFTER my act if I come before it in the list
-          const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
-          bool blk = false;
-          if (active && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
-            const double d = me.x - xc;
-            const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
-            blk = (0 < d) && (d < d_star);
+      const bool chain = n_movers > 1 && B::any_of(cm);  // block-uniform
+#ifndef HWY_BLOCK_LITERAL_CHAIN
+      if (chain && !has_tie) {
+        // The chain per THREAD, in rank space (hwy_wave2.h has the argument in full; rounds 1-5 ran one link per changer here, every
+        // link a workgroup barrier and a desired gap for all threads: 18 of 222 us at 1024 x 201).
+        //  * a rival must be AHEAD and closer than d*, and d* <= 10 + 1.5 v + v (v + 5) / (2 sqrt(ab)) for every possible rival as long
+        //    as no vehicle of the environment drives backwards or sideways faster than 5 m/s (checked: otherwise the bound is
+        //    infinite): in the rank order of the snapshot a changer walks the members of "heading for T" ahead of it and stops at the
+        //    first one beyond that bound -- usually the very first;
+        //  * the links only interact through ABORTS, and an abort can only REMOVE a rival (its target becomes its own lane): a
+        //    blocking rival that is itself an EARLIER changer counts only while it has not aborted, every other one for good;
+        //  * a link depends on earlier links only, so iterating "aborts = blocked by a rival that is not an earlier changer, or by
+        //    an earlier changer that does not abort" from "nobody aborts" reaches the literal chain's result after (depth + 1)
+        //    rounds: one workgroup ballot per round, two rounds when somebody aborts, one when nobody does.
+        // (1) S_T (rank space) = the vehicles heading for lane T from another lane: every such vehicle ORs its rank bit into row T
+        // (zeroed with the membership masks of section C); what a walker needs of a rival beyond the snapshot goes by index
+        if (active && me.lane != me.tgt)
+          __hip_atomic_fetch_or(&sh.amask[me.tgt][rank >> 6], (u64)1 << (rank & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sh.acode[i] = ((me.tgt != tgt_old) ? 1 : 0) | (changer ? 2 : 0);
+        const bool sane = !__syncthreads_or(active && !(me.v * me.ch >= 0.0 && fabs(me.v * me.sh) <= 5.0));
+        // d*(c, r) = 10 + 1.5 v + v dv / (2 sqrt(ab)) with dv = v (cc^2 + sc^2) - v_r (c_r cc + s_r sc) <= v + 5 + (rounding) when v_r c_r >= 0,
+        // |v_r s_r| <= 5 (sane) and cc >= 0, v >= 0; 1e-6 relative + absolute on top of the bound, far above any rounding in d*
+        const double bound = (sane && me.v >= 0.0 && me.ch >= 0.0)
+                                 ? (HWY_DISTANCE_WANTED + me.v * HWY_TIME_WANTED + me.v * (me.v + 5.0) * 0.12909944487358055) * (1.0 + 1e-6) + 1e-6
+                                 : __builtin_inf();
+        const u64 *prev = nullptr;  // the previous round's verdicts (index space: the ballot's own LDS slot); none in the first round
+        for (;;) {  // block-uniform
+          // (2) the walk: nearest member of S_T ahead first; beyond the bound everything farther is beyond it too
+          bool fire = false;
+          if (changer) {
+            int cur = rank;
+            for (;;) {
+              int rr = -1;
+              const int rw = cur >> 6, rb = cur & 63;
+              for (int w = rw; w < NW; ++w) {
+                u64 m = sh.amask[tgt_old][w];
+                if (w == rw) m &= ~(((u64)2 << rb) - 1);  // ranks > cur  (2 << 63 wraps to 0 => all cleared)
+                if (m) { rr = w * 64 + ctz64(m); break; }
+              }
+              if (rr < 0) break;
+              const int j = sh.perm[rr];
+              const double d = sh.x[j] - me.x;
+              if (!(d < bound)) break;
+              const int fl = sh.acode[j];
+              // the target r shows to c: its current one if it comes before c in the list, else the frame-start one -- and a vehicle
+              // that decided in this very frame headed nowhere with that one
+              const bool valid = j < i || !(fl & 1);
+              const double d_star = B::desired_gap(me.v, me.ch, me.sh, sh.v[j], sh.c[j], sh.s[j]);
+              const bool blk = valid && (0 < d) && (d < d_star);
+              // an earlier changer may abort itself: it blocks only while it has not
+              const bool gone = j < i && (fl & 2) != 0 && prev != nullptr && ((prev[j >> 6] >> (j & 63)) & 1) != 0;
+              if (blk && !gone) { fire = true; break; }
+              cur = rr;
+            }
           }
-          u64 bm[NW];
-          B::block_ballot(sh, blk, sh.bal1, ph1, bm);
-          if (i == ci && B::any_of(bm)) me.tgt = me.lane;  // abort
+          // (3) the changers that abort, to the fixed point: the verdicts of a round are a workgroup ballot (its slot pair alternates,
+          // so the previous round's words are still there to compare with and to read in the next walk)
+          const u64 b = __ballot(fire);
+          u64 *slot = sh.bal1 + ph1 * NW;
+          ph1 ^= 1;
+          if (lane_id == 0) slot[wave] = b;
+          __syncthreads();
+          bool same = true;
+          for (int w = 0; w < NW; ++w) same = same && slot[w] == (prev ? prev[w] : (u64)0);
+          prev = slot;
+          if (same) break;
+        }
+#ifndef HWY_BLOCK_MUTANT_NO_ABORT  // (tests/test_wide_kernel.py: a build that never applies the verdict must fail the comparison)
+        if ((prev[wave] >> lane_id) & 1) me.tgt = me.lane;  // abort
+#endif
+      } else
+#endif
+      if (chain) {  // equal x somewhere in the environment (rare): the literal chain, one link per changer
+        for (int w = 0; w < NW; ++w) {
+          u64 m = cm[w];
+          while (m) {  // block-uniform loop
+            const int ci = w * 64 + ctz64(m);
+            m &= m - 1;
+            const int Tc = sh.tgt[ci];  // the changer's target lane (unchanged so far this frame)
+            const double xc = sh.x[ci], vc = sh.v[ci], cc = sh.c[ci], sc = sh.s[ci];
+            // what vehicle ci reads from me: my target AFTER my act if I come before it in the list
+            const int my_tgt_seen = (i < ci) ? me.tgt : tgt_old;
+            bool blk = false;
+            if (active && i != ci && me.lane != Tc && my_tgt_seen == Tc) {
+              const double d = me.x - xc;
+              const double d_star = B::desired_gap(vc, cc, sc, me.v, me.ch, me.sh);
+              blk = (0 < d) && (d < d_star);
+            }
+            u64 bm[NW];
+            B::block_ballot(sh, blk, sh.bal1, ph1, bm);
+            if (i == ci && B::any_of(bm)) me.tgt = me.lane;  // abort
+          }
         }
       }
     }
@@ -1488,12 +1568,10 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
         // the three to four barriers per round of rounds 1-5; the winner's write of its translation, which needs every
         // wavefront's ds_max, runs behind that barrier and only in the rounds in which some pair of the WORKGROUP collides.
         const int count = n_list < 64 ? n_list : 64, left = n_list - count;  // left < 128
-        int r = 0, a = 0, b = 0, c0 = 0, c1 = 0;
+        int r = 0, a = 0, b = 0;
         double tx = 0.0, ty = 0.0;
         if (count > 0) {  // wave-uniform
           const int pair = lane_id_ < count ? (int)plist[lane_id_] : -1;
-          c0 = lane_id_ < left ? (int)plist[count + lane_id_] : 0;
-          c1 = 64 + lane_id_ < left ? (int)plist[count + 64 + lane_id_] : 0;
           const int u0 = pair < 0 ? 0 : (pair & 255), u1 = pair < 0 ? 0 : (pair >> 8);  // (no pair: slot 0, discarded)
           a = u0 < u1 ? u0 : u1;  // a < b: the reference's `self` and `other`
           b = u0 < u1 ? u1 : u0;
@@ -1518,7 +1596,13 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
           if (sh.jmax[a] == b) { sh.aux1[a] = tx / 2; sh.ipy[a] = ty / 2; }
           if (sh.jmax[b] == a) { sh.aux1[b] = -tx / 2; sh.ipy[b] = -ty / 2; }
         }
-        if (count > 0) {  // (after this wavefront's own reads of the entries: its lanes run in lockstep, its LDS operations in order)
+        if (left > 0) {  // (wave-uniform; then count == 64)
+          // the entries this pass did not take move to the front: read behind the SAT, not before it -- two registers less across the
+          // routine the kernel's pressure peaks in; this wavefront's lanes run in lockstep and its LDS operations in order, so both
+          // reads land before either write
+          const int c0 = lane_id_ < left ? (int)plist[64 + lane_id_] : 0;
+          const int c1 = 64 + lane_id_ < left ? (int)plist[128 + lane_id_] : 0;
+          HWY_WAVEFRONT_FENCE();
           if (lane_id_ < left) plist[lane_id_] = (unsigned short)c0;
           if (64 + lane_id_ < left) plist[64 + lane_id_] = (unsigned short)c1;
         }
@@ -1527,6 +1611,9 @@ __device__ __forceinline__ void block_policy_step(const StepParams &p, typename 
         if (!(round_bits & 1)) break;  // block-uniform
       }
       if (any_impact) __syncthreads();  // (block-uniform: the translations written behind the last round's barrier)
+      // my target speed from the slot this section's publish wrote it to (the same double): the list pass above -- the SAT -- is where
+      // the kernel's register pressure peaks, and this way the pair is not held across it
+      me.ts = sh.ts[i];
       if (active && sh.jmax[i] >= 0) {
         me.impx = sh.aux1[i];
         me.impy = sh.ipy[i];

@@ -76,11 +76,13 @@ def test_workgroup_kernel_allocation(res):
     """hwy_step_kernel<W, WPE> (N > 64: W wavefronts per environment).  The 3-wave builds hold no spills; the 4-wave builds
     (batches beyond 3 resident wavefronts per SIMD) carried 16 .. 34 spilled VGPRs through round 5 -- the SAT's interleaved axis
     directions on top of the frame loop's state, and the sparse-checker loop unrolled over the workgroup's wavefronts with one
-    inlined SAT each -- and hold none since round 6."""
+    inlined SAT each -- and hold at most 2 since round 6 (none before the abort rule moved to the per-thread rank-space chain:
+    the post-allocation liveness of the frame loop peaks at 125 registers, inside the SAT, and the allocator needs 130 for it; the
+    chain is worth 12.5 us of 215 at 1024 x 201 with those two in scratch, profiles/r06_history.md section 7)."""
     for w in (1, 2, 3, 4):
         r3, r4 = res[f"hwy::hwy_step_kernel<{w}, 3>"], res[f"hwy::hwy_step_kernel<{w}, 4>"]
         assert r3["vgpr_spill"] == 0 and waves_per_simd(r3["vgpr"]) >= 3, r3
-        assert waves_per_simd(r4["vgpr"]) >= 4 and r4["vgpr_spill"] == 0, r4
+        assert waves_per_simd(r4["vgpr"]) >= 4 and r4["vgpr_spill"] <= 2, r4
         assert r3["workgroup"] == 64 * w and r3["lds"] == r4["lds"]
         # LDS never limits below what the registers allow: (waves/SIMD x 4 SIMDs) / W workgroups per CU
         assert (12 // w) * r3["lds"] <= LDS_PER_CU and (16 // w) * r4["lds"] <= LDS_PER_CU, (r3, r4)

@@ -259,6 +259,108 @@ def test_one_wavefront_abort_chain_on_the_emulator():
         emu._lib = saved
 
 
+def test_workgroup_kernel_abort_chain_against_its_literal_build():
+    """Round 6: the workgroup kernel (hwy_device.h section D, the N > 128 path) resolves the abort rule per thread in rank space too
+    -- one workgroup ballot per round instead of one barrier per changer.  Against a build of the same kernel with the literal
+    link-by-link chain (-DHWY_BLOCK_LITERAL_CHAIN), bit for bit, on dense traffic at N = 201 (four wavefronts) and N = 90 (two);
+    a build that never applies a verdict must fail the same comparison."""
+    import ctypes as C
+    import tests.emu.emu as emu
+
+    def soak(E, T, n, lanes):
+        cfg_d = _abi.highway_default_config()
+        cfg_d.update({"vehicles_count": n, "lanes_count": lanes, "vehicles_density": 2.2, "duration": 12, "tuning": {"block_kernel": 1}})
+        block = make_engine("emu", _abi.make_config(cfg_d, E, fast=False))
+        cfg = _abi.make_config(cfg_d, E, fast=False)
+        st = spawn.spawn_reference_stream(cfg, np.arange(E) + 51, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+        block.set_state(_abi.copy_state(st))
+        block.set_autoreset(True, base_seed=9, ego_spacing=cfg_d["ego_spacing"], vehicles_density=cfg_d["vehicles_density"])
+        rng = np.random.default_rng(6)
+        trace = []
+        for t in range(T):
+            block.step(rng.integers(0, 5, size=(E, 1)).astype(np.int32))
+            trace.append(block.get_state())
+        block.close()
+        return trace
+
+    def same(a, b):
+        for t, (x, y) in enumerate(zip(a, b)):
+            _assert_same(x, y, f"step {t}")
+
+    emu.build()
+    runs = ((2, 10, 200, 4), (4, 12, 89, 3))
+    ours = [soak(*r) for r in runs]
+    assert sum(int((s["lane"] != s["target_lane"]).sum()) for tr in ours for s in tr) > 20
+    src = emu.os.path.join(emu._HERE, "emu_engine.cpp")
+    saved = emu._lib
+    try:
+        for flag, lib, must_match in (("-DHWY_BLOCK_LITERAL_CHAIN=1", "libhwy_emu_block_literal.so", True),
+                                      ("-DHWY_BLOCK_MUTANT_NO_ABORT=1", "libhwy_emu_block_noabort.so", False)):
+            path = emu.os.path.join(emu._HERE, "_build", lib)
+            emu.compile_emulator(src, path, [flag])
+            emu._lib = C.CDLL(path)
+            emu._lib.emu_config_size.restype = C.c_size_t
+            theirs = [soak(*r) for r in runs]
+            if must_match:
+                for a, b in zip(ours, theirs):
+                    same(a, b)
+            else:
+                with pytest.raises(AssertionError):
+                    for a, b in zip(ours, theirs):
+                        same(a, b)
+    finally:
+        emu._lib = saved
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("n_other,kernel", [(8, 0), (8, 1), (80, 2), (80, 1), (140, 1)], ids=["wave", "block_small", "wide", "block_2w", "block_3w"])
+def test_abort_chain_of_depth_two_vs_oracle(backend, n_other, kernel):
+    """A directed chain of depth two (behavior.py:229-244): r0 (lane 2 -> 1, nobody ahead) keeps going; c1 (lane 0 -> 1, 30 m behind
+    r0) is blocked by r0; c2 (lane 2 -> 1, 35 m behind c1, 65 m behind r0) is blocked by c1 ONLY while c1 still heads for lane 1.
+    In list order r0, c1, c2 the literal chain lets c1 abort first and c2 go on; in list order c2 < c1 the rule reads c1's
+    frame-start target and c2 aborts too.  Every kernel family resolves this per thread by a fixed-point iteration -- all six list
+    orders against the oracle's literal loop, and the two outcomes spelled out."""
+    import itertools
+    cfg_d = _abi.highway_default_config()
+    cfg_d.update({"vehicles_count": n_other, "lanes_count": 4, "tuning": {"block_kernel": kernel}})
+    perms = list(itertools.permutations((1, 2, 3)))
+    E = len(perms)
+    cfg = _abi.make_config(cfg_d, E, fast=False)
+    st = spawn.spawn_reference_stream(cfg, np.arange(E) + 9, cfg_d["ego_spacing"], cfg_d["vehicles_density"], cfg_d["initial_lane_id"])
+    N = st["x"].shape[1]
+    # everybody else: far ahead on lane 3, one behind the other, no decision due
+    st["x"][:, :] = 2000.0 + 40.0 * np.arange(N)[None, :]
+    st["y"][:, :] = 12.0
+    st["heading"][:, :] = 0.0
+    st["speed"][:, :] = 20.0
+    st["target_speed"][:, :] = 20.0
+    st["lane"][:, :] = 3
+    st["target_lane"][:, :] = 3
+    st["timer"][:, :] = 0.0
+    st["impact_x"][:, :] = 0.0
+    st["impact_y"][:, :] = 0.0
+    st["flags"][:, 1:] &= ~(_abi.F_CRASHED | _abi.F_HAS_IMPACT)
+    for e, (ir0, ic1, ic2) in enumerate(perms):
+        for idx, x, lane in ((ir0, 130.0, 2), (ic1, 100.0, 0), (ic2, 65.0, 2)):
+            st["x"][e, idx] = x
+            st["y"][e, idx] = 4.0 * lane
+            st["lane"][e, idx] = lane
+            st["target_lane"][e, idx] = 1
+    ref = _abi.copy_state(st)
+    eng = make_engine(backend, cfg)
+    eng.set_state(st)
+    eng.step_frames(np.full((E, 1), 1, np.int32), 1)
+    oracle.frames(cfg, ref, np.full((E, 1), 1, np.int32), 1)
+    got = eng.get_state()
+    np.testing.assert_array_equal(got["target_lane"], ref["target_lane"])
+    assert_state_close(got, ref, atol=1e-9, what="depth-two chain")
+    for e, (ir0, ic1, ic2) in enumerate(perms):
+        assert got["target_lane"][e, ir0] == 1 and got["target_lane"][e, ic1] == 0, (e, got["target_lane"][e, :4])
+        # c2 goes on exactly when c1 acted (and aborted) before it
+        assert got["target_lane"][e, ic2] == (1 if ic1 < ic2 else 2), (e, got["target_lane"][e, :4])
+    eng.close()
+
+
 def test_abort_chain_window_bound_dominates_the_desired_gap():
     """The wide kernel's abort chain stops walking the vehicles ahead of a changer at
     bound = (10 + 1.5 v + v (v + 5) / (2 sqrt(ab))) (1 + 1e-6) + 1e-6, claimed to dominate IDMVehicle.desired_gap(changer, rival)
