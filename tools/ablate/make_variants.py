@@ -314,7 +314,10 @@ VARIANTS = {
     "nologexp": NO_LOGEXP,
     "nosincos": [(D, sub("      sincos_bounded(me.h, &me.sh, &me.ch);\n", "      me.sh = me.h; me.ch = 1 - me.h;\n"))],
     "nosteer": [(D, sub("      tb = B::steer_tan_beta(p, me.y, me.h, inv_v, me.tgt);", "      tb = inv_v * 1e-9;"))],
-    "nochain": [(D, cutter("    // abort rule for ongoing lane changes: ordered chain", "    // ---- E. Road.act: low-level control"))],
+    "nochain": [(D, cutter("    // abort rule for ongoing lane changes (behavior.py:229-244): an ordered chain (Gauss-Seidel", "    wave_turn(turn);\n    // ---- E. Road.act: low-level control"))],
+    "nomobilb": [(D, sub("      const u64 dm = __ballot(cl || cr);", "      const u64 dm = 0;"))],
+    "nosatb": [(D, sub("              r = hwy::pair_collide(A, Bb, p.dt, &tx, &ty);", "              r = 0;"))],
+    "nolistb": [(D, sub("          const bool cand = pair >= 0 && !hwy::surely_apart(A, Bb, p.dt);", "          const bool cand = false;"))],
 }
 
 
