@@ -680,16 +680,24 @@ def main(argv=None, platform=None, emit=None):
 
     one_step, fence, outs = make_stepper(K)
 
-    t_first_launch = time.perf_counter()
     for t in range(args.warmup):
         one_step(t)
     # Clock settling (untimed, like the warm-up; --settle-ms 0 switches it off): a short command line (the driver's --warmup 5
     # --steps 20 is 5 ms of GPU work in all) would otherwise time the first milliseconds after an idle period, while the engine
     # clock is still ramping up -- measured 44.4 us per step there against 41.7 us in steady state on the same box
     # (profiles/r04_history.md).  More of the same untimed warm-up steps until the GPU has been busy for --settle-ms.
+    # The settling time counts from the END of the warm-up launches (a box's first launch loads the code object: hundreds of
+    # milliseconds of host time on a cold or busy box, during which the GPU does nothing -- counted from the first launch, as
+    # rounds 4-5 did, such a box skipped the settling altogether and timed the regions while the engine was still sampling its
+    # issue-priority turns: 48.5 us per step against 40.6 on the next box), and goes on -- bounded -- until the engine has chosen
+    # its turn (hwy_get_prio_turn state 1 = still sampling; 0 = no selection, 2 = chosen).
+    platform.synchronize(dev)
+    t_settle0 = time.perf_counter()
     settle_steps = 0
     while args.settle_ms > 0:
-        more = torch.tensor([1.0 if (time.perf_counter() - t_first_launch) * 1e3 < args.settle_ms else 0.0], device=dev)
+        busy_ms = (time.perf_counter() - t_settle0) * 1e3
+        want = busy_ms < args.settle_ms or (eng.prio_turn()[1] == 1 and busy_ms < 20 * args.settle_ms)
+        more = torch.tensor([1.0 if want else 0.0], device=dev)
         if use_dist:  # every rank must run the SAME number of rounds (each round holds collectives): go on while any rank wants to
             dist.all_reduce(more, op=dist.ReduceOp.MAX)
         if more.item() == 0.0:
@@ -729,12 +737,20 @@ def main(argv=None, platform=None, emit=None):
     # 40.96 us device step).
     kernel_ms, launches = 0.0, 0
     if os.environ.get("HWY_BENCH_NO_EVENTS") != "1":
-        n_k = min(args.steps, 1000)
+        # (at least 300 launches whatever --steps says, over the action rows of the timed regions, behind 10 launches that are not
+        #  counted: the driver's --steps 20 averaged the first 20 launches after the switch to signalled dispatches, 41.3 us where
+        #  the device step of the same run was 39.6)
+        n_k = min(max(args.steps, 300), 1000)
         eng.profile_enable(EVENT_EVERY)
-        for t in range(args.warmup, args.warmup + n_k):
-            one_step(t)
+        for j in range(10):
+            one_step(args.warmup + j % (R * args.steps))
         fence()
-        kernel_ms, launches = eng.profile_read()
+        ms0, n0 = eng.profile_read()  # (totals since profile_enable)
+        for j in range(n_k):
+            one_step(args.warmup + j % (R * args.steps))
+        fence()
+        ms1, n1 = eng.profile_read()
+        kernel_ms, launches = ms1 - ms0, n1 - n0
         eng.profile_enable(0)
     # N > 1: the same loop with ONE gather per step (what a policy that needs every step's outputs on rank 0 before it can
     # act would see), reported next to the batched number

@@ -128,7 +128,7 @@ def test_two_rank_bench_control_flow_on_gloo(tmp_path, scaling, envs, gather_eve
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "hbm"
     # both ranks stepped the same number of times: warm-up + regions (+ the one-gather-per-step leg when gathers are batched)
     extra = 0 if gather_every == 1 else (20 + min(steps, 300))
-    extra += min(steps, 1000)  # the kernel-timing region after the timed ones (every launch carries an event pair there)
+    extra += 10 + min(max(steps, 300), 1000)  # the kernel-timing region after the timed ones (every launch carries an event pair there; 10 uncounted launches first)
     # (the clock-settle rounds hold collectives: both ranks must agree on their number, whatever their own clocks say)
     assert r0["steps"] == r1["steps"] == warmup + line["settle_steps"] + repeats * steps + extra
     assert (line["settle_steps"] > 0) == (settle_ms > 0) and line["settle_steps"] % warmup == 0
