@@ -38,7 +38,13 @@ class FakeEngine:
         return 0.0, 0
 
     def prio_turn(self):
-        return 0, 0
+        # HWY_FAKE_SAMPLING="40,70": rank r's engine reports "still sampling its issue-priority turns" (state 1) until it has taken
+        # that many steps, "chosen" (2) afterwards; -1 = never finishes.  Unset: no selection (state 0).
+        spec = os.environ.get("HWY_FAKE_SAMPLING")
+        if not spec:
+            return 0, 0
+        need = int(spec.split(",")[self.rank])
+        return 256, (1 if need < 0 or self.steps < need else 2)
 
     def step_device(self, d_actions, d_obs, d_reward, d_term, d_trunc, d_speed, d_crashed):
         E, A = self.E, self.A
@@ -109,6 +115,27 @@ def _run(tmp_path, argv, world=2):
     out = str(tmp_path / "rank")
     mp.spawn(_rank_main, args=(world, port, argv, out), nprocs=world, join=True)
     return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+@pytest.mark.parametrize("sampling,chosen", [("40,90", True), ("10,-1", False)])
+def test_settling_goes_on_until_the_engine_has_chosen_its_turn(tmp_path, monkeypatch, sampling, chosen):
+    """bench.py's untimed settling (round 6): counted from the END of the warm-up launches, and continued -- every rank the same
+    number of rounds, bounded by 20 x --settle-ms -- while ANY rank's engine is still sampling its issue-priority turns.  A cold box
+    whose first launch outlasted --settle-ms used to skip the settling and time the sampling (profiles/r06_history.md section 8)."""
+    monkeypatch.setenv("HWY_FAKE_SAMPLING", sampling)
+    steps, warmup, repeats = 4, 5, 2
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--repeats", str(repeats), "--envs-per-gpu", "4",
+            "--gather-every", "1", "--settle-ms", "2", "--no-cpu-baseline"]
+    r0, r1 = _run(tmp_path, argv)
+    line = r0["lines"][0]
+    assert r0["steps"] == r1["steps"]  # (the settle rounds hold collectives: both ranks ran the same number)
+    settle = line["settle_steps"]
+    assert settle > 0 and settle % warmup == 0
+    turn = line["config"]["issue_priority_turn"]
+    if chosen:  # the slower rank needed 90 steps: the settling covered them although 2 ms of the fake engine are a handful of steps
+        assert warmup + settle >= 90 and turn["chosen_by"] == "engine (timed its first launches)", (settle, turn)
+    else:       # rank 1 never finishes: the bound (20 x 2 ms) ends the settling and the line says so (rank 0 reports its own state)
+        assert turn["chosen_by"] in ("engine (timed its first launches)", "engine, still sampling")
 
 
 @pytest.mark.parametrize("scaling,envs,gather_every,settle_ms", [("weak", 6, 4, 0), ("strong", 8, 1, 0), ("weak", 4, 4, 30)])
