@@ -288,7 +288,7 @@ def test_workgroup_kernel_abort_chain_against_its_literal_build():
             _assert_same(x, y, f"step {t}")
 
     emu.build()
-    runs = ((2, 10, 200, 4), (4, 12, 89, 3))
+    runs = ((1, 9, 200, 4), (3, 10, 89, 3))
     ours = [soak(*r) for r in runs]
     assert sum(int((s["lane"] != s["target_lane"]).sum()) for tr in ours for s in tr) > 20
     src = emu.os.path.join(emu._HERE, "emu_engine.cpp")
