@@ -470,6 +470,8 @@ def secondary_workloads(steps: int = 200, repeats: int = 3, budget_s: float = 10
                             "roofline_frac_hbm": rf["frac"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
                             # the ceiling that binds these kernels (None unless profiles/ holds SQ counters of THIS build)
                             "valu_issue": v.get("valu_issue"), "valu_issue_floor_us": v.get("valu_issue_floor_us"),
+                            "issue_any": v.get("issue_any"), "issue_any_of_mean_wavefront_life": v.get("issue_any_of_mean_wavefront_life"),
+                            "binding_issue_limit": v.get("binding_issue_limit"), "waves_per_simd": v.get("waves_per_simd"),
                             "wait_fraction_of_a_wavefront": v.get("wait_fraction_of_a_wavefront"),
                             "valu_active_fraction_of_a_wavefront": v.get("valu_active_fraction_of_a_wavefront")}
         except Exception as ex:  # a report next to the headline, never a reason to lose the headline
