@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 # HWY_FUZZ_BACKEND=emu replays a chunk on the CPU emulator of the kernel source (tests/emu): `pytest -m gpu` with that variable set
 # needs no GPU -- how a failing chunk of a large GPU run (HWY_FUZZ_CHUNKS) is taken apart
 BACKEND = os.environ.get("HWY_FUZZ_BACKEND", "hip")
-# HWY_FUZZ_CHUNKS chunks starting at HWY_FUZZ_FIRST (a chunk's seed is its number: large runs continue where the last one ended)
-CHUNKS = range(int(os.environ.get("HWY_FUZZ_FIRST", "0")), int(os.environ.get("HWY_FUZZ_FIRST", "0")) + int(os.environ.get("HWY_FUZZ_CHUNKS", "25")))
+# HWY_FUZZ_CHUNKS chunks starting at HWY_FUZZ_FIRST (a chunk's seed is its number: large runs continue where the last one ended).
+# The default -- what the round driver's `pytest -m gpu` runs -- is 100 chunks per family: ~0.23 s each on the MI355X.
+CHUNKS = range(int(os.environ.get("HWY_FUZZ_FIRST", "0")), int(os.environ.get("HWY_FUZZ_FIRST", "0")) + int(os.environ.get("HWY_FUZZ_CHUNKS", "100")))
 
 # whole-step coverage of the intersection fuzz (printed per chunk): the rest are env-steps in which some car is below 1 m/s.
 # A per-chunk statistic over 6 random configurations: of 150 chunks on the GPU one fell to 38.8 %, the others stay above 40 %.
